@@ -1,0 +1,173 @@
+/*
+ * pinkhip.h -- C ABI of the MI355X (gfx950) batched differential-IK solver.
+ *
+ * The reference (stephane-caron/pink) has no FFI: its seam is Python.  The
+ * entry points below are what a binding for the per-step hot path would call;
+ * each one cites the reference code it replaces (paths relative to the
+ * reference checkout).  Everything is `extern "C"`, plain pointers and sizes,
+ * no exceptions cross the boundary, no PyTorch/pybind types.
+ *
+ * Conventions
+ *   - all floating point data is IEEE fp64, C-contiguous;
+ *   - every function returns 0 on success or a negative PINKHIP_E_* code, with
+ *     a message available from pinkhip_last_error();
+ *   - per-instance solver outcomes are reported in `status[B]`
+ *     (PINKHIP_STATUS_*), mirroring the `found` flag that makes
+ *     pink/solve_ik.py:271-273 raise NoSolutionFound;
+ *   - a handle is bound to ONE device and is not thread-safe; distinct handles
+ *     are independent (one process / one handle per GPU when sharding a batch);
+ *   - "_host" entry points take host pointers the caller owns (copied in and
+ *     out, synchronous); "_device" entry points take device pointers on the
+ *     handle's device and only enqueue work on the handle's stream.
+ */
+#ifndef PINKHIP_H
+#define PINKHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINKHIP_VERSION 100
+
+/* API-level error codes (negative). */
+#define PINKHIP_OK 0
+#define PINKHIP_E_INVALID (-1)     /* bad argument / unsupported shape          */
+#define PINKHIP_E_HIP (-2)         /* a HIP runtime call failed                 */
+#define PINKHIP_E_NOMEM (-3)       /* device or host allocation failed          */
+#define PINKHIP_E_NODEVICE (-4)    /* no usable gfx950 device                   */
+#define PINKHIP_E_UNSUPPORTED (-5) /* feature reserved in the ABI (n_eq > 0)    */
+#define PINKHIP_E_COMM (-6)        /* RCCL failure                              */
+
+/* Per-instance outcome (status[b]); anything non-zero maps to
+ * pink.exceptions.NoSolutionFound (pink/exceptions.py:49-67). */
+#define PINKHIP_STATUS_OPTIMAL 0
+#define PINKHIP_STATUS_MAX_ITER 1
+#define PINKHIP_STATUS_INFEASIBLE 2 /* quadprog: "constraints are inconsistent"        */
+#define PINKHIP_STATUS_NOT_PD 3     /* quadprog: "matrix G is not positive definite"   */
+
+#define PINKHIP_TASK_DENSE 0    /* rows of J stored                                      */
+#define PINKHIP_TASK_DIAGONAL 1 /* J = eye(nv)[col0:col0+k] (pink/tasks/posture_task.py:128-129) */
+
+#define PINKHIP_MAX_NV 64 /* tangent dimension supported by the wave-per-QP kernels */
+#define PINKHIP_MAX_MD 32 /* dense inequality rows per instance                      */
+
+typedef struct pinkhip_handle pinkhip_handle;
+
+/*
+ * Shape of one batch of IK problems.  Replaces the per-call Python state of
+ * pink.build_ik (pink/solve_ik.py:152-203): the task list with each task's
+ * cost/gain/lm_damping (pink/tasks/task.py:38-64), `damping`, `dt`.
+ *
+ *   rows of `e` / `cost`:  the Kd rows of the dense tasks first (task after
+ *   task), then the rows of the diagonal tasks.  task_rows[t]..task_rows[t+1]
+ *   are the rows of task t; dense tasks must precede diagonal ones.
+ */
+typedef struct pinkhip_desc {
+  int64_t B;   /* instances in this call                                       */
+  int32_t nv;  /* tangent dimension (configuration.model.nv), 1..PINKHIP_MAX_NV */
+  int32_t T;   /* number of tasks                                               */
+  int32_t Kd;  /* rows of dense-task Jacobians per instance                     */
+  int32_t K;   /* all task rows per instance (= task_rows[T])                   */
+  int32_t md;  /* dense inequality rows per instance, 0..PINKHIP_MAX_MD         */
+  int32_t n_eq; /* reserved: equality rows (constraints=, solve_ik.py:125-149); must be 0 */
+  const int32_t *task_rows;  /* [T+1] host                                      */
+  const int32_t *task_kind;  /* [T]   host, PINKHIP_TASK_*                      */
+  const int32_t *task_col0;  /* [T]   host, first tangent column of a diagonal task */
+  const double *gain;        /* [T]   host, Task.gain (task.py:146)             */
+  const double *lm_damping;  /* [T]   host, Task.lm_damping (task.py:160)       */
+  int32_t n_barriers;        /* barrier row groups among the md dense rows      */
+  const int32_t *barrier_rows;    /* [n_barriers+1] host, offsets into the md rows */
+  const double *barrier_safe_gain; /* [n_barriers] host, safe_displacement_gain
+                                      (barrier.py:193-200): adds r/||J_h||_F^2 I */
+  double damping;            /* Tikhonov weight, solve_ik.py:55                 */
+  double dt;                 /* timestep: barrier rows are -J_h/dt (barrier.py:246) */
+  int32_t cost_is_batched;   /* cost is [B,K] instead of [K]                    */
+  int32_t max_iter;          /* active-set iteration cap, <=0: 20*(nv+md)+50    */
+} pinkhip_desc;
+
+/* Per-instance data.  Host or device pointers depending on the entry point.
+ *   J   [B,Kd,nv]  Task.compute_jacobian of the dense tasks (task.py:145)
+ *   e   [B,K]      Task.compute_error (task.py:146)
+ *   cost [K] | [B,K]  diagonal of W (task.py:148-156), already expanded per row
+ *   lb, ub [B,nv]  box merged from every +-e_i limit row
+ *                  (configuration_limit.py:117-120, velocity_limit.py:118-120);
+ *                  -inf/+inf = coordinate without that bound
+ *   Gd  [B,md,nv], hd [B,md]  remaining rows of G dq <= h (solve_ik.py:107-122)
+ *   c_extra [B,nv] or NULL   extra linear term (barrier.py:201)
+ */
+typedef struct pinkhip_problem {
+  const double *J;
+  const double *e;
+  const double *cost;
+  const double *lb;
+  const double *ub;
+  const double *Gd;
+  const double *hd;
+  const double *c_extra;
+} pinkhip_problem;
+
+/* Results.  dq [B,nv] is the QP minimiser (pink/solve_ik.py:271; the caller
+ * divides by dt for the velocity, :274).  status [B]; iters [B] may be NULL. */
+typedef struct pinkhip_result {
+  double *dq;
+  int32_t *status;
+  int32_t *iters;
+} pinkhip_result;
+
+typedef struct pinkhip_device_info {
+  int32_t device_id;
+  int32_t compute_units;
+  int32_t wavefront_size;
+  int32_t clock_mhz;
+  int64_t total_mem_bytes;
+  int64_t lds_per_cu_bytes;
+  char name[128];
+  char gcn_arch[64];
+} pinkhip_device_info;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int pinkhip_version(void);
+int pinkhip_device_count(int *count);
+/* Bind a handle to `device_id` (creates a stream and timing events). */
+int pinkhip_create(pinkhip_handle **h, int device_id);
+int pinkhip_destroy(pinkhip_handle *h);
+const char *pinkhip_last_error(const pinkhip_handle *h); /* h may be NULL */
+int pinkhip_get_device_info(const pinkhip_handle *h, pinkhip_device_info *info);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Stack + solve, replaces for B instances at once:
+ *   Task.compute_qp_objective (pink/tasks/task.py:145-167)
+ *   __compute_qp_objective / __compute_qp_inequalities (pink/solve_ik.py:54-67,107-122)
+ *   qpsolvers.solve_problem(problem, solver="quadprog") (pink/solve_ik.py:270)
+ * Host variant: copies the batch to the device, solves, copies dq/status back.
+ */
+int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
+                       const pinkhip_result *host_out);
+/* Device variant: enqueue on the handle's stream; pointers stay owned by the
+ * caller and must remain valid until pinkhip_sync(). */
+int pinkhip_solve_device(pinkhip_handle *h, const pinkhip_desc *desc,
+                         const pinkhip_problem *dev_in, const pinkhip_result *dev_out);
+
+/* Stack only (pink.build_ik's P, q: pink/solve_ik.py:198): H_out [B,nv,nv], c_out [B,nv]. */
+int pinkhip_stack_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
+                       double *H_out, double *c_out);
+int pinkhip_stack_device(pinkhip_handle *h, const pinkhip_desc *desc,
+                         const pinkhip_problem *dev_in, double *H_out, double *c_out);
+
+/* ---- device memory, stream, timing ------------------------------------- */
+int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
+int pinkhip_free(pinkhip_handle *h, void *dptr);
+int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+int pinkhip_sync(pinkhip_handle *h);
+/* HIP events recorded on the handle's stream around whatever is enqueued in
+ * between; elapsed_ms is valid after pinkhip_timer_stop returns. */
+int pinkhip_timer_start(pinkhip_handle *h);
+int pinkhip_timer_stop(pinkhip_handle *h, float *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINKHIP_H */

@@ -1,0 +1,185 @@
+"""ctypes binding of ``libpinkhip.so`` (the C ABI declared in ``include/pinkhip.h``).
+
+No PyTorch, no pybind: the host side stays plain Python + NumPy and talks to the
+HIP library through ``extern "C"`` entry points.  There is no CPU fallback: if
+the library cannot be loaded, or no gfx950 device is visible, the calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from .batch import IKBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpinkhip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+
+class PinkHipError(RuntimeError):
+    """API-level failure of the HIP library (negative return code)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"pinkhip error {code}: {message}")
+        self.code = code
+
+
+class Desc(ctypes.Structure):
+    """``pinkhip_desc``."""
+
+    _fields_ = [
+        ("B", ctypes.c_int64),
+        ("nv", ctypes.c_int32),
+        ("T", ctypes.c_int32),
+        ("Kd", ctypes.c_int32),
+        ("K", ctypes.c_int32),
+        ("md", ctypes.c_int32),
+        ("n_eq", ctypes.c_int32),
+        ("task_rows", c_int32_p),
+        ("task_kind", c_int32_p),
+        ("task_col0", c_int32_p),
+        ("gain", c_double_p),
+        ("lm_damping", c_double_p),
+        ("n_barriers", ctypes.c_int32),
+        ("barrier_rows", c_int32_p),
+        ("barrier_safe_gain", c_double_p),
+        ("damping", ctypes.c_double),
+        ("dt", ctypes.c_double),
+        ("cost_is_batched", ctypes.c_int32),
+        ("max_iter", ctypes.c_int32),
+    ]
+
+
+class Problem(ctypes.Structure):
+    """``pinkhip_problem`` (host or device addresses)."""
+
+    _fields_ = [(n, ctypes.c_void_p) for n in ("J", "e", "cost", "lb", "ub", "Gd", "hd", "c_extra")]
+
+
+class Result(ctypes.Structure):
+    """``pinkhip_result``."""
+
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dq", "status", "iters")]
+
+
+class DeviceInfo(ctypes.Structure):
+    """``pinkhip_device_info``."""
+
+    _fields_ = [
+        ("device_id", ctypes.c_int32),
+        ("compute_units", ctypes.c_int32),
+        ("wavefront_size", ctypes.c_int32),
+        ("clock_mhz", ctypes.c_int32),
+        ("total_mem_bytes", ctypes.c_int64),
+        ("lds_per_cu_bytes", ctypes.c_int64),
+        ("name", ctypes.c_char * 128),
+        ("gcn_arch", ctypes.c_char * 64),
+    ]
+
+
+# every symbol include/pinkhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
+    "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
+    "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_malloc", "pinkhip_free",
+    "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_sync", "pinkhip_timer_start",
+    "pinkhip_timer_stop",
+)
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Load ``libpinkhip.so`` (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("PINKHIP_LIBRARY", LIB_PATH)
+    if not os.path.exists(p):
+        raise PinkHipError(
+            -4, f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+        )
+    lib = ctypes.CDLL(p)
+    vp = ctypes.c_void_p
+    lib.pinkhip_version.restype = ctypes.c_int
+    lib.pinkhip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    lib.pinkhip_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.pinkhip_destroy.argtypes = [vp]
+    lib.pinkhip_last_error.argtypes = [vp]
+    lib.pinkhip_last_error.restype = ctypes.c_char_p
+    lib.pinkhip_get_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
+    for name in ("pinkhip_solve_host", "pinkhip_solve_device"):
+        getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)]
+    for name in ("pinkhip_stack_host", "pinkhip_stack_device"):
+        getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), vp, vp]
+    lib.pinkhip_malloc.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_int64]
+    lib.pinkhip_free.argtypes = [vp, vp]
+    lib.pinkhip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_sync.argtypes = [vp]
+    lib.pinkhip_timer_start.argtypes = [vp]
+    lib.pinkhip_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class PackedArgs:
+    """Keeps the NumPy buffers behind a (Desc, Problem) pair alive."""
+
+    def __init__(self, batch: IKBatch, max_iter: int = 0):
+        self.batch = batch
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        self.task_rows = i32(batch.task_rows)
+        self.task_kind = i32(batch.task_kind)
+        self.task_col0 = i32(batch.task_col0)
+        self.gain = f64(batch.gain)
+        self.lm = f64(batch.lm_damping)
+        self.barrier_rows = i32(batch.barrier_rows)
+        self.barrier_safe_gain = f64(batch.barrier_safe_gain)
+        self.J, self.e, self.cost = f64(batch.J), f64(batch.e), f64(batch.cost)
+        self.lb, self.ub = f64(batch.lb), f64(batch.ub)
+        self.Gd, self.hd = f64(batch.Gd), f64(batch.hd)
+        self.c_extra = None if batch.c_extra is None else f64(batch.c_extra)
+        B, nv = batch.B, batch.nv
+        if self.J.shape != (B, batch.Kd, nv) or self.lb.shape != (B, nv) or self.ub.shape != (B, nv):
+            raise ValueError("inconsistent batch shapes")
+        if self.Gd.shape != (B, batch.md, nv) or self.hd.shape != (B, batch.md):
+            raise ValueError("inconsistent dense-row shapes")
+        d = Desc()
+        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, batch.T, batch.Kd, batch.K, batch.md, 0
+        d.task_rows = self.task_rows.ctypes.data_as(c_int32_p)
+        d.task_kind = self.task_kind.ctypes.data_as(c_int32_p)
+        d.task_col0 = self.task_col0.ctypes.data_as(c_int32_p)
+        d.gain = self.gain.ctypes.data_as(c_double_p)
+        d.lm_damping = self.lm.ctypes.data_as(c_double_p)
+        d.n_barriers = int(self.barrier_safe_gain.size)
+        d.barrier_rows = self.barrier_rows.ctypes.data_as(c_int32_p)
+        d.barrier_safe_gain = self.barrier_safe_gain.ctypes.data_as(c_double_p)
+        d.damping, d.dt = float(batch.damping), float(batch.dt)
+        d.cost_is_batched = int(self.cost.ndim == 2)
+        d.max_iter = int(max_iter)
+        self.desc = d
+
+    def host_problem(self) -> Problem:
+        p = Problem()
+        p.J, p.e, p.cost = self.J.ctypes.data, self.e.ctypes.data, self.cost.ctypes.data
+        p.lb, p.ub = self.lb.ctypes.data, self.ub.ctypes.data
+        p.Gd, p.hd = self.Gd.ctypes.data, self.hd.ctypes.data
+        p.c_extra = None if self.c_extra is None else self.c_extra.ctypes.data
+        return p
+
+    def streams(self):
+        """(name, array) pairs of the per-instance inputs, for device uploads."""
+        out = [("J", self.J), ("e", self.e), ("cost", self.cost), ("lb", self.lb), ("ub", self.ub),
+               ("Gd", self.Gd), ("hd", self.hd)]
+        if self.c_extra is not None:
+            out.append(("c_extra", self.c_extra))
+        return out

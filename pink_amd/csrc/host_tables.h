@@ -1,0 +1,89 @@
+// Host-side validation of a pinkhip_desc and expansion of its task list into the
+// small broadcast tables the kernels read (per-row gain / lm_damping, diagonal
+// task map).  Plain C++ (no HIP) so that the CPU wave emulator used by the test
+// suite shares it with the real library.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pinkhip.h"
+
+namespace pinkhip {
+
+struct HostTables {
+  std::vector<double> row_gain, row_lm;
+  std::vector<int32_t> dtask_col0, dtask_row0, dtask_k;
+  std::vector<int32_t> barrier_rows;
+  std::vector<double> barrier_safe_gain;
+};
+
+// Padded kernel dimension for a tangent dimension nv (0 if unsupported).
+inline int padded_nv(int nv) {
+  static const int sizes[] = {8, 16, 24, 32, 40, 48, 56, 64};
+  for (int s : sizes)
+    if (nv <= s) return s;
+  return 0;
+}
+
+// Returns an empty string when `d` is well-formed, otherwise what is wrong.
+inline std::string build_tables(const pinkhip_desc &d, HostTables &t) {
+  if (d.B < 0) return "B must be >= 0";
+  if (d.nv < 1 || d.nv > PINKHIP_MAX_NV) return "nv must be in 1..PINKHIP_MAX_NV";
+  if (d.md < 0 || d.md > PINKHIP_MAX_MD) return "md must be in 0..PINKHIP_MAX_MD";
+  if (d.n_eq != 0) return "equality constraints (n_eq > 0) are reserved in this ABI";
+  if (d.T < 0 || d.Kd < 0 || d.K < d.Kd) return "need T >= 0 and 0 <= Kd <= K";
+  if (d.T > 0 && (!d.task_rows || !d.task_kind || !d.gain || !d.lm_damping))
+    return "task tables must not be NULL when T > 0";
+  if (!(d.dt > 0.0) || !std::isfinite(d.dt)) return "dt must be a positive finite number";
+  if (!std::isfinite(d.damping) || d.damping < 0.0) return "damping must be finite and >= 0";
+  t = HostTables();
+  t.row_gain.assign(d.K, 1.0);
+  t.row_lm.assign(d.K, 0.0);
+  int row = 0;
+  bool seen_diag = false;
+  for (int i = 0; i < d.T; ++i) {
+    if (d.task_rows[i] != row) return "task_rows must start at 0 and be contiguous";
+    const int k = d.task_rows[i + 1] - d.task_rows[i];
+    if (k < 0) return "task_rows must be non-decreasing";
+    if (d.task_kind[i] == PINKHIP_TASK_DENSE) {
+      if (seen_diag) return "dense tasks must precede diagonal tasks";
+    } else if (d.task_kind[i] == PINKHIP_TASK_DIAGONAL) {
+      if (!seen_diag && row != d.Kd) return "dense task rows must add up to Kd";
+      seen_diag = true;
+      if (!d.task_col0) return "task_col0 must not be NULL with diagonal tasks";
+      const int c0 = d.task_col0[i];
+      if (c0 < 0 || c0 + k > d.nv) return "diagonal task exceeds the tangent space";
+      t.dtask_col0.push_back(c0);
+      t.dtask_row0.push_back(row);
+      t.dtask_k.push_back(k);
+    } else {
+      return "unknown task kind";
+    }
+    for (int r = 0; r < k; ++r) {
+      t.row_gain[row + r] = d.gain[i];
+      t.row_lm[row + r] = d.lm_damping[i];
+    }
+    row += k;
+  }
+  if (row != d.K) return "task_rows[T] must equal K";
+  if (!seen_diag && row != d.Kd) return "dense task rows must add up to Kd";
+  if (d.n_barriers < 0) return "n_barriers must be >= 0";
+  if (d.n_barriers > 0) {
+    if (!d.barrier_rows || !d.barrier_safe_gain) return "barrier tables must not be NULL";
+    for (int i = 0; i <= d.n_barriers; ++i) {
+      const int r = d.barrier_rows[i];
+      if (r < 0 || r > d.md || (i > 0 && r < d.barrier_rows[i - 1]))
+        return "barrier_rows must be non-decreasing offsets into the md dense rows";
+      t.barrier_rows.push_back(r);
+    }
+    for (int i = 0; i < d.n_barriers; ++i) t.barrier_safe_gain.push_back(d.barrier_safe_gain[i]);
+  } else {
+    t.barrier_rows.push_back(0);
+  }
+  return std::string();
+}
+
+}  // namespace pinkhip

@@ -1,0 +1,227 @@
+"""Synthetic batches shaped like the BASELINE.json configurations.
+
+No robot description is available offline (the reference pulls URDFs from the
+network through ``robot_descriptions``), so the configurations are
+*dimension-faithful stand-ins*: the task stacks, costs, gains and timestep come
+from the reference's examples, the Jacobians/errors/bounds are random with the
+distributions fixed in SURVEY.md section 8(d).
+
+``make_terms`` returns the problem as *terms* (what ``Task.compute_jacobian`` /
+``compute_error`` and ``Limit.compute_qp_inequalities`` would return for each
+instance).  ``pack`` turns terms into the packed :class:`pink_amd.batch.IKBatch`
+the HIP path consumes; ``pink_form`` expands the same terms the way Pink itself
+assembles them (identity Jacobians materialised, every limit as ``[P; -P]``
+rows, duplicated directions included) which is what the CPU oracle consumes.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .batch import BarrierTerm, DenseTaskTerm, DiagonalTaskTerm, IKBatch, pack_terms
+
+SEED0 = 20260924
+
+CONFIGS: Dict[str, dict] = {
+    # examples/arm_ur5.py:33-42,62-63 -- UR5, one FrameTask (lm_damping 1) + PostureTask 1e-3
+    "ur5": dict(config_id=2, nv=6, root_nv=0, dt=1.0 / 200.0,
+                frame_costs=[(1.0, 1.0)], frame_lm=1.0, posture_cost=1e-3, n_barriers=0),
+    # examples/humanoid_draco3.py:69-91 -- 4 FrameTasks + PostureTask 1e-1 (nv = 30 stand-in)
+    "draco3": dict(config_id=3, nv=30, root_nv=6, dt=5e-3,
+                   frame_costs=[(1.0, 1.0), (1.0, 0.0), (1.0, 1.0), (4.0, 4.0)], frame_lm=0.0,
+                   posture_cost=1e-1, n_barriers=0),
+    # examples/humanoid_jvrc.py:69-80 (+ posture task, + 2 position barriers as
+    # examples/barriers/arm_ur5.py:50-57) -- JVRC-1 has nv = 50
+    "jvrc": dict(config_id=4, nv=50, root_nv=6, dt=5e-3,
+                 frame_costs=[(1.0, 3.0), (1.0, 0.0), (1.0, 3.0), (1.0, 3.0)], frame_lm=0.0,
+                 posture_cost=1e-1, n_barriers=2),
+}
+
+
+@dataclass
+class Terms:
+    """One synthetic batch as per-term arrays (see module docstring)."""
+
+    name: str
+    nv: int
+    root_nv: int
+    dt: float
+    damping: float
+    dense_tasks: List[DenseTaskTerm]
+    diag_tasks: List[DiagonalTaskTerm]
+    # limits as Pink emits them: two boxes on the actuated coordinates
+    cfg_lo: np.ndarray  # [B, n_b]  gamma (q_min - q)   (configuration_limit.py:111-120)
+    cfg_hi: np.ndarray  # [B, n_b]  gamma (q_max - q)
+    vel: np.ndarray  # [B, n_b]  dt v_max            (velocity_limit.py:118-120)
+    limit_idx: np.ndarray  # [n_b] tangent indices carrying limits
+    barriers: List[BarrierTerm] = field(default_factory=list)
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def B(self) -> int:
+        return self.cfg_lo.shape[0]
+
+
+def _frame_jacobians(rng, B, nv, root_nv, n_frames, mode):
+    if mode == "dense":
+        return [rng.normal(0.0, 0.5, size=(B, 6, nv)) for _ in range(n_frames)]
+    # kinematic-like: body Jacobian of a frame at the end of a chain
+    out = []
+    n_act = nv - root_nv
+    for _ in range(n_frames):
+        J = np.zeros((B, 6, nv))
+        if root_nv:
+            # floating base: [R^T, -R^T [p]x; 0, R^T]-like block, random rotation/lever
+            A = rng.normal(size=(B, 3, 3))
+            Q, _ = np.linalg.qr(A)
+            p = rng.uniform(-1.0, 1.0, size=(B, 3))
+            px = np.zeros((B, 3, 3))
+            px[:, 0, 1], px[:, 0, 2] = -p[:, 2], p[:, 1]
+            px[:, 1, 0], px[:, 1, 2] = p[:, 2], -p[:, 0]
+            px[:, 2, 0], px[:, 2, 1] = -p[:, 1], p[:, 0]
+            J[:, :3, :3] = Q
+            J[:, :3, 3:6] = -Q @ px
+            J[:, 3:, 3:6] = Q
+        chain = int(rng.integers(6, 8)) if n_act >= 7 else n_act
+        start = int(rng.integers(0, n_act - chain + 1))
+        cols = root_nv + start + np.arange(chain)
+        axis = rng.normal(size=(B, chain, 3))
+        axis /= np.linalg.norm(axis, axis=2, keepdims=True)
+        lever = rng.uniform(0.0, 1.0, size=(B, chain, 1)) * rng.normal(size=(B, chain, 3))
+        lin = np.cross(axis, lever)
+        J[:, :3, cols] = np.swapaxes(lin, 1, 2)
+        J[:, 3:, cols] = np.swapaxes(axis, 1, 2)
+        # -Jlog6-like factor close to -identity (frame_task.py:222-227)
+        M = -np.eye(6)[None] + 0.1 * rng.normal(size=(B, 6, 6))
+        out.append(M @ J)
+    return out
+
+
+def make_terms(
+    name: str,
+    B: int,
+    bounds: str = "tight",
+    jacobians: str = "dense",
+    seed: Optional[int] = None,
+    damping: float = 1e-12,
+) -> Terms:
+    """Draw one batch.  ``bounds``: ``"tight"`` (about 45 % of the boxes active,
+    the solver stress case) or ``"kinematic"`` (realistic joint-limit geometry,
+    few active bounds); ``jacobians``: ``"dense"`` or ``"kinematic"``."""
+    cfg = CONFIGS[name]
+    nv, root_nv, dt = cfg["nv"], cfg["root_nv"], cfg["dt"]
+    rng = np.random.default_rng(SEED0 + cfg["config_id"] if seed is None else seed)
+    n_frames = len(cfg["frame_costs"])
+    Js = _frame_jacobians(rng, B, nv, root_nv, n_frames, jacobians)
+    dense = []
+    for Jt, (pc, oc) in zip(Js, cfg["frame_costs"]):
+        e = 0.1 * rng.normal(size=(B, 6))
+        cost = np.array([pc] * 3 + [oc] * 3)  # frame_task.py:71-127: [pos x3, ori x3]
+        dense.append(DenseTaskTerm(J=Jt, e=e, cost=cost, gain=1.0, lm_damping=cfg["frame_lm"]))
+    n_act = nv - root_nv
+    e_post = rng.uniform(-1.0, 1.0, size=(B, n_act)) * (1.0 if name == "ur5" else 0.5)
+    diag = [DiagonalTaskTerm(col0=root_nv, e=e_post, cost=cfg["posture_cost"], gain=1.0, lm_damping=0.0)]
+
+    idx = root_nv + np.arange(n_act)
+    if bounds == "tight":
+        cfg_hi = rng.uniform(0.002, 0.05, size=(B, n_act))
+        cfg_lo = -rng.uniform(0.002, 0.05, size=(B, n_act))
+        vel = rng.uniform(0.002, 0.05, size=(B, n_act))
+    elif bounds == "kinematic":
+        q_max, q_min = np.pi, -np.pi
+        q = rng.uniform(q_min, q_max, size=(B, n_act))
+        near = rng.random(size=(B, n_act)) < 0.05
+        side = rng.random(size=(B, n_act)) < 0.5
+        eps = rng.uniform(0.0, 1e-3, size=(B, n_act))
+        q = np.where(near & side, q_max - eps, q)
+        q = np.where(near & ~side, q_min + eps, q)
+        cfg_hi = 0.5 * (q_max - q)
+        cfg_lo = 0.5 * (q_min - q)
+        vel = dt * rng.uniform(1.0, 10.0, size=(B, n_act))
+    else:
+        raise ValueError(bounds)
+
+    barriers = []
+    for _ in range(cfg["n_barriers"]):
+        # PositionBarrier with p_min on x, y, z of one frame (position_barrier.py:109-153)
+        axis = rng.normal(size=(B, nv, 3))
+        J_p = 0.3 * np.swapaxes(axis, 1, 2) * (rng.random(size=(B, 1, nv)) < 0.4)
+        J_p[:, :, :3] = np.eye(3)[None] if root_nv else J_p[:, :, :3]
+        h_val = rng.uniform(0.0, 0.05, size=(B, 3))
+        barriers.append(BarrierTerm(J_h=J_p, h=h_val, gain=100.0, safe_displacement_gain=1.0))
+
+    return Terms(
+        name=name, nv=nv, root_nv=root_nv, dt=dt, damping=damping, dense_tasks=dense,
+        diag_tasks=diag, cfg_lo=cfg_lo, cfg_hi=cfg_hi, vel=vel, limit_idx=idx, barriers=barriers,
+        meta=dict(config=name, bounds=bounds, jacobians=jacobians, B=B),
+    )
+
+
+def pack(terms: Terms) -> IKBatch:
+    """Terms -> packed batch for the HIP path (limits merged into one box)."""
+    B, nv = terms.B, terms.nv
+    lo = np.full((B, nv), -np.inf)
+    hi = np.full((B, nv), np.inf)
+    lo[:, terms.limit_idx] = np.maximum(terms.cfg_lo, -terms.vel)
+    hi[:, terms.limit_idx] = np.minimum(terms.cfg_hi, terms.vel)
+    batch = pack_terms(
+        nv, list(terms.dense_tasks) + list(terms.diag_tasks), terms.dt, terms.damping,
+        boxes=[(lo, hi)], barriers=terms.barriers, batch_size=B,
+    )
+    batch.meta = dict(terms.meta)
+    return batch
+
+
+def pink_form(terms: Terms) -> dict:
+    """Terms -> the dense arrays Pink would build for each instance.
+
+    Every task dense (``J = eye[col0:col0+k]`` for diagonal tasks,
+    posture_task.py:128-129); limits as ``[P; -P]`` for the configuration limit
+    then ``[P; -P]`` for the velocity limit (solve_ik.py:94-113), barrier rows
+    last (solve_ik.py:114-119).  Returns the keyword arguments of
+    ``oracle.c_oracle.solve_ik_batch``.
+    """
+    B, nv = terms.B, terms.nv
+    Js, es, costs, gains, lms, rows = [], [], [], [], [], [0]
+    for t in terms.dense_tasks:
+        k = t.J.shape[1]
+        Js.append(t.J)
+        es.append(t.e)
+        w = np.ones(k) if t.cost is None else np.broadcast_to(np.asarray(t.cost, float), (k,))
+        costs.append(w)
+        gains.append(t.gain)
+        lms.append(t.lm_damping)
+        rows.append(rows[-1] + k)
+    for t in terms.diag_tasks:
+        k = t.e.shape[1]
+        Jt = np.broadcast_to(np.eye(nv)[t.col0:t.col0 + k], (B, k, nv))
+        Js.append(Jt)
+        es.append(t.e)
+        w = np.ones(k) if t.cost is None else np.broadcast_to(np.asarray(t.cost, float), (k,))
+        costs.append(w)
+        gains.append(t.gain)
+        lms.append(t.lm_damping)
+        rows.append(rows[-1] + k)
+    P = np.eye(nv)[terms.limit_idx]
+    G_blocks = [np.broadcast_to(np.vstack([P, -P, P, -P]), (B, 4 * P.shape[0], nv))]
+    h_blocks = [np.concatenate([terms.cfg_hi, -terms.cfg_lo, terms.vel, terms.vel], axis=1)]
+    diag_extra = None
+    for b in terms.barriers:
+        G_blocks.append(-b.J_h / terms.dt)
+        g = np.broadcast_to(np.asarray(b.gain, float), (b.h.shape[1],))
+        h_blocks.append(g * b.h)
+        if b.safe_displacement_gain > 1e-6:
+            rho = b.safe_displacement_gain / np.sum(b.J_h * b.J_h, axis=(1, 2))
+            diag_extra = rho if diag_extra is None else diag_extra + rho
+    return dict(
+        J=np.ascontiguousarray(np.concatenate(Js, axis=1)),
+        e=np.ascontiguousarray(np.concatenate(es, axis=1)),
+        cost=np.concatenate(costs), gain=np.array(gains, float), lm=np.array(lms, float),
+        rows=np.array(rows, np.int32), damping=terms.damping,
+        G=np.ascontiguousarray(np.concatenate(G_blocks, axis=1)),
+        h=np.ascontiguousarray(np.concatenate(h_blocks, axis=1)),
+        diag_extra=diag_extra,
+    )

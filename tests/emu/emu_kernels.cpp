@@ -1,0 +1,100 @@
+// Host harness that runs the HIP kernel source on the CPU wave emulator.
+// TEST INFRASTRUCTURE ONLY (see wave_emu.h).  Exposes the same struct-based
+// signature as the host entry points of include/pinkhip.h.
+#include "wave_emu.h"
+// clang-format off
+#include "../../pink_amd/csrc/ik_kernels.h"
+#include "../../pink_amd/csrc/host_tables.h"
+// clang-format on
+
+#include <string>
+
+namespace {
+
+using pinkhip::KernelArgs;
+
+template <int NV, bool SOLVE>
+void lane_main(void *p) {
+  const KernelArgs *a = static_cast<const KernelArgs *>(p);
+  pinkhip::ik_instance<NV, SOLVE>(*a, pinkhip::block_id());
+}
+
+template <bool SOLVE>
+pinkhip::LaneFn pick(int nvp) {
+  switch (nvp) {
+    case 8: return lane_main<8, SOLVE>;
+    case 16: return lane_main<16, SOLVE>;
+    case 24: return lane_main<24, SOLVE>;
+    case 32: return lane_main<32, SOLVE>;
+    case 40: return lane_main<40, SOLVE>;
+    case 48: return lane_main<48, SOLVE>;
+    case 56: return lane_main<56, SOLVE>;
+    case 64: return lane_main<64, SOLVE>;
+  }
+  return nullptr;
+}
+
+std::string g_err;
+
+int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *out, double *H_out,
+        double *c_out, bool solve) {
+  pinkhip::HostTables t;
+  g_err = pinkhip::build_tables(*d, t);
+  if (!g_err.empty()) return PINKHIP_E_INVALID;
+  KernelArgs a{};
+  a.B = d->B;
+  a.nv = d->nv;
+  a.Kd = d->Kd;
+  a.K = d->K;
+  a.md = d->md;
+  a.n_dtasks = static_cast<int>(t.dtask_k.size());
+  a.n_barriers = d->n_barriers;
+  a.cost_batched = d->cost_is_batched;
+  a.max_iter = d->max_iter;
+  a.damping = d->damping;
+  a.dt = d->dt;
+  a.J = in->J;
+  a.e = in->e;
+  a.cost = in->cost;
+  a.lb = in->lb;
+  a.ub = in->ub;
+  a.Gd = in->Gd;
+  a.hd = in->hd;
+  a.c_extra = in->c_extra;
+  a.row_gain = t.row_gain.data();
+  a.row_lm = t.row_lm.data();
+  a.dtask_col0 = t.dtask_col0.data();
+  a.dtask_row0 = t.dtask_row0.data();
+  a.dtask_k = t.dtask_k.data();
+  a.barrier_rows = t.barrier_rows.data();
+  a.barrier_safe_gain = t.barrier_safe_gain.data();
+  if (out) {
+    a.dq = out->dq;
+    a.status = out->status;
+    a.iters = out->iters;
+  }
+  a.H_out = H_out;
+  a.c_out = c_out;
+  const int nvp = pinkhip::padded_nv(d->nv);
+  pinkhip::LaneFn fn = solve ? pick<true>(nvp) : pick<false>(nvp);
+  if (!fn) {
+    g_err = "unsupported nv";
+    return PINKHIP_E_INVALID;
+  }
+  for (long long b = 0; b < d->B; ++b) pinkhip::emu_run_block(b, fn, &a);
+  return PINKHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+int pinkhip_emu_solve_host(const pinkhip_desc *d, const pinkhip_problem *in,
+                           const pinkhip_result *out) {
+  return run(d, in, out, nullptr, nullptr, true);
+}
+int pinkhip_emu_stack_host(const pinkhip_desc *d, const pinkhip_problem *in, double *H_out,
+                           double *c_out) {
+  return run(d, in, nullptr, H_out, c_out, false);
+}
+const char *pinkhip_emu_last_error(void) { return g_err.c_str(); }
+}

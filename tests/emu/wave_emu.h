@@ -1,0 +1,207 @@
+// CPU emulation of one 64-lane wavefront -- TEST INFRASTRUCTURE ONLY.
+//
+// Runs the *unmodified* kernel source (pink_amd/csrc/ik_kernels.h) on the host so
+// that the SIMT logic (lane ownership, broadcasts, LDS hand-offs) can be checked
+// without a GPU.  Each lane is a ucontext fiber; every cross-lane primitive and
+// every wave_sync() is a rendezvous of all 64 fibers (round-robin switch), which
+// reproduces lock-step semantics and additionally detects divergence: all lanes
+// must arrive at the same primitive the same number of times.
+//
+// The product never links this; pink_amd's API fails loudly without the HIP
+// library (pink_amd/_lib.py).
+#pragma once
+
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+
+namespace pinkhip {
+
+constexpr int kWave = 64;
+
+struct Emu {
+  int cur = 0;
+  long long block = 0;
+  ucontext_t main_ctx;
+  ucontext_t ctx[kWave];
+  bool done[kWave];
+  int live = 0;
+  double slot_d[kWave];
+  int slot_i[kWave];
+  long long arrivals[kWave];
+  int tag[kWave];
+  alignas(16) double lds[20480];  // 160 KiB
+  char *stacks = nullptr;
+};
+
+inline Emu &emu() {
+  static Emu e;
+  return e;
+}
+
+inline int lane_id() { return emu().cur; }
+inline long long block_id() { return emu().block; }
+inline double *shared_base() { return emu().lds; }
+
+// Switch to the next live lane; one full round == one barrier.
+inline void emu_rendezvous(int tag) {
+  Emu &e = emu();
+  const int me = e.cur;
+  e.arrivals[me]++;
+  e.tag[me] = tag;
+  int nxt = me;
+  do {
+    nxt = (nxt + 1) % kWave;
+  } while (e.done[nxt] && nxt != me);
+  if (nxt != me) {
+    e.cur = nxt;
+    swapcontext(&e.ctx[me], &e.ctx[nxt]);
+  }
+  // everybody has arrived: check lock-step
+  for (int l = 0; l < kWave; ++l) {
+    if (e.done[l]) continue;
+    if (e.arrivals[l] != e.arrivals[me] && e.arrivals[l] != e.arrivals[me] + 1 &&
+        e.arrivals[l] + 1 != e.arrivals[me]) {
+      std::fprintf(stderr, "wave emulator: divergence at lane %d vs %d (tag %d vs %d)\n", me, l,
+                   e.tag[me], e.tag[l]);
+      std::abort();
+    }
+    if (e.arrivals[l] == e.arrivals[me] && e.tag[l] != e.tag[me]) {
+      std::fprintf(stderr, "wave emulator: lanes %d and %d at different primitives (%d vs %d)\n", me,
+                   l, e.tag[me], e.tag[l]);
+      std::abort();
+    }
+  }
+}
+
+inline void wave_sync() { emu_rendezvous(1); }
+
+inline double bcast(double v, int src) {
+  Emu &e = emu();
+  e.slot_d[e.cur] = v;
+  emu_rendezvous(2);
+  if (src < 0 || src >= kWave) {
+    std::fprintf(stderr, "wave emulator: bcast from lane %d\n", src);
+    std::abort();
+  }
+  const double r = e.slot_d[src];
+  emu_rendezvous(3);
+  return r;
+}
+
+inline int bcast_i(int v, int src) {
+  Emu &e = emu();
+  e.slot_i[e.cur] = v;
+  emu_rendezvous(4);
+  if (src < 0 || src >= kWave) std::abort();
+  const int r = e.slot_i[src];
+  emu_rendezvous(5);
+  return r;
+}
+
+inline double wave_sum(double v) {
+  // same butterfly order as the device code (xor 32, 16, ..., 1)
+  Emu &e = emu();
+  for (int m = 32; m >= 1; m >>= 1) {
+    e.slot_d[e.cur] = v;
+    emu_rendezvous(6);
+    const double o = e.slot_d[e.cur ^ m];
+    emu_rendezvous(7);
+    v += o;
+  }
+  return v;
+}
+
+inline void wave_argmin(double &v, int &idx) {
+  Emu &e = emu();
+  for (int m = 32; m >= 1; m >>= 1) {
+    e.slot_d[e.cur] = v;
+    e.slot_i[e.cur] = idx;
+    emu_rendezvous(8);
+    const double ov = e.slot_d[e.cur ^ m];
+    const int oi = e.slot_i[e.cur ^ m];
+    emu_rendezvous(9);
+    const bool take = (ov < v) || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+  }
+}
+
+inline double from_next_lane(double v) {
+  Emu &e = emu();
+  e.slot_d[e.cur] = v;
+  emu_rendezvous(10);
+  const double r = e.slot_d[e.cur < kWave - 1 ? e.cur + 1 : e.cur];
+  emu_rendezvous(11);
+  return r;
+}
+
+inline int from_next_lane_i(int v) {
+  Emu &e = emu();
+  e.slot_i[e.cur] = v;
+  emu_rendezvous(12);
+  const int r = e.slot_i[e.cur < kWave - 1 ? e.cur + 1 : e.cur];
+  emu_rendezvous(13);
+  return r;
+}
+
+// Run `fn(arg)` on all 64 lanes of workgroup `block`.
+using LaneFn = void (*)(void *);
+
+struct EmuLaunch {
+  LaneFn fn;
+  void *arg;
+};
+
+inline void emu_lane_entry(unsigned lo, unsigned hi) {
+  EmuLaunch *L = reinterpret_cast<EmuLaunch *>((static_cast<unsigned long long>(hi) << 32) | lo);
+  L->fn(L->arg);
+  Emu &e = emu();
+  const int me = e.cur;
+  e.done[me] = true;
+  e.live--;
+  if (e.live == 0) {
+    setcontext(&e.main_ctx);
+  }
+  int nxt = me;
+  do {
+    nxt = (nxt + 1) % kWave;
+  } while (e.done[nxt]);
+  e.cur = nxt;
+  setcontext(&e.ctx[nxt]);
+}
+
+inline void emu_run_block(long long block, LaneFn fn, void *arg) {
+  Emu &e = emu();
+  constexpr size_t kStack = 512 * 1024;
+  if (!e.stacks) e.stacks = static_cast<char *>(std::malloc(kStack * kWave));
+  EmuLaunch L{fn, arg};
+  const unsigned long long p = reinterpret_cast<unsigned long long>(&L);
+  e.block = block;
+  e.live = kWave;
+  // poison LDS so that reads of never-written words are noticed (NaN)
+  std::memset(e.lds, 0xff, sizeof(e.lds));
+  for (int l = 0; l < kWave; ++l) {
+    e.done[l] = false;
+    e.arrivals[l] = 0;
+    e.tag[l] = 0;
+    getcontext(&e.ctx[l]);
+    e.ctx[l].uc_stack.ss_sp = e.stacks + kStack * l;
+    e.ctx[l].uc_stack.ss_size = kStack;
+    e.ctx[l].uc_link = nullptr;
+    makecontext(&e.ctx[l], reinterpret_cast<void (*)()>(emu_lane_entry), 2,
+                static_cast<unsigned>(p & 0xffffffffu), static_cast<unsigned>(p >> 32));
+  }
+  e.cur = 0;
+  swapcontext(&e.main_ctx, &e.ctx[0]);
+}
+
+}  // namespace pinkhip
