@@ -1,0 +1,193 @@
+"""Batched IK solves on one MI355X through the C ABI (``include/pinkhip.h``).
+
+``BatchSolver`` owns one ``pinkhip_handle`` (one device, one stream).  Batches
+can be solved straight from host memory (``solve``), or uploaded once and
+re-solved from HBM (``upload`` / ``solve_device`` / ``download``), which is what
+the benchmark times.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PackedArgs, PinkHipError, Problem, Result
+from .batch import IKBatch
+
+
+@dataclass
+class BatchResult:
+    """Output of one batched solve."""
+
+    dq: np.ndarray  # [B, nv] displacement (divide by dt for the velocity, solve_ik.py:274)
+    status: np.ndarray  # [B] int32, 0 = optimal (see include/pinkhip.h)
+    iters: np.ndarray  # [B] int32 active-set iterations
+
+    @property
+    def all_found(self) -> bool:
+        return bool((self.status == 0).all())
+
+    def failed_indices(self) -> np.ndarray:
+        return np.nonzero(self.status != 0)[0]
+
+
+class DeviceBatch:
+    """A batch resident in HBM together with its output buffers."""
+
+    def __init__(self, solver: "BatchSolver", args: PackedArgs):
+        self.solver = solver
+        self.args = args
+        self.ptrs: Dict[str, int] = {}
+        self.nbytes = 0
+        b = args.batch
+        for name, arr in args.streams():
+            self.ptrs[name] = solver._malloc(max(arr.nbytes, 8))
+            solver._h2d(self.ptrs[name], arr)
+            self.nbytes += arr.nbytes
+        self.d_dq = solver._malloc(max(8 * b.B * b.nv, 8))
+        self.d_status = solver._malloc(max(4 * b.B, 8))
+        self.d_iters = solver._malloc(max(4 * b.B, 8))
+        self.d_H: Optional[int] = None
+        self.d_c: Optional[int] = None
+        p = Problem()
+        for name in ("J", "e", "cost", "lb", "ub", "Gd", "hd", "c_extra"):
+            setattr(p, name, self.ptrs.get(name))
+        self.problem = p
+        r = Result()
+        r.dq, r.status, r.iters = self.d_dq, self.d_status, self.d_iters
+        self.result = r
+
+    def free(self) -> None:
+        s = self.solver
+        for ptr in list(self.ptrs.values()) + [self.d_dq, self.d_status, self.d_iters, self.d_H, self.d_c]:
+            if ptr:
+                s._free(ptr)
+        self.ptrs = {}
+        self.d_dq = self.d_status = self.d_iters = self.d_H = self.d_c = None
+
+
+class BatchSolver:
+    """One handle of the HIP library bound to ``device_id``."""
+
+    def __init__(self, device_id: int = 0, library: Optional[ctypes.CDLL] = None):
+        self._lib = library or _lib.load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.pinkhip_create(ctypes.byref(h), int(device_id))
+        if rc != 0:
+            raise PinkHipError(rc, (self._lib.pinkhip_last_error(None) or b"").decode())
+        self._h = h
+        self.device_id = device_id
+
+    # -- plumbing --------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise PinkHipError(rc, (self._lib.pinkhip_last_error(self._h) or b"").decode())
+
+    def _malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._check(self._lib.pinkhip_malloc(self._h, ctypes.byref(p), int(nbytes)))
+        return p.value
+
+    def _free(self, ptr: int) -> None:
+        self._check(self._lib.pinkhip_free(self._h, ctypes.c_void_p(ptr)))
+
+    def _h2d(self, dptr: int, arr: np.ndarray) -> None:
+        self._check(self._lib.pinkhip_memcpy_h2d(self._h, ctypes.c_void_p(dptr), arr.ctypes.data, arr.nbytes))
+
+    def _d2h(self, arr: np.ndarray, dptr: int) -> None:
+        self._check(self._lib.pinkhip_memcpy_d2h(self._h, arr.ctypes.data, ctypes.c_void_p(dptr), arr.nbytes))
+
+    def close(self) -> None:
+        if self._h is not None:
+            self._lib.pinkhip_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self) -> dict:
+        info = _lib.DeviceInfo()
+        self._check(self._lib.pinkhip_get_device_info(self._h, ctypes.byref(info)))
+        return dict(
+            device_id=info.device_id, compute_units=info.compute_units,
+            wavefront_size=info.wavefront_size, clock_mhz=info.clock_mhz,
+            total_mem_bytes=info.total_mem_bytes, lds_per_cu_bytes=info.lds_per_cu_bytes,
+            name=info.name.decode(), gcn_arch=info.gcn_arch.decode(),
+        )
+
+    # -- host-memory path ------------------------------------------------------
+    def solve(self, batch: IKBatch, max_iter: int = 0) -> BatchResult:
+        """Stack and solve every instance of ``batch`` (host buffers in, host out)."""
+        a = PackedArgs(batch, max_iter)
+        B, nv = batch.B, batch.nv
+        dq = np.zeros((B, nv))
+        status = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        r = Result()
+        r.dq, r.status, r.iters = dq.ctypes.data, status.ctypes.data, iters.ctypes.data
+        p = a.host_problem()
+        self._check(self._lib.pinkhip_solve_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r)))
+        return BatchResult(dq, status, iters)
+
+    def stack(self, batch: IKBatch) -> Tuple[np.ndarray, np.ndarray]:
+        """QP objective only: ``H [B, nv, nv]``, ``c [B, nv]`` (``build_ik``'s P, q)."""
+        a = PackedArgs(batch)
+        B, nv = batch.B, batch.nv
+        H = np.zeros((B, nv, nv))
+        c = np.zeros((B, nv))
+        p = a.host_problem()
+        self._check(self._lib.pinkhip_stack_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), H.ctypes.data, c.ctypes.data))
+        return H, c
+
+    # -- HBM-resident path -----------------------------------------------------
+    def upload(self, batch: IKBatch, max_iter: int = 0) -> DeviceBatch:
+        return DeviceBatch(self, PackedArgs(batch, max_iter))
+
+    def solve_device(self, dev: DeviceBatch) -> None:
+        """Enqueue one stack+solve pass over a resident batch (asynchronous)."""
+        self._check(self._lib.pinkhip_solve_device(self._h, ctypes.byref(dev.args.desc), ctypes.byref(dev.problem), ctypes.byref(dev.result)))
+
+    def stack_device(self, dev: DeviceBatch) -> None:
+        b = dev.args.batch
+        if dev.d_H is None:
+            dev.d_H = self._malloc(max(8 * b.B * b.nv * b.nv, 8))
+            dev.d_c = self._malloc(max(8 * b.B * b.nv, 8))
+        self._check(self._lib.pinkhip_stack_device(self._h, ctypes.byref(dev.args.desc), ctypes.byref(dev.problem), ctypes.c_void_p(dev.d_H), ctypes.c_void_p(dev.d_c)))
+
+    def download(self, dev: DeviceBatch) -> BatchResult:
+        b = dev.args.batch
+        dq = np.zeros((b.B, b.nv))
+        status = np.zeros(b.B, dtype=np.int32)
+        iters = np.zeros(b.B, dtype=np.int32)
+        if b.B:
+            self._d2h(dq, dev.d_dq)
+            self._d2h(status, dev.d_status)
+            self._d2h(iters, dev.d_iters)
+        return BatchResult(dq, status, iters)
+
+    def download_stack(self, dev: DeviceBatch) -> Tuple[np.ndarray, np.ndarray]:
+        b = dev.args.batch
+        H = np.zeros((b.B, b.nv, b.nv))
+        c = np.zeros((b.B, b.nv))
+        if b.B:
+            self._d2h(H, dev.d_H)
+            self._d2h(c, dev.d_c)
+        return H, c
+
+    def sync(self) -> None:
+        self._check(self._lib.pinkhip_sync(self._h))
+
+    def timer_start(self) -> None:
+        self._check(self._lib.pinkhip_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float(0.0)
+        self._check(self._lib.pinkhip_timer_stop(self._h, ctypes.byref(ms)))
+        return float(ms.value)

@@ -151,7 +151,10 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
       const double aa = was[k] * jki;
       ci += gs[k] * jki;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) M[j] += aa * row[j];  // row[j], j >= nv: stale but in-bounds, zeroed below
+      for (int j = 0; j < NV; ++j) {
+        M[j] += aa * row[j];  // row[j], j >= nv: stale but in-bounds, zeroed below
+        pin(M[j]);
+      }
     }
   }
   // diagonal tasks: J = eye[col0:col0+k] -> H[i][i] += w^2, c[i] += gain w^2 e  (posture_task.py:128-129)
@@ -241,7 +244,10 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
     cp = (lane > j) ? cp - lij * yj : (lane == j ? yj : cp);
     wave_sync();
 #pragma unroll
-    for (int m = j + 1; m < NV; ++m) M[m] -= lij * xs[m];
+    for (int m = j + 1; m < NV; ++m) {
+      M[m] -= lij * xs[m];
+      pin(M[m]);
+    }
     wave_sync();
   }
   // J = L^-T: lane i solves L y = e_i by forward substitution (uniform reads of L)
@@ -252,12 +258,19 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   for (int j = 0; j < NV; ++j) {
     double acc = (lane == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int m = 0; m < j; ++m) acc -= Ls[j * NVP + m] * Jr[m];
+    for (int m = 0; m < j; ++m) {
+      acc -= Ls[j * NVP + m] * Jr[m];
+      if ((m & 3) == 3) pin(acc);
+    }
     Jr[j] = acc * ds[j];
+    pin(Jr[j]);
   }
   double x = 0.0;  // unconstrained minimum x = L^-T y
 #pragma unroll
-  for (int j = 0; j < NV; ++j) x += Jr[j] * xs[j];
+  for (int j = 0; j < NV; ++j) {
+    x += Jr[j] * xs[j];
+    if ((j & 3) == 3) pin(x);
+  }
   wave_sync();
 
   // ------------------------------------------------------------------ (3) Goldfarb-Idnani
@@ -351,6 +364,10 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
       for (int j = 0; j < NV; ++j) {
         z += Jr[j] * d2s[j];
         w += Jr[j] * vs[j];
+        if ((j & 3) == 3) {
+          pin(z);
+          pin(w);
+        }
       }
       // r = R^-1 d1 (dual step direction): column-oriented back substitution
       double rv = 0.0, dp = dl;
@@ -387,7 +404,10 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
           // full step: the constraint becomes active.  J2 <- J2 H, R gains column [d1; -sgq|d2|]
           const double wb = beta * w;
 #pragma unroll
-          for (int j = 0; j < NV; ++j) Jr[j] -= wb * vs[j];
+          for (int j = 0; j < NV; ++j) {
+            Jr[j] -= wb * vs[j];
+            pin(Jr[j]);
+          }
           const double rqq = -sgq * nrm2;
           if (lane < q) Rs[q * NVP + lane] = dl;
           if (lane == q) {

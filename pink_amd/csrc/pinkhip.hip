@@ -1,0 +1,438 @@
+// libpinkhip.so -- host side of the C ABI in include/pinkhip.h (gfx950 only).
+//
+// One handle = one device, one stream, two timing events, a small device-side
+// table area for the per-descriptor broadcast constants, and a grow-only device
+// arena used by the *_host entry points.  No exceptions cross the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// clang-format off
+#include "wave.h"
+#include "ik_kernels.h"
+#include "host_tables.h"
+// clang-format on
+
+namespace {
+
+thread_local std::string g_last_error;
+
+constexpr size_t kTableBytes = 64 * 1024;
+
+}  // namespace
+
+struct pinkhip_handle {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  char *d_tables = nullptr;          // device copy of the broadcast tables
+  std::vector<char> h_tables;        // what d_tables currently holds
+  char *arena = nullptr;             // grow-only scratch of the *_host entry points
+  size_t arena_bytes = 0;
+  hipDeviceProp_t prop;
+};
+
+namespace {
+
+int fail(pinkhip_handle *h, int code, const std::string &msg) {
+  g_last_error = msg;
+  if (h) h->err = msg;
+  return code;
+}
+
+#define PH_HIP(h, call)                                                                    \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return fail(h, e__ == hipErrorOutOfMemory ? PINKHIP_E_NOMEM : PINKHIP_E_HIP,         \
+                  std::string(#call) + ": " + hipGetErrorString(e__));                    \
+  } while (0)
+
+using pinkhip::KernelArgs;
+
+template <int NV>
+int launch_nv(pinkhip_handle *h, const KernelArgs &a, bool solve) {
+  const size_t lds = static_cast<size_t>(pinkhip::Lds<NV>::bytes(a.md));
+  const dim3 grid(static_cast<unsigned>(a.B)), block(pinkhip::kWave);
+  if (solve)
+    hipLaunchKernelGGL(pinkhip::ik_solve_kernel<NV>, grid, block, lds, h->stream, a);
+  else
+    hipLaunchKernelGGL(pinkhip::ik_stack_kernel<NV>, grid, block, lds, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
+  if (a.B == 0) return PINKHIP_OK;
+  if (a.B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "B exceeds the grid limit 2^31-1");
+  switch (pinkhip::padded_nv(a.nv)) {
+    case 8: return launch_nv<8>(h, a, solve);
+    case 16: return launch_nv<16>(h, a, solve);
+    case 24: return launch_nv<24>(h, a, solve);
+    case 32: return launch_nv<32>(h, a, solve);
+    case 40: return launch_nv<40>(h, a, solve);
+    case 48: return launch_nv<48>(h, a, solve);
+    case 56: return launch_nv<56>(h, a, solve);
+    case 64: return launch_nv<64>(h, a, solve);
+  }
+  return fail(h, PINKHIP_E_INVALID, "unsupported nv");
+}
+
+// Validate `d`, refresh the device tables if they changed, fill the table part of `a`.
+int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (!d) return fail(h, PINKHIP_E_INVALID, "null descriptor");
+  pinkhip::HostTables t;
+  const std::string why = pinkhip::build_tables(*d, t);
+  if (!why.empty()) return fail(h, d->n_eq != 0 ? PINKHIP_E_UNSUPPORTED : PINKHIP_E_INVALID, why);
+  PH_HIP(h, hipSetDevice(h->device));
+
+  // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
+  const size_t K = t.row_gain.size(), nd = t.dtask_k.size(), nb = t.barrier_safe_gain.size();
+  const size_t nbytes = 8 * (2 * K + nb) + 4 * (3 * nd + (nb + 1));
+  if (nbytes > kTableBytes) return fail(h, PINKHIP_E_INVALID, "task tables exceed 64 KiB");
+  std::vector<char> img(nbytes);
+  char *p = img.data();
+  auto put = [&](const void *src, size_t n) {
+    if (n) std::memcpy(p, src, n);
+    p += n;
+  };
+  put(t.row_gain.data(), 8 * K);
+  put(t.row_lm.data(), 8 * K);
+  put(t.barrier_safe_gain.data(), 8 * nb);
+  put(t.dtask_col0.data(), 4 * nd);
+  put(t.dtask_row0.data(), 4 * nd);
+  put(t.dtask_k.data(), 4 * nd);
+  put(t.barrier_rows.data(), 4 * (nb + 1));
+  if (img != h->h_tables) {
+    // stream-ordered after any kernel still reading the previous tables
+    if (nbytes) PH_HIP(h, hipMemcpyAsync(h->d_tables, img.data(), nbytes, hipMemcpyHostToDevice, h->stream));
+    PH_HIP(h, hipStreamSynchronize(h->stream));
+    h->h_tables.swap(img);
+  }
+  char *dp = h->d_tables;
+  a.row_gain = reinterpret_cast<const double *>(dp);
+  a.row_lm = reinterpret_cast<const double *>(dp + 8 * K);
+  a.barrier_safe_gain = reinterpret_cast<const double *>(dp + 16 * K);
+  const char *ip = dp + 8 * (2 * K + nb);
+  a.dtask_col0 = reinterpret_cast<const int *>(ip);
+  a.dtask_row0 = reinterpret_cast<const int *>(ip + 4 * nd);
+  a.dtask_k = reinterpret_cast<const int *>(ip + 8 * nd);
+  a.barrier_rows = reinterpret_cast<const int *>(ip + 12 * nd);
+
+  a.B = d->B;
+  a.nv = d->nv;
+  a.Kd = d->Kd;
+  a.K = d->K;
+  a.md = d->md;
+  a.n_dtasks = static_cast<int>(nd);
+  a.n_barriers = static_cast<int>(nb);
+  a.cost_batched = d->cost_is_batched;
+  a.max_iter = d->max_iter;
+  a.damping = d->damping;
+  a.dt = d->dt;
+  return PINKHIP_OK;
+}
+
+int check_problem(pinkhip_handle *h, const pinkhip_desc *d, const pinkhip_problem *in) {
+  if (!in) return fail(h, PINKHIP_E_INVALID, "null problem");
+  if (d->B == 0) return PINKHIP_OK;
+  if (d->Kd > 0 && !in->J) return fail(h, PINKHIP_E_INVALID, "J is NULL but Kd > 0");
+  if (d->K > 0 && (!in->e || !in->cost)) return fail(h, PINKHIP_E_INVALID, "e/cost NULL but K > 0");
+  if (!in->lb || !in->ub) return fail(h, PINKHIP_E_INVALID, "lb/ub must not be NULL");
+  if (d->md > 0 && (!in->Gd || !in->hd)) return fail(h, PINKHIP_E_INVALID, "Gd/hd NULL but md > 0");
+  return PINKHIP_OK;
+}
+
+void set_problem(KernelArgs &a, const pinkhip_problem *in) {
+  a.J = in->J;
+  a.e = in->e;
+  a.cost = in->cost;
+  a.lb = in->lb;
+  a.ub = in->ub;
+  a.Gd = in->Gd;
+  a.hd = in->hd;
+  a.c_extra = in->c_extra;
+}
+
+struct ArenaPlan {
+  size_t off[8];
+  size_t bytes[8];
+  size_t out_dq, out_status, out_iters, out_H, out_c, total;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+int ensure_arena(pinkhip_handle *h, size_t bytes) {
+  if (bytes <= h->arena_bytes) return PINKHIP_OK;
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->arena) PH_HIP(h, hipFree(h->arena));
+  h->arena = nullptr;
+  h->arena_bytes = 0;
+  PH_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->arena), bytes));
+  h->arena_bytes = bytes;
+  return PINKHIP_OK;
+}
+
+// Upload the per-instance streams of `in` into the arena; returns device views.
+int upload(pinkhip_handle *h, const pinkhip_desc *d, const pinkhip_problem *in, size_t extra_out,
+           pinkhip_problem &dev, char *&out_base) {
+  const size_t B = static_cast<size_t>(d->B), nv = d->nv;
+  const void *src[8] = {in->J, in->e, in->cost, in->lb, in->ub, in->Gd, in->hd, in->c_extra};
+  const size_t n[8] = {8 * B * d->Kd * nv,
+                       8 * B * d->K,
+                       8 * (d->cost_is_batched ? B : 1) * d->K,
+                       8 * B * nv,
+                       8 * B * nv,
+                       8 * B * d->md * nv,
+                       8 * B * d->md,
+                       in->c_extra ? 8 * B * nv : 0};
+  size_t off[8], total = 0;
+  for (int i = 0; i < 8; ++i) {
+    off[i] = total;
+    total += align256(n[i]);
+  }
+  const size_t out_off = total;
+  total += align256(extra_out);
+  int rc = ensure_arena(h, total);
+  if (rc) return rc;
+  const double *dp[8];
+  for (int i = 0; i < 8; ++i) {
+    dp[i] = (n[i] && src[i]) ? reinterpret_cast<const double *>(h->arena + off[i]) : nullptr;
+    if (n[i] && src[i])
+      PH_HIP(h, hipMemcpyAsync(h->arena + off[i], src[i], n[i], hipMemcpyHostToDevice, h->stream));
+  }
+  dev.J = dp[0];
+  dev.e = dp[1];
+  dev.cost = dp[2];
+  dev.lb = dp[3];
+  dev.ub = dp[4];
+  dev.Gd = dp[5];
+  dev.hd = dp[6];
+  dev.c_extra = dp[7];
+  out_base = h->arena + out_off;
+  return PINKHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pinkhip_version(void) { return PINKHIP_VERSION; }
+
+int pinkhip_device_count(int *count) {
+  if (!count) return fail(nullptr, PINKHIP_E_INVALID, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, PINKHIP_E_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return PINKHIP_OK;
+}
+
+int pinkhip_create(pinkhip_handle **out, int device_id) {
+  if (!out) return fail(nullptr, PINKHIP_E_INVALID, "null handle pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, PINKHIP_E_NODEVICE, "no HIP device visible (libpinkhip has no CPU path)");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, PINKHIP_E_INVALID, "device_id out of range");
+  pinkhip_handle *h = new (std::nothrow) pinkhip_handle();
+  if (!h) return fail(nullptr, PINKHIP_E_NOMEM, "out of host memory");
+  h->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&h->prop, device_id);
+  if (e == hipSuccess && std::strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
+    const std::string arch = h->prop.gcnArchName;
+    delete h;
+    return fail(nullptr, PINKHIP_E_NODEVICE, "device is " + arch + ", kernels are built for gfx950 only");
+  }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_tables), kTableBytes);
+  if (e != hipSuccess) {
+    const std::string msg = std::string("pinkhip_create: ") + hipGetErrorString(e);
+    pinkhip_destroy(h);
+    return fail(nullptr, PINKHIP_E_HIP, msg);
+  }
+  *out = h;
+  return PINKHIP_OK;
+}
+
+int pinkhip_destroy(pinkhip_handle *h) {
+  if (!h) return PINKHIP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->d_tables) (void)hipFree(h->d_tables);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PINKHIP_OK;
+}
+
+const char *pinkhip_last_error(const pinkhip_handle *h) {
+  return h ? h->err.c_str() : g_last_error.c_str();
+}
+
+int pinkhip_get_device_info(const pinkhip_handle *h, pinkhip_device_info *info) {
+  if (!h || !info) return fail(nullptr, PINKHIP_E_INVALID, "null argument");
+  std::memset(info, 0, sizeof(*info));
+  info->device_id = h->device;
+  info->compute_units = h->prop.multiProcessorCount;
+  info->wavefront_size = h->prop.warpSize;
+  info->clock_mhz = h->prop.clockRate / 1000;
+  info->total_mem_bytes = static_cast<int64_t>(h->prop.totalGlobalMem);
+  info->lds_per_cu_bytes = static_cast<int64_t>(h->prop.maxSharedMemoryPerMultiProcessor);
+  std::snprintf(info->name, sizeof(info->name), "%s", h->prop.name);
+  std::snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", h->prop.gcnArchName);
+  return PINKHIP_OK;
+}
+
+int pinkhip_solve_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *dev_in,
+                         const pinkhip_result *dev_out) {
+  KernelArgs a{};
+  int rc = prepare(h, desc, a);
+  if (rc) return rc;
+  if ((rc = check_problem(h, desc, dev_in))) return rc;
+  if (!dev_out || (desc->B > 0 && (!dev_out->dq || !dev_out->status)))
+    return fail(h, PINKHIP_E_INVALID, "dq/status must not be NULL");
+  set_problem(a, dev_in);
+  a.dq = dev_out->dq;
+  a.status = dev_out->status;
+  a.iters = dev_out->iters;
+  return launch(h, a, true);
+}
+
+int pinkhip_stack_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *dev_in,
+                         double *H_out, double *c_out) {
+  KernelArgs a{};
+  int rc = prepare(h, desc, a);
+  if (rc) return rc;
+  if ((rc = check_problem(h, desc, dev_in))) return rc;
+  if (desc->B > 0 && (!H_out || !c_out)) return fail(h, PINKHIP_E_INVALID, "H_out/c_out must not be NULL");
+  set_problem(a, dev_in);
+  a.H_out = H_out;
+  a.c_out = c_out;
+  return launch(h, a, false);
+}
+
+int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
+                       const pinkhip_result *host_out) {
+  KernelArgs a{};
+  int rc = prepare(h, desc, a);
+  if (rc) return rc;
+  if ((rc = check_problem(h, desc, host_in))) return rc;
+  if (!host_out || (desc->B > 0 && (!host_out->dq || !host_out->status)))
+    return fail(h, PINKHIP_E_INVALID, "dq/status must not be NULL");
+  if (desc->B == 0) return PINKHIP_OK;
+  const size_t B = static_cast<size_t>(desc->B), nv = desc->nv;
+  const size_t n_dq = align256(8 * B * nv), n_st = align256(4 * B);
+  pinkhip_problem dev{};
+  char *out = nullptr;
+  if ((rc = upload(h, desc, host_in, n_dq + 2 * n_st, dev, out))) return rc;
+  set_problem(a, &dev);
+  a.dq = reinterpret_cast<double *>(out);
+  a.status = reinterpret_cast<int *>(out + n_dq);
+  a.iters = reinterpret_cast<int *>(out + n_dq + n_st);
+  if ((rc = launch(h, a, true))) return rc;
+  PH_HIP(h, hipMemcpyAsync(host_out->dq, a.dq, 8 * B * nv, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipMemcpyAsync(host_out->status, a.status, 4 * B, hipMemcpyDeviceToHost, h->stream));
+  if (host_out->iters)
+    PH_HIP(h, hipMemcpyAsync(host_out->iters, a.iters, 4 * B, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_stack_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
+                       double *H_out, double *c_out) {
+  KernelArgs a{};
+  int rc = prepare(h, desc, a);
+  if (rc) return rc;
+  if ((rc = check_problem(h, desc, host_in))) return rc;
+  if (desc->B == 0) return PINKHIP_OK;
+  if (!H_out || !c_out) return fail(h, PINKHIP_E_INVALID, "H_out/c_out must not be NULL");
+  const size_t B = static_cast<size_t>(desc->B), nv = desc->nv;
+  const size_t n_H = align256(8 * B * nv * nv), n_c = align256(8 * B * nv);
+  pinkhip_problem dev{};
+  char *out = nullptr;
+  if ((rc = upload(h, desc, host_in, n_H + n_c, dev, out))) return rc;
+  set_problem(a, &dev);
+  a.H_out = reinterpret_cast<double *>(out);
+  a.c_out = reinterpret_cast<double *>(out + n_H);
+  if ((rc = launch(h, a, false))) return rc;
+  PH_HIP(h, hipMemcpyAsync(H_out, a.H_out, 8 * B * nv * nv, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipMemcpyAsync(c_out, a.c_out, 8 * B * nv, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes) {
+  if (!h || !dptr || bytes < 0) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  *dptr = nullptr;
+  PH_HIP(h, hipSetDevice(h->device));
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipMalloc(dptr, static_cast<size_t>(bytes)));
+  return PINKHIP_OK;
+}
+
+int pinkhip_free(pinkhip_handle *h, void *dptr) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (!dptr) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  PH_HIP(h, hipFree(dptr));
+  return PINKHIP_OK;
+}
+
+int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_sync(pinkhip_handle *h) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_timer_start(pinkhip_handle *h) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipEventRecord(h->ev0, h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_timer_stop(pinkhip_handle *h, float *elapsed_ms) {
+  if (!h || !elapsed_ms) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipEventRecord(h->ev1, h->stream));
+  PH_HIP(h, hipEventSynchronize(h->ev1));
+  PH_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return PINKHIP_OK;
+}
+
+}  // extern "C"

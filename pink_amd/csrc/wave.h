@@ -24,6 +24,23 @@ __device__ __forceinline__ double *shared_base() {
   return pinkhip_lds;
 }
 
+// Scheduling fence: keeps hipcc from hoisting the LDS loads of later unrolled
+// iterations above this point (bounds VGPR pressure in the fully unrolled
+// triangular loops).  Emits no instruction.
+__device__ __forceinline__ void sched_fence() {
+  asm volatile("" ::: "memory");  // orders the loads at IR / DAG level
+  __builtin_amdgcn_sched_barrier(0);  // and in the machine scheduler
+}
+
+// Pin a value to the program point: an empty asm that "modifies" x, so the
+// arithmetic producing x cannot be sunk below it and later loads cannot be
+// hoisted above it.  Without it hipcc issues all NV^2/2 uniform LDS loads of a
+// fully unrolled triangular loop first and keeps them live (1000+ VGPRs).
+template <typename T>
+__device__ __forceinline__ void pin(T &x) {
+  asm volatile("" : "+v"(x) : : "memory");
+}
+
 // Broadcast `v` of lane `src` (wave-uniform) to every lane: 2 x v_readlane_b32.
 __device__ __forceinline__ double bcast(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -83,6 +83,9 @@ inline void emu_rendezvous(int tag) {
 }
 
 inline void wave_sync() { emu_rendezvous(1); }
+inline void sched_fence() {}
+template <typename T>
+inline void pin(T &) {}
 
 inline double bcast(double v, int src) {
   Emu &e = emu();
