@@ -38,7 +38,7 @@ class BatchResult:
 class DeviceBatch:
     """A batch resident in HBM together with its output buffers."""
 
-    def __init__(self, solver: "BatchSolver", args: PackedArgs):
+    def __init__(self, solver: "BatchSolver", args: PackedArgs, out_ptrs=None):
         self.solver = solver
         self.args = args
         self.ptrs: Dict[str, int] = {}
@@ -48,9 +48,15 @@ class DeviceBatch:
             self.ptrs[name] = solver._malloc(max(arr.nbytes, 8))
             solver._h2d(self.ptrs[name], arr)
             self.nbytes += arr.nbytes
-        self.d_dq = solver._malloc(max(8 * b.B * b.nv, 8))
-        self.d_status = solver._malloc(max(4 * b.B, 8))
-        self.d_iters = solver._malloc(max(4 * b.B, 8))
+        # outputs: library-allocated, or caller-owned device buffers (e.g. tensors of
+        # a framework that will run a collective on them)
+        self.owns_outputs = out_ptrs is None
+        if out_ptrs is None:
+            self.d_dq = solver._malloc(max(8 * b.B * b.nv, 8))
+            self.d_status = solver._malloc(max(4 * b.B, 8))
+            self.d_iters = solver._malloc(max(4 * b.B, 8))
+        else:
+            self.d_dq, self.d_status, self.d_iters = (int(p) for p in out_ptrs)
         self.d_H: Optional[int] = None
         self.d_c: Optional[int] = None
         p = Problem()
@@ -63,7 +69,8 @@ class DeviceBatch:
 
     def free(self) -> None:
         s = self.solver
-        for ptr in list(self.ptrs.values()) + [self.d_dq, self.d_status, self.d_iters, self.d_H, self.d_c]:
+        outs = [self.d_dq, self.d_status, self.d_iters] if self.owns_outputs else []
+        for ptr in list(self.ptrs.values()) + outs + [self.d_H, self.d_c]:
             if ptr:
                 s._free(ptr)
         self.ptrs = {}
@@ -147,8 +154,10 @@ class BatchSolver:
         return H, c
 
     # -- HBM-resident path -----------------------------------------------------
-    def upload(self, batch: IKBatch, max_iter: int = 0) -> DeviceBatch:
-        return DeviceBatch(self, PackedArgs(batch, max_iter))
+    def upload(self, batch: IKBatch, max_iter: int = 0, out_ptrs=None) -> DeviceBatch:
+        """Copy a batch to HBM.  ``out_ptrs = (dq, status, iters)`` device addresses
+        makes the solve write into caller-owned buffers instead of library ones."""
+        return DeviceBatch(self, PackedArgs(batch, max_iter), out_ptrs)
 
     def solve_device(self, dev: DeviceBatch) -> None:
         """Enqueue one stack+solve pass over a resident batch (asynchronous)."""

@@ -64,6 +64,25 @@ class Terms:
     def B(self) -> int:
         return self.cfg_lo.shape[0]
 
+    def slice(self, lo: int, hi: int) -> "Terms":
+        """Instances ``[lo, hi)`` of this batch."""
+        import copy
+
+        def cut(t):
+            t = copy.copy(t)
+            for f in ("J", "e", "J_h", "h", "safe_displacement"):
+                v = getattr(t, f, None)
+                if isinstance(v, np.ndarray) and v.ndim >= 2:
+                    setattr(t, f, v[lo:hi])
+            return t
+
+        return Terms(
+            name=self.name, nv=self.nv, root_nv=self.root_nv, dt=self.dt, damping=self.damping,
+            dense_tasks=[cut(t) for t in self.dense_tasks], diag_tasks=[cut(t) for t in self.diag_tasks],
+            cfg_lo=self.cfg_lo[lo:hi], cfg_hi=self.cfg_hi[lo:hi], vel=self.vel[lo:hi], limit_idx=self.limit_idx,
+            barriers=[cut(b) for b in self.barriers], meta=dict(self.meta),
+        )
+
 
 def _frame_jacobians(rng, B, nv, root_nv, n_frames, mode):
     if mode == "dense":

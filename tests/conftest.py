@@ -1,0 +1,86 @@
+"""Shared fixtures.  ``-m "not gpu"`` runs everywhere; ``-m gpu`` needs an MI355X."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / at round end)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Everything native is compiled (hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as g
+
+    g.build()
+    return g
+
+
+@pytest.fixture(scope="session")
+def emu(built):
+    """CPU wave emulator running the real kernel source (tests/emu)."""
+    from pink_amd._lib import Desc, Problem, Result
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libpinkemu.so"))
+    lib.pinkhip_emu_solve_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)]
+    lib.pinkhip_emu_stack_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.c_void_p, ctypes.c_void_p]
+    lib.pinkhip_emu_last_error.restype = ctypes.c_char_p
+    return EmuSolver(lib)
+
+
+class EmuSolver:
+    """Same surface as pink_amd.batch_solver.BatchSolver.solve/stack, on the emulator."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def solve(self, batch, max_iter=0):
+        from pink_amd._lib import PackedArgs, Result
+        from pink_amd.batch_solver import BatchResult
+
+        a = PackedArgs(batch, max_iter)
+        dq = np.zeros((batch.B, batch.nv))
+        st = np.zeros(batch.B, np.int32)
+        it = np.zeros(batch.B, np.int32)
+        r = Result()
+        r.dq, r.status, r.iters = dq.ctypes.data, st.ctypes.data, it.ctypes.data
+        p = a.host_problem()
+        rc = self.lib.pinkhip_emu_solve_host(ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r))
+        if rc != 0:
+            raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
+        return BatchResult(dq, st, it)
+
+    def stack(self, batch):
+        from pink_amd._lib import PackedArgs
+
+        a = PackedArgs(batch)
+        H = np.zeros((batch.B, batch.nv, batch.nv))
+        c = np.zeros((batch.B, batch.nv))
+        p = a.host_problem()
+        rc = self.lib.pinkhip_emu_stack_host(ctypes.byref(a.desc), ctypes.byref(p), H.ctypes.data, c.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
+        return H, c
+
+
+@pytest.fixture(scope="session")
+def gpu_solver(built):
+    """A BatchSolver on device 0; only requested by gpu-marked tests."""
+    from pink_amd.batch_solver import BatchSolver
+
+    s = BatchSolver(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "pink_build_ik.npz"))

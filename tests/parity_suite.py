@@ -1,0 +1,192 @@
+"""Parity checks of the HIP kernels against the CPU oracle.
+
+The same functions are run on the CPU wave emulator (``test_emulator_parity.py``,
+small batches, no GPU) and on the MI355X through the C ABI
+(``test_gpu_parity.py``).  ``solver`` is anything with ``solve(batch)`` and
+``stack(batch)``.
+
+Tolerance: north_star demands |dq - dq_ref| <= 1e-8 (fp64); the suite holds the
+kernels to 1e-10 absolute (what is observed is ~1e-14).
+"""
+import numpy as np
+
+from oracle import c_oracle
+from oracle import pink_oracle as po
+from pink_amd.batch import DenseTaskTerm, DiagonalTaskTerm, pack_terms
+from tests.cases import config_case, golden_case, random_case
+
+TOL_DQ = 1e-10
+
+
+def check_against_oracle(solver, batch, pf, tol=TOL_DQ, expect_status=None):
+    ref = c_oracle.solve_ik_batch(**pf, want_Hc=True, nthreads=0)
+    H, c = solver.stack(batch)
+    scale = max(1.0, np.abs(ref["H"]).max())
+    assert np.abs(H - ref["H"]).max() <= 1e-13 * scale
+    assert np.abs(c - ref["c"]).max() <= 1e-13 * max(1.0, np.abs(ref["c"]).max())
+    out = solver.solve(batch)
+    if expect_status is None:
+        assert (ref["status"] == 0).all()
+        assert (out.status == 0).all(), out.status[out.status != 0][:10]
+        # fp64 round-off grows with cond(H): two correct solvers agree to ~cond*eps*|x|
+        cond = np.linalg.cond(ref["H"])
+        xmax = np.abs(ref["dq"]).max(axis=1)
+        tol_b = np.maximum(tol, 100 * np.finfo(float).eps * cond * xmax)
+        err = np.abs(out.dq - ref["dq"]).max(axis=1)
+        assert (err <= tol_b).all(), (err.max(), cond.max())
+        assert err.max() <= 1e-8, err.max()  # north_star bound, unconditionally
+    else:
+        assert (out.status == expect_status).all(), out.status
+        assert (ref["status"] == expect_status).all(), ref["status"]
+    return out, ref
+
+
+def golden(solver, golden_npz, name):
+    """Fixture produced by the reference's own build_ik: H, c vs its (P, q); dq vs
+    the oracle solving the reference's own (P, q, G, h)."""
+    batch, P, q, G, h = golden_case(golden_npz, name)
+    H, c = solver.stack(batch)
+    assert np.allclose(H[0], P, rtol=1e-13, atol=1e-15)
+    assert np.allclose(c[0], q, rtol=1e-13, atol=1e-15)
+    out = solver.solve(batch)
+    x, st, _, _ = c_oracle.gi_solve(P, q, G, h)
+    assert st == 0 and out.status[0] == 0
+    assert np.abs(out.dq[0] - x).max() <= TOL_DQ
+    stat, viol, _ = po.kkt_residuals(P, q, G, h, out.dq[0])
+    assert stat < 1e-10 and viol < 1e-11
+
+
+def config(solver, name, bounds, jac, B):
+    batch, pf = config_case(name, bounds, jac, B)
+    return check_against_oracle(solver, batch, pf)
+
+
+def random_dims(solver, nv, B, seed, **kw):
+    batch, pf = random_case(nv, B, seed, **kw)
+    return check_against_oracle(solver, batch, pf)
+
+
+def empty_task_list(solver, nv=7, B=3):
+    """tests/test_solve_ik.py:79-87: no task => dq = 0 (H = damping I, c = 0)."""
+    lb = -np.ones((B, nv))
+    ub = np.ones((B, nv))
+    batch = pack_terms(nv, [], 0.01, 1e-12, boxes=[(lb, ub)], batch_size=B)
+    H, c = solver.stack(batch)
+    assert np.array_equal(H, np.broadcast_to(1e-12 * np.eye(nv), (B, nv, nv))) and not c.any()
+    out = solver.solve(batch)
+    assert (out.status == 0).all() and not out.dq.any()
+
+
+def fulfilled_tasks_give_zero(solver, nv=10, B=4):
+    """tests/test_solve_ik.py:89-102: zero error => dq = 0 whatever the bounds (0 inside)."""
+    rng = np.random.default_rng(5)
+    J = rng.normal(size=(B, 6, nv))
+    t = [DenseTaskTerm(J=J, e=np.zeros((B, 6)), cost=1.0), DiagonalTaskTerm(col0=0, e=np.zeros((B, nv)), cost=0.1)]
+    batch = pack_terms(nv, t, 0.01, 1e-12, boxes=[(-np.ones((B, nv)), np.ones((B, nv)))], batch_size=B)
+    out = solver.solve(batch)
+    assert (out.status == 0).all() and np.abs(out.dq).max() < 1e-15
+
+
+def infeasible(solver):
+    """Crossed bounds: quadprog's "constraints are inconsistent" -> status 2 (NoSolutionFound)."""
+    nv, B = 5, 2
+    t = [DiagonalTaskTerm(col0=0, e=np.ones((B, nv)), cost=1.0)]
+    lb = np.full((B, nv), -1.0)
+    ub = np.full((B, nv), 1.0)
+    lb[:, 2], ub[:, 2] = 0.5, 0.25
+    batch = pack_terms(nv, t, 0.01, 1e-12, boxes=[(lb, ub)], batch_size=B)
+    out = solver.solve(batch)
+    assert (out.status == 2).all()
+
+
+def infeasible_dense_rows(solver):
+    nv, B = 6, 2
+    t = [DiagonalTaskTerm(col0=0, e=np.ones((B, nv)), cost=1.0)]
+    g = np.ones((B, 1, nv))
+    G = np.concatenate([g, -g], axis=1)  # sum x <= -1 and -sum x <= -1
+    h = -np.ones((B, 2))
+    batch = pack_terms(nv, t, 0.01, 1e-12, dense_rows=[(G, h)], batch_size=B)
+    out = solver.solve(batch)
+    assert (out.status == 2).all()
+
+
+def not_positive_definite(solver):
+    """No task, zero damping: H = 0 -> quadprog's "matrix G is not positive definite" -> status 3."""
+    nv, B = 4, 2
+    batch = pack_terms(nv, [], 0.01, 0.0, boxes=[(-np.ones((B, nv)), np.ones((B, nv)))], batch_size=B)
+    out = solver.solve(batch)
+    assert (out.status == 3).all()
+
+
+def mixed_status_batch(solver):
+    """One bad instance must not disturb its neighbours (per-instance status)."""
+    batch, pf = random_case(12, 6, 77, md=0)
+    batch.lb[3, 4], batch.ub[3, 4] = 1.0, -1.0
+    out = solver.solve(batch)
+    ref = c_oracle.solve_ik_batch(**pf)
+    good = np.array([0, 1, 2, 4, 5])
+    assert out.status[3] == 2 and (out.status[good] == 0).all()
+    assert np.abs(out.dq[good] - ref["dq"][good]).max() <= TOL_DQ
+
+
+def max_iter_is_reported(solver):
+    batch, _ = config_case("draco3", "tight", "dense", 2)
+    out = solver.solve(batch, max_iter=3)
+    assert (out.status == 1).all() and (out.iters == 4).all()
+
+
+def batched_cost(solver):
+    """cost given per instance ([B, K]) equals solving each instance with its own cost."""
+    rng = np.random.default_rng(9)
+    nv, B = 9, 4
+    J = rng.normal(size=(B, 6, nv))
+    e = 0.1 * rng.normal(size=(B, 6))
+    ep = rng.uniform(-0.3, 0.3, size=(B, nv))
+    cost = rng.uniform(0.5, 2.0, size=(B, 6))
+    lb, ub = -0.02 * np.ones((B, nv)), 0.02 * np.ones((B, nv))
+    tb = [DenseTaskTerm(J=J, e=e, cost=cost, lm_damping=0.1), DiagonalTaskTerm(col0=0, e=ep, cost=0.3)]
+    out = solver.solve(pack_terms(nv, tb, 0.01, 1e-12, boxes=[(lb, ub)], batch_size=B))
+    for b in range(B):
+        t1 = [DenseTaskTerm(J=J[b:b + 1], e=e[b:b + 1], cost=cost[b], lm_damping=0.1),
+              DiagonalTaskTerm(col0=0, e=ep[b:b + 1], cost=0.3)]
+        o1 = solver.solve(pack_terms(nv, t1, 0.01, 1e-12, boxes=[(lb[b:b + 1], ub[b:b + 1])], batch_size=1))
+        assert np.array_equal(o1.dq[0], out.dq[b])
+
+
+def many_dense_rows_chunked_staging(solver):
+    """Kd larger than one LDS staging chunk (rows are streamed in pieces)."""
+    nv, B = 6, 3
+    rng = np.random.default_rng(11)
+    tasks, Js, es, rows = [], [], [], [0]
+    for _ in range(20):  # 120 rows of nv=6: staging chunk is 13 rows at NV=8
+        J = rng.normal(size=(B, 6, nv))
+        e = 0.05 * rng.normal(size=(B, 6))
+        tasks.append(DenseTaskTerm(J=J, e=e, cost=1.0))
+        Js.append(J), es.append(e), rows.append(rows[-1] + 6)
+    lb, ub = -0.01 * np.ones((B, nv)), 0.01 * np.ones((B, nv))
+    batch = pack_terms(nv, tasks, 0.01, 1e-12, boxes=[(lb, ub)], batch_size=B)
+    eye = np.eye(nv)
+    G = np.broadcast_to(np.vstack([eye, -eye]), (B, 2 * nv, nv))
+    h = np.concatenate([ub, -lb], axis=1)
+    pf = dict(J=np.concatenate(Js, axis=1), e=np.concatenate(es, axis=1), cost=np.ones(120), gain=np.ones(20),
+              lm=np.zeros(20), rows=np.array(rows, np.int32), damping=1e-12, G=np.ascontiguousarray(G), h=h)
+    check_against_oracle(solver, batch, pf)
+
+
+def empty_batch(solver):
+    batch, _ = config_case("ur5", "tight", "dense", 4)
+    out = solver.solve(batch.slice(0, 0))
+    assert out.dq.shape == (0, 6) and out.status.shape == (0,)
+
+
+def unconstrained(solver):
+    """limits=[] (solve_ik.py:187-189): no rows at all -> dq = -H^-1 c."""
+    batch, pf = random_case(15, 5, 3)
+    batch.lb[:] = -np.inf
+    batch.ub[:] = np.inf
+    ref = c_oracle.solve_ik_batch(**{**pf, "G": None, "h": None}, want_Hc=True)
+    out = solver.solve(batch)
+    assert (out.status == 0).all() and (out.iters == 0).all()
+    assert np.abs(out.dq - ref["dq"]).max() <= TOL_DQ
+    x = -np.linalg.solve(ref["H"], ref["c"][..., None])[..., 0]
+    assert np.abs(out.dq - x).max() <= 1e-9

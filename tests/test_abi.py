@@ -1,0 +1,71 @@
+"""The C-ABI library: it loads, exports what include/pinkhip.h declares, validates
+descriptors, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pink_amd import _lib
+from pink_amd._lib import PackedArgs, PinkHipError
+from tests.cases import config_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "pinkhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pinkhip_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+    lib = _lib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pinkhip_version() == 100
+
+
+def test_struct_layouts_match_the_header(built):
+    # pinkhip_desc: 8 + 6*4 + 5*8 + 4(+4 pad) + 2*8 + 2*8 + 2*4
+    assert ctypes.sizeof(_lib.Desc) == 8 + 24 + 40 + 8 + 16 + 16 + 8
+    assert ctypes.sizeof(_lib.Problem) == 64 and ctypes.sizeof(_lib.Result) == 24
+    assert ctypes.sizeof(_lib.DeviceInfo) == 4 * 4 + 2 * 8 + 128 + 64
+
+
+def test_no_gpu_means_loud_failure(built):
+    lib = _lib.load_library()
+    n = ctypes.c_int(-1)
+    rc = lib.pinkhip_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    from pink_amd.batch_solver import BatchSolver
+
+    with pytest.raises(PinkHipError) as ei:
+        BatchSolver(0)
+    assert ei.value.code == -4  # PINKHIP_E_NODEVICE
+
+
+def test_descriptor_validation(emu):
+    def err(mutate):
+        batch, _ = config_case("ur5", "tight", "dense", 2)  # fresh arrays: mutations must not leak
+        a = PackedArgs(batch)
+        mutate(a)
+        dq = np.zeros((2, 6)); st = np.zeros(2, np.int32)
+        r = _lib.Result(); r.dq, r.status = dq.ctypes.data, st.ctypes.data
+        p = a.host_problem()
+        rc = emu.lib.pinkhip_emu_solve_host(ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r))
+        return rc, emu.lib.pinkhip_emu_last_error().decode()
+
+    assert err(lambda a: None)[0] == 0
+    for mut, word in [
+        (lambda a: setattr(a.desc, "nv", 65), "nv"),
+        (lambda a: setattr(a.desc, "md", 33), "md"),
+        (lambda a: setattr(a.desc, "n_eq", 1), "equality"),
+        (lambda a: setattr(a.desc, "dt", 0.0), "dt"),
+        (lambda a: setattr(a.desc, "K", 13), "task_rows"),
+        (lambda a: setattr(a.desc, "Kd", 5), "Kd"),
+        (lambda a: a.task_kind.__setitem__(0, 1), "dense task"),
+        (lambda a: a.task_col0.__setitem__(1, 3), "exceeds"),
+    ]:
+        rc, msg = err(mut)
+        assert rc == -1 and re.search(word, msg), (rc, msg)

@@ -1,0 +1,78 @@
+"""The HIP kernel source, executed on the CPU wave emulator, against the oracle.
+
+This is the SIMT logic check that runs without a GPU (``-m "not gpu"``); the
+same suite runs on the MI355X in ``test_gpu_parity.py``.
+"""
+import pytest
+
+from tests import parity_suite as ps
+from tests.cases import CONFIG_CASES
+
+
+@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier"])
+def test_golden_fixture(emu, golden, name):
+    ps.golden(emu, golden, name)
+
+
+@pytest.mark.parametrize("name,bounds,jac", CONFIG_CASES)
+def test_baseline_configs(emu, name, bounds, jac):
+    ps.config(emu, name, bounds, jac, B=3 if name == "jvrc" else 5)
+
+
+@pytest.mark.parametrize("nv", [1, 2, 5, 8, 9, 16, 17, 24, 25, 33, 40, 41, 48, 56, 57, 64])
+def test_every_padding_class(emu, nv):
+    ps.random_dims(emu, nv, B=2, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
+
+
+@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32)])
+def test_dense_inequality_rows(emu, nv, md):
+    ps.random_dims(emu, nv, B=3, seed=500 + nv, md=md)
+
+
+def test_lm_damping_and_rank_deficient_tasks(emu):
+    ps.random_dims(emu, 14, B=3, seed=7, lm=0.5, rank_deficient=True)
+
+
+def test_no_diagonal_task(emu):
+    ps.random_dims(emu, 6, B=3, seed=8, Kd_tasks=3, diag=False, lm=1.0)
+
+
+def test_empty_task_list(emu):
+    ps.empty_task_list(emu)
+
+
+def test_fulfilled_tasks_give_zero(emu):
+    ps.fulfilled_tasks_give_zero(emu)
+
+
+def test_infeasible(emu):
+    ps.infeasible(emu)
+    ps.infeasible_dense_rows(emu)
+
+
+def test_not_positive_definite(emu):
+    ps.not_positive_definite(emu)
+
+
+def test_mixed_status_batch(emu):
+    ps.mixed_status_batch(emu)
+
+
+def test_max_iter(emu):
+    ps.max_iter_is_reported(emu)
+
+
+def test_batched_cost(emu):
+    ps.batched_cost(emu)
+
+
+def test_chunked_staging(emu):
+    ps.many_dense_rows_chunked_staging(emu)
+
+
+def test_empty_batch(emu):
+    ps.empty_batch(emu)
+
+
+def test_unconstrained(emu):
+    ps.unconstrained(emu)

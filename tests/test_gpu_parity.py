@@ -1,0 +1,130 @@
+"""Parity of the HIP path on a real MI355X, through the C ABI (libpinkhip.so).
+
+Small/medium batches are compared with the CPU oracle instance by instance;
+BASELINE.json's full sizes are checked through size-independent properties
+(KKT conditions against the GPU-stacked H, c; feasibility; determinism;
+permutation equivariance) plus an oracle comparison on a random sample.
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from tests import parity_suite as ps
+from tests.cases import CONFIG_CASES, config_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier"])
+def test_golden_fixture(gpu_solver, golden, name):
+    ps.golden(gpu_solver, golden, name)
+
+
+@pytest.mark.parametrize("name,bounds,jac", CONFIG_CASES)
+def test_baseline_configs(gpu_solver, name, bounds, jac):
+    ps.config(gpu_solver, name, bounds, jac, B=4096 if name == "ur5" else 2048)
+
+
+@pytest.mark.parametrize("nv", [1, 2, 5, 8, 9, 16, 17, 24, 25, 33, 40, 41, 48, 56, 57, 64])
+def test_every_padding_class(gpu_solver, nv):
+    ps.random_dims(gpu_solver, nv, B=256, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
+
+
+@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32), (50, 12)])
+def test_dense_inequality_rows(gpu_solver, nv, md):
+    ps.random_dims(gpu_solver, nv, B=256, seed=500 + nv, md=md)
+
+
+def test_lm_damping_and_rank_deficient_tasks(gpu_solver):
+    ps.random_dims(gpu_solver, 14, B=512, seed=7, lm=0.5, rank_deficient=True)
+
+
+def test_no_diagonal_task(gpu_solver):
+    ps.random_dims(gpu_solver, 6, B=512, seed=8, Kd_tasks=3, diag=False, lm=1.0)
+
+
+def test_edge_cases(gpu_solver):
+    ps.empty_task_list(gpu_solver)
+    ps.fulfilled_tasks_give_zero(gpu_solver)
+    ps.infeasible(gpu_solver)
+    ps.infeasible_dense_rows(gpu_solver)
+    ps.not_positive_definite(gpu_solver)
+    ps.mixed_status_batch(gpu_solver)
+    ps.max_iter_is_reported(gpu_solver)
+    ps.batched_cost(gpu_solver)
+    ps.many_dense_rows_chunked_staging(gpu_solver)
+    ps.empty_batch(gpu_solver)
+    ps.unconstrained(gpu_solver)
+
+
+def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
+    """Vectorised KKT check for box (+ dense) QPs; returns (stationarity, violation)."""
+    g = np.einsum("bij,bj->bi", H, dq) + c
+    scale = 1.0 + np.abs(c).max(axis=1, keepdims=True)
+    tol = 1e-9
+    at_lb = np.isfinite(lb) & (dq <= lb + tol * (1 + np.abs(lb)))
+    at_ub = np.isfinite(ub) & (dq >= ub - tol * (1 + np.abs(ub)))
+    viol = max(float(np.max(np.where(np.isfinite(lb), lb - dq, -1.0))), float(np.max(np.where(np.isfinite(ub), dq - ub, -1.0))))
+    if Gd is not None and Gd.shape[1]:
+        slack = hd - np.einsum("bmj,bj->bm", Gd, dq)
+        viol = max(viol, float(-slack.min()))
+        act = slack <= tol * (1 + np.abs(hd))
+        # remove the dense-row part of the gradient by least squares on the active rows
+        for b in np.nonzero(act.any(axis=1))[0]:
+            A = Gd[b][act[b]].T
+            free = ~(at_lb[b] | at_ub[b])
+            if free.any():
+                lam, *_ = np.linalg.lstsq(A[free], -g[b][free], rcond=None)
+                g[b] = g[b] + A @ lam
+    free = ~(at_lb | at_ub)
+    stat = np.abs(np.where(free, g, 0.0) / scale).max()
+    # multipliers: gradient must push outward at active bounds
+    sign_ok = (np.where(at_lb & ~at_ub, g, 0.0) >= -1e-8 * scale).all() and (np.where(at_ub & ~at_lb, g, 0.0) <= 1e-8 * scale).all()
+    return float(stat), float(viol), bool(sign_ok)
+
+
+@pytest.mark.parametrize("name,B", [("draco3", 65536), ("jvrc", 65536), ("ur5", 4096)])
+def test_full_size_properties(gpu_solver, name, B):
+    """BASELINE.json configs 2-4 at their full batch size."""
+    s = gpu_solver
+    batch, pf = config_case(name, "tight", "dense", B)
+    dev = s.upload(batch)
+    s.solve_device(dev)
+    s.stack_device(dev)
+    s.sync()
+    out = s.download(dev)
+    H, c = s.download_stack(dev)
+    assert (out.status == 0).all()
+    # oracle on a random sample of the batch (the whole batch would take minutes on CPU)
+    idx = np.sort(np.random.default_rng(0).choice(B, size=1024, replace=False))
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == B else v) for k, v in pf.items()}
+    if sub.get("diag_extra") is not None:
+        sub["diag_extra"] = pf["diag_extra"][idx]
+    ref = c_oracle.solve_ik_batch(**sub, want_Hc=True, nthreads=0)
+    assert np.abs(out.dq[idx] - ref["dq"]).max() <= 1e-10
+    assert np.abs(H[idx] - ref["H"]).max() <= 1e-12 * np.abs(ref["H"]).max()
+    # KKT over the WHOLE batch with the GPU-stacked (H, c)
+    stat, viol, sign_ok = _kkt_batch(H, c, batch.lb, batch.ub, out.dq, batch.Gd, batch.hd)
+    assert stat < 1e-9 and viol < 1e-11 and sign_ok
+    # determinism: a second pass is bit-identical
+    s.solve_device(dev)
+    s.sync()
+    out2 = s.download(dev)
+    assert np.array_equal(out.dq, out2.dq) and np.array_equal(out.iters, out2.iters)
+    dev.free()
+    # permutation equivariance + host path == device path (bitwise)
+    perm = np.random.default_rng(1).permutation(B)[:8192]
+    sub_batch = batch.slice(0, B)
+    for f in ("J", "e", "lb", "ub", "Gd", "hd"):
+        setattr(sub_batch, f, np.ascontiguousarray(getattr(batch, f)[perm]))
+    out3 = s.solve(sub_batch)
+    assert np.array_equal(out3.dq, out.dq[perm])
+
+
+def test_api_errors(gpu_solver):
+    from pink_amd._lib import PinkHipError
+
+    batch, _ = config_case("ur5", "tight", "dense", 4)
+    batch.dt = 0.0
+    with pytest.raises(PinkHipError):
+        gpu_solver.solve(batch)

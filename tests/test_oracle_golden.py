@@ -1,0 +1,64 @@
+"""Oracle stacking vs fixtures produced by the reference's own ``pink.build_ik``
+(tests/golden/make_golden.py imports /root/reference with stub pinocchio/qpsolvers)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import pink_oracle as po
+
+NAMES = ["ur5", "draco3", "barrier"]
+
+
+def _terms(g, n):
+    nv, root, dt = int(g[f"{n}/nv"]), int(g[f"{n}/root"]), float(g[f"{n}/dt"])
+    tasks = [(g[f"{n}/J"][i], g[f"{n}/e"][i], g[f"{n}/cost"][i], float(g[f"{n}/gain"][i]), float(g[f"{n}/lm"][i]))
+             for i in range(g[f"{n}/J"].shape[0])]
+    tasks.append((np.eye(nv)[root:], g[f"{n}/e_posture"], float(g[f"{n}/posture_cost"]), 1.0, 0.0))
+    q, q_min, q_max, v_max = g[f"{n}/q"], g[f"{n}/q_min"], g[f"{n}/q_max"], g[f"{n}/v_max"]
+    ci = po.configuration_limit_indices(q_min, q_max)
+    vi = po.velocity_limit_indices(v_max)
+    blocks = [po.configuration_limit_rows(q, q_min, q_max, ci, nv), po.velocity_limit_rows(v_max, vi, nv, dt)]
+    barriers = []
+    if f"{n}/barrier_J" in g:
+        for i in range(g[f"{n}/barrier_J"].shape[0]):
+            barriers.append((g[f"{n}/barrier_J"][i], g[f"{n}/barrier_h"][i], float(g[f"{n}/barrier_gain"][i]),
+                             float(g[f"{n}/barrier_safe_gain"][i]), None))
+    return nv, dt, tasks, blocks, barriers, ci, vi
+
+
+@pytest.mark.parametrize("n", NAMES)
+def test_build_qp_matches_reference_build_ik(golden, n):
+    nv, dt, tasks, blocks, barriers, ci, vi = _terms(golden, n)
+    assert np.array_equal(ci, golden[f"{n}/config_limit_indices"])
+    assert np.array_equal(vi, golden[f"{n}/velocity_limit_indices"])
+    P, q, G, h = po.build_qp(nv, tasks, 1e-12, blocks, barriers, dt)
+    assert np.allclose(P, golden[f"{n}/P"], rtol=1e-13, atol=1e-15)
+    assert np.allclose(q, golden[f"{n}/qvec"], rtol=1e-13, atol=1e-15)
+    assert G.shape == golden[f"{n}/G"].shape
+    assert np.allclose(G, golden[f"{n}/G"], rtol=1e-14, atol=0)
+    assert np.allclose(h, golden[f"{n}/h"], rtol=1e-14, atol=0)
+    H0, c0 = po.task_objective(*tasks[0])
+    assert np.allclose(H0, golden[f"{n}/H_task0"], rtol=1e-13, atol=1e-15)
+    assert np.allclose(c0, golden[f"{n}/c_task0"], rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("n", NAMES)
+def test_c_oracle_stacking_matches_reference(golden, n):
+    nv, dt, tasks, blocks, barriers, _, _ = _terms(golden, n)
+    J = np.concatenate([t[0] for t in tasks])[None]
+    e = np.concatenate([t[1] for t in tasks])[None]
+    cost = np.concatenate([po.weight_vector(t[2], t[0].shape[0]) for t in tasks])
+    rows = np.cumsum([0] + [t[0].shape[0] for t in tasks]).astype(np.int32)
+    gain = np.array([t[3] for t in tasks])
+    lm = np.array([t[4] for t in tasks])
+    diag_extra = None
+    if barriers:
+        diag_extra = np.array([sum(b[3] / np.linalg.norm(b[0]) ** 2 for b in barriers)])
+    out = c_oracle.solve_ik_batch(J, e, cost, gain, lm, rows, 1e-12, golden[f"{n}/G"][None], golden[f"{n}/h"][None],
+                                  diag_extra=diag_extra, want_Hc=True)
+    assert np.allclose(out["H"][0], golden[f"{n}/P"], rtol=1e-13, atol=1e-15)
+    assert np.allclose(out["c"][0], golden[f"{n}/qvec"], rtol=1e-13, atol=1e-15)
+    # and the solve on the reference's own (P, q, G, h) is KKT-certified
+    assert out["status"][0] == 0
+    stat, viol, lam = po.kkt_residuals(golden[f"{n}/P"], golden[f"{n}/qvec"], golden[f"{n}/G"], golden[f"{n}/h"], out["dq"][0])
+    assert stat < 1e-10 and viol < 1e-12
