@@ -20,15 +20,30 @@
 // (one QP per wave), so the data-dependent active-set iteration never diverges.
 //
 // The file only uses the primitives of wave.h (lane_id, wave_sync, bcast,
-// wave_sum, wave_argmin, from_next_lane, shared_base); the CPU wave emulator
+// wave_sum, wave_min, key_pack, fast_rcp/rsqrt, from_next_lane, shared_base); the CPU wave emulator
 // under tests/emu provides the same names to run this exact source in tests.
 #pragma once
 
 #include <cmath>
 #include <cstdint>
 
+// Tuning knobs (compile-time): how many independent LDS loads are batched before
+// their FMAs are pinned, and the occupancy the register allocator is told to aim for.
+// Measured on MI355X (profiles/): nv <= 32 runs best at 4 waves/SIMD (128 VGPRs) with
+// groups of 4; the larger register-resident rows (NV >= 40) need the 256-VGPR budget.
+#ifndef PINKHIP_GROUP
+#define PINKHIP_GROUP 4
+#endif
+#ifndef PINKHIP_WAVES_SMALL
+#define PINKHIP_WAVES_SMALL 4  // NV <= 32
+#endif
+#ifndef PINKHIP_WAVES_LARGE
+#define PINKHIP_WAVES_LARGE 2  // NV >= 40
+#endif
+
 namespace pinkhip {
 
+constexpr int kG = PINKHIP_GROUP;
 constexpr int STATUS_OPTIMAL = 0;
 constexpr int STATUS_MAX_ITER = 1;
 constexpr int STATUS_INFEASIBLE = 2;
@@ -100,6 +115,7 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   using S = Lds<NV>;
   constexpr int NVP = S::NVP, GP = S::GP;
   constexpr double INF = INFINITY;
+  constexpr double BIG = 1e300;  // finite stand-in for +inf inside packed argmin keys
   double *sm = shared_base();
   double *Ls = sm + S::oL;
   double *xs = sm + S::oX;
@@ -126,16 +142,13 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   const double *eb = a.e + b * (long long)K;
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
 
-  int RC = (NV * NVP) / nv;  // rows per staging chunk
-  if (RC > kWave) RC = kWave;
+  // Rows are staged with the compile-time pitch NV so that the uniform (broadcast)
+  // reads below have static, 16-byte aligned offsets (ds_read_b128 = 2 doubles).
+  constexpr int RC = (NVP < 32) ? NVP : 32;  // rows per staging chunk (NVP*NV doubles available)
   for (int r0 = 0; r0 < Kd; r0 += RC) {
     const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;
     wave_sync();
-    {
-      const double *src = Jb + (long long)r0 * nv;
-      const int n = rc * nv;
-      for (int idx = lane; idx < n; idx += kWave) Ls[idx] = src[idx];
-    }
+    stage_rows(Ls, NV, Jb + (long long)r0 * nv, rc, nv, lane);
     if (lane < rc) {
       const int k = r0 + lane;
       const double w = costb[k], ev = eb[k], g = a.row_gain[k], l = a.row_lm[k];
@@ -146,14 +159,16 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
     }
     wave_sync();
     for (int k = 0; k < rc; ++k) {
-      const double *row = Ls + k * nv;
+      const double *row = Ls + k * NV;
       const double jki = row[li];
       const double aa = was[k] * jki;
       ci += gs[k] * jki;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        M[j] += aa * row[j];  // row[j], j >= nv: stale but in-bounds, zeroed below
-        pin(M[j]);
+      for (int j0 = 0; j0 < NV; j0 += kG) {
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) M[j] += aa * row[j];  // j >= nv: stale LDS, zeroed below
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) pin(M[j]);
       }
     }
   }
@@ -234,7 +249,7 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
       status = STATUS_NOT_PD;
       p = 1.0;
     }
-    const double rinv = 1.0 / sqrt(p);
+    const double rinv = fast_rsqrt(p);
     const double lij = M[j] * rinv;
     M[j] = lij;
     if (lane >= j && lane < NV) Ls[lane * NVP + j] = lij;
@@ -244,9 +259,13 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
     cp = (lane > j) ? cp - lij * yj : (lane == j ? yj : cp);
     wave_sync();
 #pragma unroll
-    for (int m = j + 1; m < NV; ++m) {
-      M[m] -= lij * xs[m];
-      pin(M[m]);
+    for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m > j) M[m] -= lij * xs[m];
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m > j) pin(M[m]);
     }
     wave_sync();
   }
@@ -258,18 +277,23 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   for (int j = 0; j < NV; ++j) {
     double acc = (lane == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int m = 0; m < j; ++m) {
-      acc -= Ls[j * NVP + m] * Jr[m];
-      if ((m & 3) == 3) pin(acc);
+    for (int m0 = 0; m0 < j; m0 += kG) {
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m < j) acc -= Ls[j * NVP + m] * Jr[m];
+      pin(acc);
     }
     Jr[j] = acc * ds[j];
     pin(Jr[j]);
   }
+  double rown2 = 0.0;  // |row i of J|^2 = (H^-1)_ii, invariant under J <- J Q
+#pragma unroll
+  for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
   double x = 0.0;  // unconstrained minimum x = L^-T y
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     x += Jr[j] * xs[j];
-    if ((j & 3) == 3) pin(x);
+    if ((j & (kG - 1)) == kG - 1) pin(x);
   }
   wave_sync();
 
@@ -278,6 +302,8 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   const double lbv = in ? a.lb[b * (long long)nv + lane] : -INF;
   const double ubv = in ? a.ub[b * (long long)nv + lane] : INF;
   const double tol = 1e-13;
+  const double thr_lo = (in && lbv > -INF) ? -tol * (1.0 + fabs(lbv)) : -INF;  // -inf: never violated
+  const double thr_up = (in && ubv < INF) ? -tol * (1.0 + fabs(ubv)) : -INF;
   const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
   int q = 0, it = 0;
   int bstate = 0;   // lane i: 0 free, 1 lower bound active, 2 upper bound active
@@ -287,20 +313,12 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   bool running = (status == STATUS_OPTIMAL);
 
   while (running) {
-    // (a) most violated constraint, violation / row norm as quadprog
-    double best = INF, sd = 0.0;
-    int bid = 0x7fffffff;
+    // (a) most violated constraint, violation / row norm as quadprog.  `best` is a
+    // key: the (negative) scaled violation with the constraint id in its low bits.
+    double best = BIG, sd = 0.0;
     const double slo = x - lbv, sup = ubv - x;
-    if (in) {
-      if (lbv > -INF && bstate != 1 && slo < -tol * (1.0 + fabs(lbv))) {
-        best = slo;
-        bid = lane;
-      }
-      if (ubv < INF && bstate != 2 && sup < -tol * (1.0 + fabs(ubv)) && sup < best) {
-        best = sup;
-        bid = 64 + lane;
-      }
-    }
+    if (bstate != 1 && slo < thr_lo) best = key_pack(slo, lane);
+    if (bstate != 2 && sup < thr_up && sup < best) best = key_pack(sup, 64 + lane);
     if (md > 0) {
       if (lane < NV) xs[lane] = x;
       wave_sync();
@@ -309,15 +327,13 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
         for (int j = 0; j < nv; ++j) s -= Gs[lane * GP + j] * xs[j];
         sd = s;
         const double sc = s * ginv;
-        if (!dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) {
-          best = sc;
-          bid = 128 + lane;
-        }
+        if (!dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) best = key_pack(sc, 128 + lane);
       }
       wave_sync();
     }
-    wave_argmin(best, bid);
-    if (!(best < INF)) break;  // no violated constraint: optimal
+    best = wave_min(best);
+    if (!(best < 0.0)) break;  // no violated constraint: optimal
+    const int bid = key_payload(best);
     const int kind = bid >> 6, src = bid & 63;
     double sp = (kind == 0) ? bcast(slo, src) : (kind == 1) ? bcast(sup, src) : bcast(sd, src);
     double uplus = 0.0;
@@ -331,13 +347,13 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
       // (b) d = J^T n+ ; n+ = +e_src (lower), -e_src (upper), -g_src (dense row)
       double dl = 0.0;
       if (kind < 2) {
-        const double sg = (kind == 0) ? 1.0 : -1.0;
-        if (lane == src) {
+        if (lane == src) {  // row src of J -> LDS (one active lane, b128 stores), sign applied on read
 #pragma unroll
-          for (int j = 0; j < NV; ++j) ds[j] = sg * Jr[j];
+          for (int j = 0; j < NV; ++j) ds[j] = Jr[j];
         }
         wave_sync();
-        dl = (lane < NV) ? ds[lv] : 0.0;
+        const double rowv = (lane < NV) ? ds[lv] : 0.0;
+        dl = (kind == 0) ? rowv : -rowv;
       } else {
         const double gi = in ? -Gs[src * GP + lane] : 0.0;
 #pragma unroll
@@ -346,14 +362,17 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
           if (lane == j) dl = s;
         }
       }
-      const double dd = wave_sum(dl * dl);
+      // |d|^2 = n+^T H^-1 n+.  For a box row it is the squared norm of row src of J,
+      // which the orthogonal updates of J never change: computed once per lane.
+      const double dd = (kind < 2) ? bcast(rown2, src) : wave_sum(dl * dl);
       const double d2n = wave_sum((lane >= q) ? dl * dl : 0.0);  // = z^T n+ = |d2|^2
       const bool lin_dep = !(d2n > 1e-24 * dd);
       const double dq_ = bcast(dl, q < kWave ? q : kWave - 1);
-      const double nrm2 = sqrt(d2n);
+      const double rn2 = lin_dep ? 0.0 : fast_rsqrt(d2n);  // 1/|d2|
+      const double nrm2 = d2n * rn2;
       const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
       // Householder reflector H = I - beta v v^T with H d2 = -sgq |d2| e_q
-      const double beta = lin_dep ? 0.0 : 1.0 / (nrm2 * (nrm2 + fabs(dq_)));
+      const double beta = lin_dep ? 0.0 : rn2 * fast_rcp(nrm2 + fabs(dq_));
       if (lane < NV) {
         d2s[lane] = (lane >= q) ? dl : 0.0;
         vs[lane] = (lane > q) ? dl : (lane == q ? dq_ + sgq * nrm2 : 0.0);
@@ -364,27 +383,26 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
       for (int j = 0; j < NV; ++j) {
         z += Jr[j] * d2s[j];
         w += Jr[j] * vs[j];
-        if ((j & 3) == 3) {
+        if ((j & (kG - 1)) == kG - 1) {
           pin(z);
           pin(w);
         }
       }
       // r = R^-1 d1 (dual step direction): column-oriented back substitution
-      double rv = 0.0, dp = dl;
-      for (int k = q - 1; k >= 0; --k) {
+      // (lane k's dp is final once step k is reached, so r_k = dp * rdiag at the end)
+      double dp = dl;
+      for (int k = q - 1; k > 0; --k) {
         const double rk = bcast(dp * rdiag, k);
         if (lane < k) dp -= Rs[k * NVP + lane] * rk;
-        if (lane == k) rv = rk;
       }
+      const double rv = dp * rdiag;
       // (c) step lengths
-      double t1 = INF;
-      int kd = 0x7fffffff;
-      if (lane < q && rv > 0.0) {
-        t1 = u / rv;
-        kd = lane;
-      }
-      wave_argmin(t1, kd);
-      const double t2 = lin_dep ? INF : -sp / d2n;
+      const bool blocking = lane < q && rv > 0.0;
+      const double ratio = blocking ? u * fast_rcp(rv) : BIG;
+      const double k1 = wave_min(blocking ? key_pack(ratio, lane) : BIG);
+      const int kd = key_payload(k1);
+      const double t1 = (k1 < BIG) ? bcast(ratio, kd & 63) : INF;
+      const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
       const double t = (t1 < t2) ? t1 : t2;
       if (!(t < INF)) {  // quadprog: "constraints are inconsistent, no solution"
         status = STATUS_INFEASIBLE;
@@ -404,15 +422,17 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
           // full step: the constraint becomes active.  J2 <- J2 H, R gains column [d1; -sgq|d2|]
           const double wb = beta * w;
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            Jr[j] -= wb * vs[j];
-            pin(Jr[j]);
+          for (int j0 = 0; j0 < NV; j0 += kG) {
+#pragma unroll
+            for (int j = j0; j < j0 + kG; ++j) Jr[j] -= wb * vs[j];
+#pragma unroll
+            for (int j = j0; j < j0 + kG; ++j) pin(Jr[j]);
           }
           const double rqq = -sgq * nrm2;
           if (lane < q) Rs[q * NVP + lane] = dl;
           if (lane == q) {
             Rs[q * NVP + q] = rqq;
-            rdiag = 1.0 / rqq;
+            rdiag = -sgq * rn2;
             A = bid;
             u = uplus;
           }
@@ -459,8 +479,8 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
             const double rb = mine ? Rs[lane * NVP + l + 1] : 0.0;
             const double ga = bcast(ra, l), gb = bcast(rb, l);
             if (gb != 0.0) {
-              const double hy = sqrt(ga * ga + gb * gb);
-              const double cc = ga / hy, ss = gb / hy;
+              const double rh = fast_rsqrt(ga * ga + gb * gb);
+              const double cc = ga * rh, ss = gb * rh;
               if (mine) {
                 Rs[lane * NVP + l] = cc * ra + ss * rb;
                 Rs[lane * NVP + l + 1] = -ss * ra + cc * rb;
@@ -471,7 +491,7 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
             }
           }
         }
-        if (lane >= kd && lane < q) rdiag = 1.0 / Rs[lane * NVP + lane];
+        if (lane >= kd && lane < q) rdiag = fast_rcp(Rs[lane * NVP + lane]);
         wave_sync();
       }
       // slack of the pending constraint at the new x, then iterate (b) with the same n+
@@ -492,7 +512,7 @@ __device__ inline void ik_instance(const KernelArgs &a, long long b) {
 }
 
 template <int NV>
-__global__ void __launch_bounds__(kWave) ik_solve_kernel(KernelArgs a) {
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_ATTR(NV) ik_solve_kernel(KernelArgs a) {
   ik_instance<NV, true>(a, block_id());
 }
 

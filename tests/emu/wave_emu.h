@@ -22,6 +22,7 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(x)
+#define PINKHIP_OCCUPANCY_ATTR(NV)
 
 namespace pinkhip {
 
@@ -110,33 +111,53 @@ inline int bcast_i(int v, int src) {
   return r;
 }
 
-inline double wave_sum(double v) {
-  // same butterfly order as the device code (xor 32, 16, ..., 1)
+inline double emu_exchange(double v, int partner_of_me, int tag) {
   Emu &e = emu();
-  for (int m = 32; m >= 1; m >>= 1) {
-    e.slot_d[e.cur] = v;
-    emu_rendezvous(6);
-    const double o = e.slot_d[e.cur ^ m];
-    emu_rendezvous(7);
-    v += o;
-  }
-  return v;
+  e.slot_d[e.cur] = v;
+  emu_rendezvous(tag);
+  const double o = e.slot_d[partner_of_me];
+  emu_rendezvous(tag + 1);
+  return o;
 }
 
-inline void wave_argmin(double &v, int &idx) {
-  Emu &e = emu();
-  for (int m = 32; m >= 1; m >>= 1) {
-    e.slot_d[e.cur] = v;
-    e.slot_i[e.cur] = idx;
-    emu_rendezvous(8);
-    const double ov = e.slot_d[e.cur ^ m];
-    const int oi = e.slot_i[e.cur ^ m];
-    emu_rendezvous(9);
-    const bool take = (ov < v) || (ov == v && oi < idx);
-    v = take ? ov : v;
-    idx = take ? oi : idx;
-  }
+// same combination order as the device code (wave.h): xor1, xor2, half-mirror,
+// mirror inside each row of 16, then row_bcast15 (rows 1,3 += lane 15 of the row
+// before), row_bcast31 (rows 2,3 += lane 31), result read from lane 63
+template <class Op>
+inline double emu_reduce(double v, double ident, Op op, int tag) {
+  const int l = emu().cur;
+  v = op(v, emu_exchange(v, l ^ 1, tag));
+  v = op(v, emu_exchange(v, l ^ 2, tag));
+  v = op(v, emu_exchange(v, (l & ~7) | (7 - (l & 7)), tag));
+  v = op(v, emu_exchange(v, (l & ~15) | (15 - (l & 15)), tag));
+  const int row = l >> 4;
+  double t = emu_exchange(v, (row == 1 || row == 3) ? (row - 1) * 16 + 15 : l, tag);
+  v = op(v, (row == 1 || row == 3) ? t : ident);
+  t = emu_exchange(v, 31, tag);
+  v = op(v, (row >= 2) ? t : ident);
+  return bcast(v, 63);
 }
+inline double wave_sum(double v) {
+  return emu_reduce(v, 0.0, [](double a, double b) { return a + b; }, 6);
+}
+inline double wave_min(double v) {
+  return emu_reduce(v, INFINITY, [](double a, double b) { return std::fmin(a, b); }, 8);
+}
+
+inline double key_pack(double v, int payload) {
+  long long b;
+  std::memcpy(&b, &v, 8);
+  b = (b & ~0xFFLL) | (long long)(payload & 0xFF);
+  std::memcpy(&v, &b, 8);
+  return v;
+}
+inline int key_payload(double k) {
+  long long b;
+  std::memcpy(&b, &k, 8);
+  return (int)(b & 0xFF);
+}
+inline double fast_rcp(double x) { return 1.0 / x; }
+inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 inline double from_next_lane(double v) {
   Emu &e = emu();
