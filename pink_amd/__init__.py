@@ -1,0 +1,21 @@
+"""pink_amd: MI355X-native batched differential inverse kinematics behind Pink's API.
+
+The public surface mirrors ``pink/__init__.py`` (``solve_ik``, ``build_ik``,
+``Configuration``, ``Task``) and adds ``solve_ik_batch`` and the packed-batch
+interface (``IKBatch``, ``BatchSolver``).
+"""
+
+__version__ = "0.1.0"
+
+from .batch import IKBatch, pack_terms
+from .batch_solver import BatchResult, BatchSolver
+from .configuration import Configuration, Model, build_chain, load_urdf
+from .exceptions import NoSolutionFound, NotWithinConfigurationLimits, PinkError, TargetNotSet
+from .solve_ik import build_ik, pack_configurations, solve_ik, solve_ik_batch
+from .tasks import DampingTask, FrameTask, PostureTask, Task
+
+__all__ = [
+    "BatchResult", "BatchSolver", "Configuration", "DampingTask", "FrameTask", "IKBatch", "Model", "NoSolutionFound",
+    "NotWithinConfigurationLimits", "PinkError", "PostureTask", "TargetNotSet", "Task", "build_chain", "build_ik",
+    "load_urdf", "pack_configurations", "pack_terms", "solve_ik", "solve_ik_batch",
+]

@@ -1,0 +1,190 @@
+"""``build_ik`` / ``solve_ik`` with Pink's signatures, plus ``solve_ik_batch``.
+
+Mirrors ``pink/solve_ik.py:152-275``.  The host evaluates the user's tasks /
+limits / barriers (Python objects, exactly as in Pink), packs the raw terms
+(``pink_amd.batch``) and hands them to the HIP library, which stacks the QP and
+solves it.  The only accepted ``solver`` is the MI355X one: there is no
+qpsolvers dispatch and no CPU path.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .batch import BarrierTerm, DenseTaskTerm, DiagonalTaskTerm, IKBatch, pack_terms, split_box_rows
+from .exceptions import NoSolutionFound, PinkError
+
+SOLVER_NAMES = ("mi355x", "pinkhip")
+
+
+class IKProblem:
+    """What ``pink.build_ik`` returns (a ``qpsolvers.Problem``): ``P, q, G, h, A, b``.
+
+    ``G, h`` are stacked on the host in Pink's order (limits, then barriers;
+    ``pink/solve_ik.py:107-122``); ``P, q`` are evaluated lazily by the HIP stack
+    kernel.  ``batch`` is the packed single-instance batch handed to the solver.
+    """
+
+    def __init__(self, batch: IKBatch, G: Optional[np.ndarray], h: Optional[np.ndarray]):
+        self.batch = batch
+        self.G, self.h = G, h
+        self.A = self.b = None
+        self._Pq: Optional[Tuple[np.ndarray, np.ndarray]] = None
+
+    def _stack(self):
+        if self._Pq is None:
+            from .runtime import default_solver
+
+            H, c = default_solver().stack(self.batch)
+            self._Pq = (H[0], c[0])
+        return self._Pq
+
+    @property
+    def P(self) -> np.ndarray:
+        return self._stack()[0]
+
+    @property
+    def q(self) -> np.ndarray:
+        return self._stack()[1]
+
+
+def _collect_terms(configuration, tasks, dt, limits, barriers):
+    """Evaluate tasks / limits / barriers at one configuration (host side)."""
+    nv = configuration.model.nv
+    task_terms = [t.as_term(configuration) for t in tasks]
+    if limits is None:  # model defaults, pink/solve_ik.py:94-105
+        limits = [configuration.model.configuration_limit, configuration.model.velocity_limit]
+        fb = getattr(configuration.model, "floating_base_velocity_limit", None)
+        if fb is not None:
+            limits.append(fb)
+    lb = np.full(nv, -np.inf)
+    ub = np.full(nv, np.inf)
+    dense_rows = []
+    G_list, h_list = [], []
+    for limit in limits:
+        box = limit.compute_box(configuration, dt) if hasattr(limit, "compute_box") else None
+        if box is not None:
+            idx, lo, up = box
+            lb[idx] = np.maximum(lb[idx], lo)
+            ub[idx] = np.minimum(ub[idx], up)
+            continue
+        mv = limit.compute_qp_inequalities(configuration, dt)
+        if mv is None:  # pink/solve_ik.py:111
+            continue
+        blo, bup, Gd, hd = split_box_rows(mv[0], mv[1], nv)
+        lb, ub = np.maximum(lb, blo), np.minimum(ub, bup)
+        if len(hd):
+            dense_rows.append((Gd[None], hd[None]))
+    barrier_terms = [b.as_term(configuration) for b in (barriers or [])]
+    return nv, task_terms, lb, ub, dense_rows, barrier_terms, limits
+
+
+def _pink_rows(configuration, dt, limits, barriers):
+    """``(G, h)`` exactly as Pink stacks them, for ``IKProblem.G/h``."""
+    G_list, h_list = [], []
+    for limit in limits:
+        mv = limit.compute_qp_inequalities(configuration, dt)
+        if mv is not None:
+            G_list.append(mv[0])
+            h_list.append(mv[1])
+    for barrier in barriers or []:
+        Gb, hb = barrier.compute_qp_inequalities(configuration, dt)
+        G_list.append(Gb)
+        h_list.append(hb)
+    if not G_list:
+        return None, None  # pink/solve_ik.py:120-121
+    return np.vstack(G_list), np.hstack(h_list)
+
+
+def build_ik(configuration, tasks: Iterable, dt: float, damping: float = 1e-12, limits=None, barriers=None,
+             constraints=None) -> IKProblem:
+    """Build the QP of one IK step (``pink/solve_ik.py:152-203``)."""
+    if constraints:
+        raise PinkError("equality constraints (constraints=) are reserved in the MI355X ABI (n_eq must be 0)")
+    tasks = list(tasks)
+    nv, task_terms, lb, ub, dense_rows, barrier_terms, limits = _collect_terms(configuration, tasks, dt, limits, barriers)
+    batch = pack_terms(nv, task_terms, dt, damping, boxes=[(lb[None], ub[None])], dense_rows=dense_rows,
+                       barriers=barrier_terms, batch_size=1)
+    G, h = _pink_rows(configuration, dt, limits, barriers)
+    return IKProblem(batch, G, h)
+
+
+def solve_ik(configuration, tasks: Iterable, dt: float, solver: str = "mi355x", damping: float = 1e-12, limits=None,
+             barriers=None, constraints=None, safety_break: bool = True, **kwargs) -> np.ndarray:
+    """Velocity tangent to ``configuration`` that best fulfils ``tasks``
+    (``pink/solve_ik.py:206-275``).  ``kwargs`` accepts ``max_iter``."""
+    if solver not in SOLVER_NAMES:
+        raise PinkError(f"solver={solver!r}: this build only provides the MI355X solver {SOLVER_NAMES}")
+    from .runtime import default_solver
+
+    configuration.check_limits(safety_break=safety_break)  # solve_ik.py:260
+    problem = build_ik(configuration, tasks, dt, damping, limits, barriers, constraints)
+    result = default_solver().solve(problem.batch, max_iter=int(kwargs.get("max_iter", 0)))
+    if not result.all_found:  # solve_ik.py:271-273
+        raise NoSolutionFound(problem, result, result.failed_indices(), result.status[result.status != 0])
+    return result.dq[0] / dt
+
+
+def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, damping: float = 1e-12, limits=None,
+                        barriers=None) -> IKBatch:
+    """Evaluate the same task / limit / barrier objects at every configuration and
+    pack the batch.  The task list may also be a list of per-instance lists (one
+    target per instance): ``tasks[b]`` is then used for ``configurations[b]``."""
+    B = len(configurations)
+    per_instance = B > 0 and len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    cols = None
+    lbs, ubs, dense, bterms = [], [], [], []
+    nv = configurations[0].model.nv if B else 0
+    for b, cfg in enumerate(configurations):
+        tl = tasks[b] if per_instance else tasks
+        _, tt, lb, ub, dr, bt, _ = _collect_terms(cfg, tl, dt, limits, barriers)
+        if cols is None:
+            cols = [[t] for t in tt]
+        else:
+            for c, t in zip(cols, tt):
+                c.append(t)
+        lbs.append(lb), ubs.append(ub), dense.append(dr), bterms.append(bt)
+    merged = []
+    for c in cols or []:
+        t0 = c[0]
+        e = np.concatenate([t.e for t in c], axis=0)
+        if isinstance(t0, DiagonalTaskTerm):
+            merged.append(DiagonalTaskTerm(col0=t0.col0, e=e, cost=t0.cost, gain=t0.gain, lm_damping=t0.lm_damping))
+        else:
+            merged.append(DenseTaskTerm(J=np.concatenate([t.J for t in c], axis=0), e=e, cost=t0.cost, gain=t0.gain,
+                                        lm_damping=t0.lm_damping))
+    dense_rows = []
+    if B and dense[0]:
+        for k in range(len(dense[0])):
+            dense_rows.append((np.concatenate([d[k][0] for d in dense], axis=0), np.concatenate([d[k][1] for d in dense], axis=0)))
+    barrier_terms = []
+    if B and bterms[0]:
+        for k, b0 in enumerate(bterms[0]):
+            sd = None if b0.safe_displacement is None else np.concatenate([bt[k].safe_displacement for bt in bterms], axis=0)
+            barrier_terms.append(BarrierTerm(J_h=np.concatenate([bt[k].J_h for bt in bterms], axis=0),
+                                             h=np.concatenate([bt[k].h for bt in bterms], axis=0), gain=b0.gain,
+                                             safe_displacement_gain=b0.safe_displacement_gain, safe_displacement=sd))
+    return pack_terms(nv, merged, dt, damping, boxes=[(np.array(lbs), np.array(ubs))] if B else (),
+                      dense_rows=dense_rows, barriers=barrier_terms, batch_size=B)
+
+
+def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
+                   limits=None, barriers=None, safety_break: bool = True, solver_handle=None, **kwargs) -> np.ndarray:
+    """Batched ``solve_ik``: velocities ``[B, nv]`` for ``B`` configurations.
+
+    Raises :class:`NoSolutionFound` listing the failing instances (the batched
+    analogue of ``pink/solve_ik.py:271-273``).
+    """
+    if solver not in SOLVER_NAMES:
+        raise PinkError(f"solver={solver!r}: this build only provides the MI355X solver {SOLVER_NAMES}")
+    from .runtime import default_solver
+
+    for cfg in configurations:
+        cfg.check_limits(safety_break=safety_break)
+    batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers)
+    result = (solver_handle or default_solver()).solve(batch, max_iter=int(kwargs.get("max_iter", 0)))
+    if not result.all_found:
+        raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])
+    return result.dq / dt

@@ -1,0 +1,71 @@
+"""Frame task: regulate the pose of a robot frame (``pink/tasks/frame_task.py``)."""
+
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from ..exceptions import TargetNotSet, TaskDefinitionError
+from ..lie import SE3, Jlog6, log6
+from .task import Task
+
+
+class FrameTask(Task):
+    """6-D pose task; cost is ``[position x3, orientation x3]`` (``frame_task.py:44-127``)."""
+
+    def __init__(self, frame: str, position_cost, orientation_cost, lm_damping: float = 0.0, gain: float = 1.0):
+        super().__init__(cost=np.ones(6), gain=gain, lm_damping=lm_damping)
+        self.frame = frame
+        self.transform_target_to_world: Optional[SE3] = None
+        self.set_position_cost(position_cost)
+        self.set_orientation_cost(orientation_cost)
+
+    def _set_cost(self, values, sl: slice, what: str) -> None:
+        v = np.asarray(values, dtype=float)
+        if v.ndim > 0 and v.shape != (3,):
+            raise TaskDefinitionError(f"{what} cost should be a float or a vector of 3, got shape {v.shape}")
+        if (v < 0.0).any():
+            raise TaskDefinitionError(f"{what} cost should be >= 0")
+        self.cost[sl] = v
+
+    def set_position_cost(self, position_cost: Union[float, Sequence[float], np.ndarray]) -> None:
+        self._set_cost(position_cost, slice(0, 3), "position")
+
+    def set_orientation_cost(self, orientation_cost: Union[float, Sequence[float], np.ndarray]) -> None:
+        self._set_cost(orientation_cost, slice(3, 6), "orientation")
+
+    @property
+    def position_cost(self):
+        return self.cost[0:3]
+
+    @property
+    def orientation_cost(self):
+        return self.cost[3:6]
+
+    def set_target(self, transform_target_to_world: SE3) -> None:
+        self.transform_target_to_world = transform_target_to_world.copy()
+
+    def set_target_from_configuration(self, configuration) -> None:
+        self.set_target(configuration.get_transform_frame_to_world(self.frame))
+
+    def compute_error(self, configuration) -> np.ndarray:
+        """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``
+        (``frame_task.py:176-193``)."""
+        if self.transform_target_to_world is None:
+            raise TargetNotSet(f"no target set for frame '{self.frame}'")
+        T_fw = configuration.get_transform_frame_to_world(self.frame)
+        return log6(T_fw.actInv(self.transform_target_to_world))
+
+    def compute_jacobian(self, configuration) -> np.ndarray:
+        """``-Jlog6(T_target^-1 T_frame) @ J_frame`` with the body Jacobian of the frame
+        (``frame_task.py:217-227``)."""
+        if self.transform_target_to_world is None:
+            raise TargetNotSet(f"no target set for frame '{self.frame}'")
+        T_fw = configuration.get_transform_frame_to_world(self.frame)
+        T_ft = self.transform_target_to_world.actInv(T_fw)
+        return -Jlog6(T_ft) @ configuration.get_frame_jacobian(self.frame)
+
+    def __repr__(self):
+        return (f"FrameTask(frame={self.frame!r}, gain={self.gain}, orientation_cost={self.orientation_cost}, "
+                f"position_cost={self.position_cost}, lm_damping={self.lm_damping})")

@@ -1,0 +1,202 @@
+"""The Pink-style Python surface (solve_ik, build_ik, Task, Limit, Barrier) on top
+of the packed-batch path.  Runs on the CPU wave emulator here and, marked ``gpu``,
+on the MI355X.  Each test names the reference test it restates."""
+import numpy as np
+import pytest
+
+import pink_amd
+from oracle import c_oracle
+from oracle import pink_oracle as po
+from pink_amd import (Configuration, DampingTask, FrameTask, NoSolutionFound, NotWithinConfigurationLimits, PostureTask,
+                      TargetNotSet, build_chain, build_ik, solve_ik, solve_ik_batch)
+from pink_amd.barriers import PositionBarrier
+from pink_amd.lie import SE3, log6
+from pink_amd.limits import ConfigurationLimit, VelocityLimit
+from pink_amd.runtime import set_default_solver
+from pink_amd.tasks import LowAccelerationTask
+
+Q0 = np.array([0.3, -0.8, 1.2, 0.4, -0.3, 0.5])
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    if request.param == "emu":
+        set_default_solver(request.getfixturevalue("emu"))
+    else:
+        set_default_solver(request.getfixturevalue("gpu_solver"))
+    yield request.param
+    set_default_solver(None)
+
+
+def _arm():
+    m = build_chain(6)
+    return m, Configuration(m, Q0)
+
+
+def test_frame_jacobians_by_finite_differences():
+    """tests/test_jacobians.py:47-84 (h = 1e-6, tol 1e-5)."""
+    m, cfg = _arm()
+    task = FrameTask("tool0", 1.0, 1.0)
+    tgt = cfg.get_transform_frame_to_world("tool0")
+    tgt.translation += [0.05, -0.1, 0.02]
+    task.set_target(tgt)
+    J = task.compute_jacobian(cfg)
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = 1e-6
+        fd = (task.compute_error(Configuration(m, Q0 + d)) - task.compute_error(Configuration(m, Q0 - d))) / 2e-6
+        assert np.abs(J[:, k] - fd).max() < 1e-5
+
+
+def test_target_not_set_and_zero_error_at_target():
+    """tests/test_frame_task.py:112-121, pink/tasks/frame_task.py:176-177."""
+    m, cfg = _arm()
+    task = FrameTask("tool0", 1.0, 1.0)
+    with pytest.raises(TargetNotSet):
+        task.compute_error(cfg)
+    task.set_target_from_configuration(cfg)
+    assert np.linalg.norm(task.compute_error(cfg)) < 1e-10
+    assert np.allclose(task.compute_jacobian(cfg), -cfg.get_frame_jacobian("tool0"))  # Jlog6(I) = I
+
+
+def test_task_qp_objective_known_answers(backend):
+    """tests/test_frame_task.py:123-141; test_low_acceleration_task.py:34-42; test_damping_task.py:34-39."""
+    m, cfg = _arm()
+    task = FrameTask("tool0", 1.0, 1.0)
+    tgt = cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.0, 0.01, 0.0])
+    task.set_target(tgt)
+    J, e = task.compute_jacobian(cfg), task.compute_error(cfg)
+    H, c = task.compute_qp_objective(cfg)
+    assert np.allclose(J.T @ J, H) and np.allclose(e.T @ J, c)
+    la = LowAccelerationTask(cost=1.0)
+    v_prev = np.array([1.0, 2.0, 3.0, 4.0, -3.0, -2.0])
+    la.set_last_integration(v_prev, 1.234e-2)
+    H, c = la.compute_qp_objective(cfg)
+    assert np.linalg.norm(H - np.eye(6)) < 1e-10 and np.linalg.norm(c + v_prev * 1.234e-2) < 1e-10
+    H, c = DampingTask(cost=1.0).compute_qp_objective(cfg)
+    assert np.array_equal(H, np.eye(6)) and not c.any()
+
+
+def test_limits_shapes_and_none():
+    """tests/test_limits.py:22-66, tests/test_velocity_limit.py:46-55."""
+    m, cfg = _arm()
+    for lim in (ConfigurationLimit(m), VelocityLimit(m)):
+        G, h = lim.compute_qp_inequalities(cfg, 1e-3)
+        assert G.shape == (12, 6) and h.shape == (12,)
+    G, h = VelocityLimit(m, np.full(6, 2.0)).compute_qp_inequalities(cfg, 1e-3)
+    assert np.allclose(h, 2e-3)
+    free = build_chain(3, limit=np.inf, velocity=np.inf)
+    c3 = Configuration(free, np.zeros(3))
+    assert ConfigurationLimit(free).compute_qp_inequalities(c3, 1e-3) is None
+    assert VelocityLimit(free).compute_qp_inequalities(c3, 1e-3) is None
+    assert build_ik(c3, [], dt=1.0).G is None  # tests/test_solve_ik.py:67-77
+
+
+def test_check_limits_raises_or_warns(backend):
+    """tests/test_solve_ik.py:39-65."""
+    m = build_chain(6, limit=1.0)
+    cfg = Configuration(m, np.array([0.0, 1.5, 0, 0, 0, 0]))
+    with pytest.raises(NotWithinConfigurationLimits):
+        solve_ik(cfg, [], dt=1e-3)
+    solve_ik(cfg, [], dt=1e-3, safety_break=False, limits=[])  # warns only
+
+
+def test_no_task_and_fulfilled_task_give_zero_velocity(backend):
+    """tests/test_solve_ik.py:79-102."""
+    m, cfg = _arm()
+    assert np.allclose(solve_ik(cfg, [], dt=1e-3), 0.0)
+    task = FrameTask("tool0", 1.0, 1.0)
+    task.set_target_from_configuration(cfg)
+    assert np.allclose(solve_ik(cfg, [task], dt=5e-3, damping=1e-8), 0.0)
+
+
+def test_build_ik_matches_oracle_and_solve_matches(backend):
+    m, cfg = _arm()
+    task = FrameTask("tool0", [1.0, 2.0, 0.5], 0.3, lm_damping=0.1, gain=0.8)
+    post = PostureTask(cost=1e-2)
+    task.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.1, 0.2, -0.1]))
+    post.set_target(np.zeros(6))
+    dt = 5e-3
+    prob = build_ik(cfg, [task, post], dt)
+    tasks = [(task.compute_jacobian(cfg), task.compute_error(cfg), task.cost, 0.8, 0.1),
+             (post.compute_jacobian(cfg), post.compute_error(cfg), 1e-2, 1.0, 0.0)]
+    P, q = po.qp_objective(6, tasks, 1e-12)
+    assert np.allclose(prob.P, P, rtol=1e-13, atol=1e-15) and np.allclose(prob.q, q, rtol=1e-13, atol=1e-15)
+    assert prob.G.shape == (24, 6)
+    v = solve_ik(cfg, [task, post], dt)
+    x, st, _, _ = c_oracle.gi_solve(P, q, prob.G, prob.h)
+    assert st == 0 and np.abs(v * dt - x).max() < 1e-11
+
+
+def test_closed_loop_convergence(backend):
+    """tests/test_solve_ik.py:160-210 (error decreases monotonically and converges)."""
+    m, cfg = _arm()
+    task = FrameTask("tool0", 1.0, 1.0, lm_damping=1e-3)
+    post = PostureTask(cost=1e-3)
+    for t in (task, post):
+        t.set_target_from_configuration(cfg)
+    tgt = task.transform_target_to_world.copy()
+    tgt.translation[1] += 0.1
+    task.set_target(tgt)
+    dt, errs = 5e-3, []
+    for _ in range(120):
+        cfg.integrate_inplace(solve_ik(cfg, [task, post], dt), dt)
+        errs.append(np.linalg.norm(task.compute_error(cfg)))
+    big = [e for e in errs if e > 1e-4]  # monotone until the posture task balances the residual
+    assert errs[-1] < 1e-3 and all(b < a for a, b in zip(big, big[1:]))
+
+
+def test_position_barrier(backend):
+    """tests/test_solve_ik.py:104-158: satisfied barrier => v = 0, active barrier stops the motion."""
+    m, cfg = _arm()
+    y0 = cfg.get_transform_frame_to_world("tool0").translation[1]
+    task = FrameTask("tool0", 1.0, 1.0)
+    task.set_target_from_configuration(cfg)
+    bar = PositionBarrier("tool0", indices=[1], p_max=np.array([y0 + 0.01]), gain=np.array([100.0]), safe_displacement_gain=1.0)
+    assert bar.compute_qp_inequalities(cfg, 1e-3)[0].shape == (1, 6)
+    assert np.allclose(solve_ik(cfg, [task], dt=5e-3, barriers=[bar]), 0.0, atol=1e-9)
+    tgt = task.transform_target_to_world.copy()
+    tgt.translation[1] += 0.2
+    task.set_target(tgt)
+    dt = 5e-3
+    for _ in range(40):
+        cfg.integrate_inplace(solve_ik(cfg, [task], dt, barriers=[bar]), dt)
+    assert cfg.get_transform_frame_to_world("tool0").translation[1] <= y0 + 0.01 + 1e-4
+
+
+def test_solve_ik_batch_equals_loop_and_reports_failures(backend):
+    m = build_chain(6)
+    rng = np.random.default_rng(3)
+    cfgs = [Configuration(m, Q0 + 0.2 * rng.normal(size=6)) for _ in range(5)]
+    task = FrameTask("tool0", 1.0, 1.0, lm_damping=0.5)
+    post = PostureTask(cost=1e-3)
+    task.set_target(cfgs[0].get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.0, 0.1, 0.05]))
+    post.set_target(Q0)
+    V = solve_ik_batch(cfgs, [task, post], 5e-3)
+    for b, cfg in enumerate(cfgs):
+        assert np.array_equal(V[b], solve_ik(cfg, [task, post], 5e-3))
+
+    class Crossed(pink_amd.limits.Limit):
+        def compute_qp_inequalities(self, configuration, dt):
+            G = np.zeros((2, 6))
+            G[0, 2], G[1, 2] = 1.0, -1.0
+            return G, np.array([-1.0, -1.0])  # dq_2 <= -1 and dq_2 >= 1
+
+    with pytest.raises(NoSolutionFound) as ei:
+        solve_ik_batch(cfgs, [task, post], 5e-3, limits=[Crossed()])
+    assert ei.value.indices.tolist() == [0, 1, 2, 3, 4] and (ei.value.status == 2).all()
+    with pytest.raises(pink_amd.PinkError):
+        solve_ik(cfgs[0], [task], 5e-3, solver="quadprog")
+
+
+def test_urdf_reader_on_reference_robots():
+    import os
+
+    path = "/root/reference/examples/robots/double_pendulum.urdf"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not mounted")
+    m = pink_amd.load_urdf(path)
+    assert m.nv == 2 and m.nq == 2
+    cfg = Configuration(m, np.array([0.3, -0.4]))
+    J = cfg.get_frame_jacobian(m.frames[-1].name)
+    assert J.shape == (6, 2) and np.abs(J).max() > 0
