@@ -26,24 +26,35 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 // Tuning knobs (compile-time): how many independent LDS loads are batched before
 // their FMAs are pinned, and the occupancy the register allocator is told to aim for.
-// Measured on MI355X (profiles/): nv <= 32 runs best at 4 waves/SIMD (128 VGPRs) with
-// groups of 4; the larger register-resident rows (NV >= 40) need the 256-VGPR budget.
-#ifndef PINKHIP_GROUP
-#define PINKHIP_GROUP 4
+// Tuning (measured on MI355X, profiles/): the number of LDS loads batched before their FMAs
+// are pinned is 8 for NV >= 24 and 4 below; occupancy targets (waves per SIMD, i.e. the VGPR
+// budget handed to the register allocator) are set per kernel in wave.h.
+#ifndef PINKHIP_GROUP_LARGE
+#define PINKHIP_GROUP_LARGE 8  // NV >= 24
 #endif
-#ifndef PINKHIP_WAVES_SMALL
-#define PINKHIP_WAVES_SMALL 4  // NV <= 32
-#endif
-#ifndef PINKHIP_WAVES_LARGE
-#define PINKHIP_WAVES_LARGE 2  // NV >= 40
+#ifndef PINKHIP_GROUP_SMALL
+#define PINKHIP_GROUP_SMALL 4  // NV <= 16
 #endif
 
 namespace pinkhip {
 
-constexpr int kG = PINKHIP_GROUP;
+template <int NV>
+constexpr int group_size() {
+  return NV >= 24 ? PINKHIP_GROUP_LARGE : PINKHIP_GROUP_SMALL;
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 constexpr int STATUS_OPTIMAL = 0;
 constexpr int STATUS_MAX_ITER = 1;
 constexpr int STATUS_INFEASIBLE = 2;
@@ -113,7 +124,7 @@ __device__ inline void stage_rows(double *dst, int pitch, const double *src, int
 template <int NV, bool SOLVE>
 __device__ inline void ik_instance(const KernelArgs &a, long long b) {
   using S = Lds<NV>;
-  constexpr int NVP = S::NVP, GP = S::GP;
+  constexpr int NVP = S::NVP, GP = S::GP, kG = group_size<NV>();
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;  // finite stand-in for +inf inside packed argmin keys
   double *sm = shared_base();

@@ -1,0 +1,515 @@
+// Packed variant of the stack+solve kernel: W lanes per QP, 64/W QPs per wavefront.
+//
+// ik_kernels.h gives every QP a whole 64-lane wave; at nv = 30 half the lanes idle and at
+// nv = 6 (UR5) 58 of 64 do, while the kernel is VALU-issue bound.  Here lane = (instance,
+// row): group g = lane / W handles instance block*G + g, lane li = lane % W owns row li of that
+// instance's matrix in NV registers (W >= NV, W in {8, 16, 32}).  Every VALU instruction then
+// advances 64/W QPs.  What changes with respect to the one-QP-per-wave kernel:
+//   * values that were wave-uniform (q, the selected constraint, step lengths, ...) become
+//     group-uniform and live in VGPRs; broadcasts from a data-dependent lane use ds_bpermute,
+//     from a compile-time lane ds_swizzle, reductions are DPP butterflies inside the group;
+//   * the active-set iteration is a flat state machine: each trip of the loop is one
+//     Goldfarb-Idnani step for every group that is still running; add / drop / select
+//     sections are executed when any group needs them and are predicated per group;
+//   * L and R are stored packed (triangular) so that a QP needs ~6 KiB of LDS at NV = 32.
+// The arithmetic per instance is the same as in ik_kernels.h (same citations apply).
+#pragma once
+
+#include "ik_kernels.h"
+
+namespace pinkhip {
+
+template <int NV>
+struct LdsP {
+  static constexpr int GP = NV + 1;               // row pitch of the dense inequality rows
+  static constexpr int TRI = NV * (NV + 3) / 2;   // packed triangle with one sub-diagonal slot per column
+  static constexpr int RC = (TRI / NV < 32) ? TRI / NV : 32;  // staged J rows per chunk (pitch NV)
+  static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then R
+  static constexpr int oX = oT + TRI;             // NV   column scratch / x
+  static constexpr int oY = oX + NV;              // NV   forward-solve scratch / y
+  static constexpr int oD = oY + NV;              // NV   d = J^T n+  (also 1/diag(L))
+  static constexpr int oD2 = oD + NV;             // NV
+  static constexpr int oV = oD2 + NV;             // NV
+  static constexpr int oWa = oV + NV;             // RC
+  static constexpr int oGs = oWa + RC + (RC & 1);  // RC
+  static constexpr int oGd = oGs + RC + (RC & 1);  // md*GP
+  static __host__ __device__ inline int stride(int md) { return (oGd + md * GP + 1) & ~1; }  // doubles per QP
+  static __host__ __device__ inline long long bytes(int md, int groups) { return 8LL * stride(md) * groups + 16; }
+  // L: row i, entries 0..i at i(i+1)/2;  R: column k, rows 0..k+1 at k(k+3)/2
+  static __host__ __device__ constexpr int lrow(int i) { return i * (i + 1) / 2; }
+  static __host__ __device__ constexpr int rcol(int k) { return k * (k + 3) / 2; }
+};
+
+template <int NV, int W>
+__device__ inline void ik_packed_instance(const KernelArgs &a, long long block) {
+  static_assert(W >= NV && (W == 8 || W == 16 || W == 32), "group width");
+  using S = LdsP<NV>;
+  constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
+  constexpr double INF = INFINITY;
+  constexpr double BIG = 1e300;
+
+  const int lane = lane_id();
+  const int g = lane / W, li = lane & (W - 1);
+  const int nv = a.nv, Kd = a.Kd, K = a.K, md = a.md;
+  long long b = block * G + g;
+  const bool valid = b < a.B;
+  if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
+
+  double *sm = shared_base() + (long long)g * S::stride(md);
+  double *Ts = sm + S::oT;
+  double *xs = sm + S::oX;
+  double *ys = sm + S::oY;
+  double *ds = sm + S::oD;
+  double *d2s = sm + S::oD2;
+  double *vs = sm + S::oV;
+  double *was = sm + S::oWa;
+  double *gs = sm + S::oGs;
+  double *Gs = sm + S::oGd;
+
+  const bool in = li < nv;
+  const int lc = in ? li : 0;
+  const int lv = li < NV ? li : 0;
+  const int rcl = S::rcol(lv);  // this lane's column of R (lane = column) / row offset helper
+
+  // ------------------------------------------------------------------ stack (task.py:145-167)
+  double M[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) M[j] = 0.0;
+  double ci = 0.0, mu_l = 0.0, dadd = 0.0;
+  const double *Jb = a.J + b * (long long)Kd * nv;
+  const double *eb = a.e + b * (long long)K;
+  const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
+
+  for (int r0 = 0; r0 < Kd; r0 += S::RC) {
+    const int rc = (Kd - r0 < S::RC) ? Kd - r0 : S::RC;
+    wave_sync();
+    {  // this group's rows, W lanes wide, LDS pitch NV
+      const double *src = Jb + (long long)r0 * nv;
+      int r = li / nv, j = li - r * nv;
+      const int dr = W / nv, dj = W - dr * nv;
+      for (int idx = li; idx < rc * nv; idx += W) {
+        Ts[r * NV + j] = src[idx];
+        r += dr;
+        j += dj;
+        if (j >= nv) {
+          j -= nv;
+          ++r;
+        }
+      }
+    }
+    for (int rr = li; rr < rc; rr += W) {
+      const int k = r0 + rr;
+      const double w = costb[k], ev = eb[k], gn = a.row_gain[k], l = a.row_lm[k];
+      const double wa = w * w;
+      was[rr] = wa;
+      gs[rr] = gn * wa * ev;
+      mu_l += l * (gn * gn) * wa * ev * ev;
+    }
+    wave_sync();
+    for (int k = 0; k < rc; ++k) {
+      const double *row = Ts + k * NV;
+      const double jki = row[lc];
+      const double aa = was[k] * jki;
+      ci += gs[k] * jki;
+#pragma unroll
+      for (int j0 = 0; j0 < NV; j0 += kG) {
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) M[j] += aa * row[j];
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) pin(M[j]);
+      }
+    }
+  }
+  if (in) {
+    for (int t = 0; t < a.n_dtasks; ++t) {
+      const int off = li - a.dtask_col0[t];
+      if (off >= 0 && off < a.dtask_k[t]) {
+        const int r = a.dtask_row0[t] + off;
+        const double w = costb[r], ev = eb[r], gn = a.row_gain[r], l = a.row_lm[r];
+        const double wa = w * w;
+        dadd += wa;
+        ci += gn * wa * ev;
+        mu_l += l * (gn * gn) * wa * ev * ev;
+      }
+    }
+    if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
+  }
+  double diag = a.damping + group_sum<W>(mu_l);
+
+  double hv = 0.0, ginv = 1.0;
+  if (md > 0) {
+    wave_sync();
+    {
+      const double *src = a.Gd + b * (long long)md * nv;
+      int r = li / nv, j = li - r * nv;
+      const int dr = W / nv, dj = W - dr * nv;
+      for (int idx = li; idx < md * nv; idx += W) {
+        Gs[r * GP + j] = src[idx];
+        r += dr;
+        j += dj;
+        if (j >= nv) {
+          j -= nv;
+          ++r;
+        }
+      }
+    }
+    wave_sync();
+    if (li < md) {  // md <= 32; for W < md the remaining rows are handled below
+      hv = a.hd[b * (long long)md + li];
+      double s = 0.0;
+      for (int j = 0; j < nv; ++j) s += Gs[li * GP + j] * Gs[li * GP + j];
+      ginv = (s > 0.0) ? 1.0 / sqrt(s) : 1.0;
+    }
+    for (int t = 0; t < a.n_barriers; ++t) {
+      const double r = a.barrier_safe_gain[t];
+      if (r > 1e-6) {
+        double s = 0.0;
+        if (in)
+          for (int rr = a.barrier_rows[t]; rr < a.barrier_rows[t + 1]; ++rr)
+            s += Gs[rr * GP + li] * Gs[rr * GP + li];
+        s = group_sum<W>(s);
+        diag += r / (s * a.dt * a.dt);
+      }
+    }
+  }
+  diag += dadd;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (j >= nv || !in) M[j] = 0.0;
+    if (j == li) M[j] += in ? diag : 1.0;
+  }
+  if (!in) ci = 0.0;
+
+  // ------------------------------------------------------------------ Cholesky + forward solve
+  // Column j (unscaled) and the running right-hand side go through LDS; the pivot is read
+  // back from there, so the step needs no cross-lane register traffic.
+  int status = STATUS_OPTIMAL;
+  double cp = -ci;
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (li < NV) {
+      xs[li] = M[j];
+      ys[li] = cp;
+    }
+    wave_sync();
+    double p = xs[j];
+    if (!(p > 0.0)) {
+      status = STATUS_NOT_PD;
+      p = 1.0;
+    }
+    const double rinv = fast_rsqrt(p);
+    const double lij = M[j] * rinv;
+    const double tj = lij * rinv;  // M[j] / p
+    if (li >= j && li < NV) Ts[S::lrow(li) + j] = lij;
+    if (li == 0) ds[j] = rinv;
+    const double yj = ys[j] * rinv;
+    cp = (li > j) ? cp - lij * yj : (li == j ? yj : cp);
+#pragma unroll
+    for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m > j) M[m] -= tj * xs[m];
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m > j) pin(M[m]);
+    }
+    wave_sync();
+  }
+  if (li < NV) xs[li] = cp;  // y
+  wave_sync();
+  // J = L^-T
+  double Jr[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double acc = (li == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m0 = 0; m0 < j; m0 += kG) {
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m < j) acc -= Ts[S::lrow(j) + m] * Jr[m];
+      pin(acc);
+    }
+    Jr[j] = acc * ds[j];
+    pin(Jr[j]);
+  }
+  double rown2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
+  double x = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    x += Jr[j] * xs[j];
+    if ((j & (kG - 1)) == kG - 1) pin(x);
+  }
+  wave_sync();
+
+  // ------------------------------------------------------------------ Goldfarb-Idnani, flat
+  double *Rs = Ts;
+  const double lbv = in ? a.lb[b * (long long)nv + li] : -INF;
+  const double ubv = in ? a.ub[b * (long long)nv + li] : INF;
+  const double tol = 1e-13;
+  const double thr_lo = (in && lbv > -INF) ? -tol * (1.0 + fabs(lbv)) : -INF;
+  const double thr_up = (in && ubv < INF) ? -tol * (1.0 + fabs(ubv)) : -INF;
+  const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
+  int q = 0, it = 0;        // group-uniform
+  int bstate = 0, dactive = 0, A = 0;
+  double u = 0.0, rdiag = 0.0;
+  bool running = (status == STATUS_OPTIMAL);
+  bool need_sel = true;
+  int kind = 0, src = 0, bid = 0;
+  double sp = 0.0, uplus = 0.0;
+
+  for (;;) {
+    // (a) selection, for the groups that have no pending constraint
+    if (wave_any(running && need_sel)) {
+      double best = BIG, sd = 0.0;
+      const double slo = x - lbv, sup = ubv - x;
+      if (bstate != 1 && slo < thr_lo) best = key_pack(slo, li);
+      if (bstate != 2 && sup < thr_up && sup < best) best = key_pack(sup, 64 + li);
+      if (md > 0) {
+        if (li < NV) xs[li] = x;
+        wave_sync();
+        if (li < md) {
+          double s = hv;
+          for (int j = 0; j < nv; ++j) s -= Gs[li * GP + j] * xs[j];
+          sd = s;
+          const double sc = s * ginv;
+          if (!dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) best = key_pack(sc, 128 + li);
+        }
+        wave_sync();
+      }
+      best = group_min<W>(best);
+      const bool sel = running && need_sel;
+      const bool none = !(best < 0.0);
+      if (sel && none) running = false;  // optimal
+      if (sel && !none) {
+        bid = key_payload(best);
+        kind = bid >> 6;
+        src = bid & 63;
+        uplus = 0.0;
+        need_sel = false;
+      }
+      const double cand = (kind == 0) ? slo : (kind == 1) ? sup : sd;
+      const double spn = group_bcast<W>(cand, src & (W - 1));
+      if (sel && !none) sp = spn;
+    }
+    if (running) {
+      if (++it > max_iter) {
+        status = STATUS_MAX_ITER;
+        running = false;
+      }
+    }
+    if (!wave_any(running)) break;
+    const bool act = running;
+
+    // (b) d = J^T n+
+    double dl = 0.0;
+    if (wave_any(act && kind < 2)) {
+      if (act && kind < 2 && li == src) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) ds[j] = Jr[j];
+      }
+      wave_sync();
+      const double rowv = (li < NV) ? ds[lv] : 0.0;
+      if (act && kind < 2) dl = (kind == 0) ? rowv : -rowv;
+    }
+    if (md > 0 && wave_any(act && kind == 2)) {
+      const bool dn = act && kind == 2;
+      const double gi = (in && dn) ? -Gs[(src & 31) * GP + li] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const double s = group_sum<W>(Jr[j] * gi);
+        if (dn && li == j) dl = s;
+      }
+    }
+    double dd = group_bcast<W>(rown2, src & (W - 1));
+    if (md > 0 && wave_any(act && kind == 2)) {
+      const double dds = group_sum<W>(dl * dl);
+      if (kind == 2) dd = dds;
+    }
+    const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
+    const bool lin_dep = !(d2n > 1e-24 * dd);
+    const double dq_ = group_bcast<W>(dl, q < W ? q : W - 1);
+    const double rn2 = lin_dep ? 0.0 : fast_rsqrt(lin_dep ? 1.0 : d2n);
+    const double nrm2 = d2n * rn2;
+    const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
+    const double beta = lin_dep ? 0.0 : rn2 * fast_rcp(lin_dep ? 1.0 : nrm2 + fabs(dq_));
+    if (li < NV) {
+      d2s[li] = (li >= q) ? dl : 0.0;
+      vs[li] = (li > q) ? dl : (li == q ? dq_ + sgq * nrm2 : 0.0);
+    }
+    wave_sync();
+    double z = 0.0, w = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      z += Jr[j] * d2s[j];
+      w += Jr[j] * vs[j];
+      if ((j & (kG - 1)) == kG - 1) {
+        pin(z);
+        pin(w);
+      }
+    }
+#ifdef PINKHIP_EXP_DUP_ZW  // timing experiment: z/w products twice
+    {
+      double z2 = 1e-300, w2 = 1e-300;
+      pin(z2);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        z2 += Jr[j] * d2s[j];
+        w2 += Jr[j] * vs[j];
+        if ((j & (kG - 1)) == kG - 1) {
+          pin(z2);
+          pin(w2);
+        }
+      }
+      if (z2 == 1.2345e300) z = z2 + w2;
+    }
+#endif
+    // r = R^-1 d1
+    double dp = dl;
+    {
+      const int qmax = groups_max<W>(act ? q : 0);
+      for (int k = qmax - 1; k > 0; --k) {
+        const double rk = group_bcast<W>(dp * rdiag, k);
+        if (li < k && k < q) dp -= Rs[S::rcol(k) + li] * rk;
+      }
+    }
+#ifdef PINKHIP_EXP_DUP_BACKSUB  // timing experiment: run the back-substitution twice
+    {
+      double dp2 = dl;
+      pin(dp2);
+      const int qmax = groups_max<W>(act ? q : 0);
+      for (int k = qmax - 1; k > 0; --k) {
+        const double rk = group_bcast<W>(dp2 * rdiag, k);
+        if (li < k && k < q) dp2 -= Rs[S::rcol(k) + li] * rk;
+      }
+      pin(dp2);
+      if (dp2 == 1.2345e300) dp = dp2;
+    }
+#endif
+    const double rv = dp * rdiag;
+    // (c) step lengths
+    const bool blocking = act && li < q && rv > 0.0;
+    const double ratio = blocking ? u * fast_rcp(rv) : BIG;
+    const double k1 = group_min<W>(blocking ? key_pack(ratio, li) : BIG);
+    const int kd = key_payload(k1) & (W - 1);
+    const double t1b = group_bcast<W>(ratio, kd);  // unconditional: cross-lane ops must not diverge
+    const double t1 = (k1 < BIG) ? t1b : INF;
+    const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
+    const double t = (t1 < t2) ? t1 : t2;
+    if (act && !(t < INF)) {
+      status = STATUS_INFEASIBLE;
+      running = false;
+    }
+    const bool act2 = act && running;
+    const bool dual_only = act2 && !(t2 < INF);
+    const bool do_add = act2 && (t2 < INF) && (t2 <= t1);
+    const bool do_drop = act2 && !do_add;
+    if (act2) {
+      if (!dual_only) x += t * z;
+      if (li < q) u -= t * rv;
+      uplus += t;
+    }
+    // (d) add: J2 <- J2 (I - beta v v^T), R gains column [d1; -sgq |d2|]
+    if (wave_any(do_add)) {
+      const double wb = do_add ? beta * w : 0.0;
+#pragma unroll
+      for (int j0 = 0; j0 < NV; j0 += kG) {
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) Jr[j] -= wb * vs[j];
+#pragma unroll
+        for (int j = j0; j < j0 + kG; ++j) pin(Jr[j]);
+      }
+      if (do_add) {
+        if (li < q) Rs[S::rcol(q) + li] = dl;
+        if (li == q) {
+          Rs[S::rcol(q) + q] = -sgq * nrm2;
+          rdiag = -sgq * rn2;
+          A = bid;
+          u = uplus;
+        }
+        if (li == src) {
+          if (kind == 0) bstate = 1;
+          else if (kind == 1) bstate = 2;
+        }
+        if (kind == 2 && li == (src & 31)) dactive = 1;
+        ++q;
+        need_sel = true;
+      }
+    }
+    wave_sync();
+    // (e) drop the blocking constraint at active position kd
+    if (wave_any(do_drop)) {
+      const int idk = group_bcast_i<W>(A, kd);
+      if (do_drop) {
+        if ((idk >> 6) < 2) {
+          if (li == (idk & 63)) bstate = 0;
+        } else if (li == (idk & 31)) {
+          dactive = 0;
+        }
+      }
+      wave_sync();
+      {
+        const int c0 = groups_min<W>(do_drop ? kd : NV);
+        const int c1 = groups_max<W>(do_drop ? q - 1 : 0);
+        for (int col = c0; col < c1; ++col)
+          if (do_drop && col >= kd && col < q - 1 && li <= col + 1)
+            Rs[S::rcol(col) + li] = Rs[S::rcol(col + 1) + li];
+      }
+      {
+        const double un = from_next_lane(u);
+        const int An = from_next_lane_i(A);
+        if (do_drop && li >= kd && li < q - 1) {
+          u = un;
+          A = An;
+        }
+      }
+      if (do_drop) --q;
+      wave_sync();
+      static_for<0, NV - 1>([&](auto L) {
+        constexpr int l = decltype(L)::value;
+        const bool rot = do_drop && l >= kd && l < q;
+        if (wave_any(rot)) {
+          const bool mine = rot && li >= l && li < q;
+          const double ra = mine ? Rs[rcl + l] : 0.0;
+          const double rb = mine ? Rs[rcl + l + 1] : 0.0;
+          const double ga = group_bcast_static<W, l>(ra);
+          const double gb = group_bcast_static<W, l>(rb);
+          const bool nz = rot && gb != 0.0;
+          const double rh = fast_rsqrt(nz ? ga * ga + gb * gb : 1.0);
+          const double cc = nz ? ga * rh : 1.0, ss = nz ? gb * rh : 0.0;
+          if (mine && nz) {
+            Rs[rcl + l] = cc * ra + ss * rb;
+            Rs[rcl + l + 1] = -ss * ra + cc * rb;
+          }
+          const double ja = Jr[l], jb = Jr[l + 1];
+          Jr[l] = cc * ja + ss * jb;
+          Jr[l + 1] = -ss * ja + cc * jb;
+        }
+      });
+      if (do_drop && li >= kd && li < q) rdiag = fast_rcp(Rs[rcl + li]);
+      wave_sync();
+      // slack of the pending constraint at the new x (same n+ next trip)
+      const double cand = (kind == 0) ? x - lbv : ubv - x;
+      const double spn = group_bcast<W>(cand, src & (W - 1));
+      if (do_drop && !dual_only) sp = (kind < 2) ? spn : sp + t * d2n;
+    }
+  }
+
+  // ------------------------------------------------------------------ write-out
+  if (valid) {
+    if (in) a.dq[b * (long long)nv + li] = x;
+    if (li == 0) {
+      a.status[b] = status;
+      if (a.iters) a.iters[b] = it;
+    }
+  }
+}
+
+template <int NV, int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV) ik_solve_packed_kernel(KernelArgs a) {
+  ik_packed_instance<NV, W>(a, block_id());
+}
+
+}  // namespace pinkhip

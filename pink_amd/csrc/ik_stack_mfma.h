@@ -1,0 +1,151 @@
+// Stack-only kernel on the fp64 matrix cores: H = damping I + sum_t J_t^T W_t^2 J_t + mu_t I,
+// c = sum_t gain_t J_t^T W_t^2 e_t for one QP per wavefront (reference pink/tasks/task.py:145-167,
+// pink/solve_ik.py:54-67 -- the P, q of pink.build_ik).
+//
+// This is the one GEMM-shaped piece of the path: H (nv x nv) = (W^2 J)^T (Kd x nv) * J (Kd x nv).
+// It is tiled for v_mfma_f64_16x16x4_f64: NT x NT output tiles of 16 x 16, K consumed 4 task rows
+// at a time.  Lane l loads J[k0 + (l >> 4)][16 tc + (l & 15)] straight from HBM (16 lanes = 128
+// contiguous bytes) and the same value serves as the B operand of tile column tc and, scaled by
+// w_k^2, as the A operand of tile row tc -- no LDS staging, no broadcast reads; the accumulators
+// are written out in the MFMA C/D layout (16 lanes = 128 contiguous bytes of one row of H).
+// The kernel is bound by the HBM stream: 8 (Kd nv + K + nv^2 + nv) bytes per QP.
+#pragma once
+
+#include "ik_kernels.h"
+
+namespace pinkhip {
+
+template <int NT>
+__device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) {
+  double *sm = shared_base();
+  double *was = sm;        // [K]   w_k^2
+  double *gws = sm + 128;  // [K]   gain_k w_k^2 e_k        (K <= 128 per pass)
+  const int lane = lane_id();
+  const int nv = a.nv, Kd = a.Kd, K = a.K;
+  const int col = lane & 15, rq = lane >> 4;
+
+  const double *Jb = a.J + b * (long long)Kd * nv;
+  const double *eb = a.e + b * (long long)K;
+  const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
+
+  v4d acc[NT][NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ti][tj][r] = 0.0;
+  double cpart[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cpart[t] = 0.0;
+  double mu_l = 0.0;
+
+  // dense rows, 128 at a time through the LDS coefficient table
+  for (int r0 = 0; r0 < Kd; r0 += 128) {
+    const int rc = (Kd - r0 < 128) ? Kd - r0 : 128;
+    wave_sync();
+    for (int rr = lane; rr < rc; rr += kWave) {
+      const int k = r0 + rr;
+      const double w = costb[k], ev = eb[k], g = a.row_gain[k], l = a.row_lm[k];
+      const double wa = w * w;
+      was[rr] = wa;
+      gws[rr] = g * wa * ev;
+      mu_l += l * (g * g) * wa * ev * ev;
+    }
+    wave_sync();
+    for (int k0 = 0; k0 < rc; k0 += 4) {
+      const int kk = k0 + rq;  // this lane's task row inside the slice
+      const bool krow = kk < rc;
+      const double wa = krow ? was[kk] : 0.0;
+      const double gw = krow ? gws[kk] : 0.0;
+      double Jv[NT], Av[NT];
+#pragma unroll
+      for (int tc = 0; tc < NT; ++tc) {
+        const int j = 16 * tc + col;
+        Jv[tc] = (krow && j < nv) ? Jb[(long long)(r0 + kk) * nv + j] : 0.0;
+        Av[tc] = wa * Jv[tc];
+        cpart[tc] += gw * Jv[tc];
+      }
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = mfma_f64_16x16x4(Av[ti], Jv[tj], acc[ti][tj]);
+    }
+  }
+
+  // c of the dense tasks: sum the four row quarters, lane i keeps coordinate i
+  double ci = 0.0;
+#pragma unroll
+  for (int tc = 0; tc < NT; ++tc) {
+    double s = cpart[tc];
+    s += lane_shfl(s, lane ^ 16);
+    s += lane_shfl(s, lane ^ 32);
+    if (rq == tc) ci = s;
+  }
+  // diagonal tasks (J = eye[col0:col0+k], posture_task.py:128-129) in the lane = coordinate layout
+  const bool in = lane < nv;
+  if (in) {
+    for (int t = 0; t < a.n_dtasks; ++t) {
+      const int off = lane - a.dtask_col0[t];
+      if (off >= 0 && off < a.dtask_k[t]) {
+        const int r = a.dtask_row0[t] + off;
+        const double w = costb[r], ev = eb[r], g = a.row_gain[r], l = a.row_lm[r];
+        const double wa = w * w;
+        ci += g * wa * ev;
+        mu_l += l * (g * g) * wa * ev * ev;
+      }
+    }
+    if (a.c_extra) ci += a.c_extra[b * (long long)nv + lane];
+  }
+  double diag = a.damping + wave_sum(mu_l);
+  for (int t = 0; t < a.n_barriers; ++t) {  // barrier.py:193-200: r / ||J_h||_F^2, J_h = -Gd dt
+    const double r = a.barrier_safe_gain[t];
+    if (r > 1e-6) {
+      const double *Gb = a.Gd + b * (long long)a.md * nv;
+      double s = 0.0;
+      for (int idx = a.barrier_rows[t] * nv + lane; idx < a.barrier_rows[t + 1] * nv; idx += kWave)
+        s += Gb[idx] * Gb[idx];
+      s = wave_sum(s);
+      diag += r / (s * a.dt * a.dt);
+    }
+  }
+  // diagonal entries live in lanes with (lane >> 4) == (col & 3), element col >> 2 of the diagonal tiles
+  if (rq == (col & 3)) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int i = 16 * ti + col;
+      double dd = diag;
+      for (int t = 0; t < a.n_dtasks; ++t) {
+        const int off = i - a.dtask_col0[t];
+        if (off >= 0 && off < a.dtask_k[t]) {
+          const double w = costb[a.dtask_row0[t] + off];
+          dd += w * w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r == (col >> 2)) acc[ti][ti][r] += dd;
+    }
+  }
+  // write-out: element r of tile (ti, tj) is H[16 ti + rq + 4 r][16 tj + col]
+  double *Hb = a.H_out + b * (long long)nv * nv;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ti + rq + 4 * r;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const int j = 16 * tj + col;
+        if (i < nv && j < nv) Hb[(long long)i * nv + j] = acc[ti][tj][r];
+      }
+    }
+  if (in) a.c_out[b * (long long)nv + lane] = ci;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kWave) ik_stack_mfma_kernel(KernelArgs a) {
+  ik_stack_mfma_instance<NT>(a, block_id());
+}
+
+}  // namespace pinkhip

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -14,6 +15,8 @@
 // clang-format off
 #include "wave.h"
 #include "ik_kernels.h"
+#include "ik_kernels_packed.h"
+#include "ik_stack_mfma.h"
 #include "host_tables.h"
 // clang-format on
 
@@ -35,6 +38,7 @@ struct pinkhip_handle {
   char *arena = nullptr;             // grow-only scratch of the *_host entry points
   size_t arena_bytes = 0;
   hipDeviceProp_t prop;
+  bool packed = true;                // PINKHIP_KERNEL=wave forces one QP per wavefront
 };
 
 namespace {
@@ -67,9 +71,42 @@ int launch_nv(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   return PINKHIP_OK;
 }
 
+template <int NT>
+int launch_stack_mfma(pinkhip_handle *h, const KernelArgs &a) {
+  const dim3 grid(static_cast<unsigned>(a.B)), block(pinkhip::kWave);
+  hipLaunchKernelGGL(pinkhip::ik_stack_mfma_kernel<NT>, grid, block, 2048, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+template <int NV, int W>
+int launch_packed(pinkhip_handle *h, const KernelArgs &a) {
+  constexpr int G = pinkhip::kWave / W;
+  const size_t lds = static_cast<size_t>(pinkhip::LdsP<NV>::bytes(a.md, G));
+  const dim3 grid(static_cast<unsigned>((a.B + G - 1) / G)), block(pinkhip::kWave);
+  hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W>), grid, block, lds, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
 int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   if (a.B == 0) return PINKHIP_OK;
   if (a.B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "B exceeds the grid limit 2^31-1");
+  if (!solve && h->packed) {  // stack only: fp64 MFMA tiles, NT = ceil(nv / 16)
+    switch ((a.nv + 15) / 16) {
+      case 1: return launch_stack_mfma<1>(h, a);
+      case 2: return launch_stack_mfma<2>(h, a);
+      case 3: return launch_stack_mfma<3>(h, a);
+      case 4: return launch_stack_mfma<4>(h, a);
+    }
+  }
+  if (solve && h->packed) {
+    // several QPs per wavefront when a row group (8 / 16 / 32 lanes) holds the problem
+    if (a.nv <= 8 && a.md <= 8) return launch_packed<8, 8>(h, a);
+    if (a.nv <= 16 && a.md <= 16) return launch_packed<16, 16>(h, a);
+    if (a.nv <= 24) return launch_packed<24, 32>(h, a);
+    if (a.nv <= 32) return launch_packed<32, 32>(h, a);
+  }
   switch (pinkhip::padded_nv(a.nv)) {
     case 8: return launch_nv<8>(h, a, solve);
     case 16: return launch_nv<16>(h, a, solve);
@@ -247,6 +284,7 @@ int pinkhip_create(pinkhip_handle **out, int device_id) {
   pinkhip_handle *h = new (std::nothrow) pinkhip_handle();
   if (!h) return fail(nullptr, PINKHIP_E_NOMEM, "out of host memory");
   h->device = device_id;
+  if (const char *k = std::getenv("PINKHIP_KERNEL")) h->packed = std::strcmp(k, "wave") != 0;
   hipError_t e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipGetDeviceProperties(&h->prop, device_id);
   if (e == hipSuccess && std::strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {

@@ -9,10 +9,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// Occupancy hint for the register allocator (waves per SIMD), see ik_kernels.h.
+// Occupancy hints for the register allocator (waves per SIMD = 512 / VGPRs per lane).
+// One QP per wave: 4 waves (128 VGPRs) up to NV = 32, 2 waves for the larger register-resident
+// rows.  Packed kernel: 4 waves for NV <= 16, 3 for NV = 24 / 32 (LDS allows ~3 anyway).
+#ifndef PINKHIP_WAVES_SMALL
+#define PINKHIP_WAVES_SMALL 4
+#endif
+#ifndef PINKHIP_WAVES_LARGE
+#define PINKHIP_WAVES_LARGE 2
+#endif
+#ifndef PINKHIP_WAVES_PACKED_SMALL
+#define PINKHIP_WAVES_PACKED_SMALL 4
+#endif
+#ifndef PINKHIP_WAVES_PACKED_LARGE
+#define PINKHIP_WAVES_PACKED_LARGE 3
+#endif
 #define PINKHIP_OCCUPANCY_ATTR(NV) \
   __attribute__((amdgpu_waves_per_eu((NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE, \
                                      (NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE)))
+#define PINKHIP_OCCUPANCY_PACKED(NV) \
+  __attribute__((amdgpu_waves_per_eu((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : PINKHIP_WAVES_PACKED_LARGE, \
+                                     (NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : PINKHIP_WAVES_PACKED_LARGE)))
 
 namespace pinkhip {
 
@@ -130,6 +147,94 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = fma(0.5 * y, e, y);
   e = fma(-(x * y), y, 1.0);
   return fma(0.5 * y, e, y);
+}
+
+// ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
+__device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
+
+// Value of an arbitrary (per-lane) source lane: 2 x ds_bpermute_b32 (LDS crossbar, no LDS memory).
+__device__ __forceinline__ double lane_shfl(double v, int src_lane) {
+  const int a = src_lane << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int lane_shfl_i(int v, int src_lane) {
+  return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+
+// Broadcast inside each group of W lanes from the group's lane `src` (group-uniform, may
+// differ between groups).
+template <int W>
+__device__ __forceinline__ double group_bcast(double v, int src) {
+  return lane_shfl(v, (lane_id() & ~(W - 1)) | src);
+}
+template <int W>
+__device__ __forceinline__ int group_bcast_i(int v, int src) {
+  return lane_shfl_i(v, (lane_id() & ~(W - 1)) | src);
+}
+// Same with a compile-time source lane: ds_swizzle bit mode (no address register).
+template <int W, int K>
+__device__ __forceinline__ double group_bcast_static(double v) {
+  static_assert(W <= 32 && K < W, "ds_swizzle bit mode works inside 32 lanes");
+  constexpr int pattern = ((~(W - 1)) & 0x1F) | (K << 5);
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swizzle_xor16(double v) {
+  constexpr int pattern = (0x10 << 10) | 0x1F;
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
+  return __hiloint2double(hi, lo);
+}
+// All-reduce inside each group of W lanes (every lane gets its group's result).
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+  v += dpp_mov<kDppXor1>(v);
+  v += dpp_mov<kDppXor2>(v);
+  v += dpp_mov<kDppHalfMirror>(v);
+  if (W >= 16) v += dpp_mov<kDppMirror>(v);
+  if (W >= 32) v += swizzle_xor16(v);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ double group_min(double v) {
+  v = fmin(v, dpp_mov<kDppXor1>(v));
+  v = fmin(v, dpp_mov<kDppXor2>(v));
+  v = fmin(v, dpp_mov<kDppHalfMirror>(v));
+  if (W >= 16) v = fmin(v, dpp_mov<kDppMirror>(v));
+  if (W >= 32) v = fmin(v, swizzle_xor16(v));
+  return v;
+}
+// max / min over the groups of a group-uniform int (one v_readlane per group).
+template <int W>
+__device__ __forceinline__ int groups_max(int v) {
+  int m = bcast_i(v, 0);
+#pragma unroll
+  for (int g = 1; g < kWave / W; ++g) {
+    const int o = bcast_i(v, g * W);
+    m = o > m ? o : m;
+  }
+  return m;
+}
+template <int W>
+__device__ __forceinline__ int groups_min(int v) {
+  int m = bcast_i(v, 0);
+#pragma unroll
+  for (int g = 1; g < kWave / W; ++g) {
+    const int o = bcast_i(v, g * W);
+    m = o < m ? o : m;
+  }
+  return m;
+}
+
+// ---- fp64 matrix core: D(16x16) += A(16x4) B(4x16), one wavefront ----
+// Operand layout (cdna_hip_programming.md, fragment layout): lane l supplies A[l & 15][l >> 4]
+// and B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15] in element r of the accumulator.
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4d mfma_f64_16x16x4(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
 // Value held by lane+1 (lane 63 receives its own value).

@@ -10,7 +10,10 @@ cases = [("draco3", 65536, "tight"), ("draco3", 65536, "kinematic"), ("jvrc", 32
 if len(sys.argv) > 1: cases = cases[:int(sys.argv[1])]
 for name, B, bounds in cases:
     t = synthetic.make_terms(name, B, bounds=bounds, jacobians="dense" if bounds == "tight" else "kinematic")
-    pk = synthetic.pack(t); dev = s.upload(pk)
+    pk = synthetic.pack(t)
+    if os.environ.get("UNBOUNDED"):
+        pk.lb[:] = -np.inf; pk.ub[:] = np.inf
+    dev = s.upload(pk)
     s.solve_device(dev); s.sync()
     best = 1e9
     for rep in range(3):

@@ -4,6 +4,8 @@
 #include "wave_emu.h"
 // clang-format off
 #include "../../pink_amd/csrc/ik_kernels.h"
+#include "../../pink_amd/csrc/ik_kernels_packed.h"
+#include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/host_tables.h"
 // clang-format on
 
@@ -17,6 +19,18 @@ template <int NV, bool SOLVE>
 void lane_main(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
   pinkhip::ik_instance<NV, SOLVE>(*a, pinkhip::block_id());
+}
+
+template <int NV, int W>
+void lane_main_packed(void *p) {
+  const KernelArgs *a = static_cast<const KernelArgs *>(p);
+  pinkhip::ik_packed_instance<NV, W>(*a, pinkhip::block_id());
+}
+
+template <int NT>
+void lane_main_stack_mfma(void *p) {
+  const KernelArgs *a = static_cast<const KernelArgs *>(p);
+  pinkhip::ik_stack_mfma_instance<NT>(*a, pinkhip::block_id());
 }
 
 template <bool SOLVE>
@@ -81,7 +95,26 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
     g_err = "unsupported nv";
     return PINKHIP_E_INVALID;
   }
-  for (long long b = 0; b < d->B; ++b) pinkhip::emu_run_block(b, fn, &a);
+  long long blocks = d->B;
+  const char *k = std::getenv("PINKHIP_KERNEL");
+  const bool packed = !(k && std::strcmp(k, "wave") == 0);
+  if (!solve && packed) {
+    switch ((a.nv + 15) / 16) {
+      case 1: fn = lane_main_stack_mfma<1>; break;
+      case 2: fn = lane_main_stack_mfma<2>; break;
+      case 3: fn = lane_main_stack_mfma<3>; break;
+      case 4: fn = lane_main_stack_mfma<4>; break;
+    }
+  }
+  if (solve && packed) {  // same dispatch rule as pinkhip.hip
+    int G = 0;
+    if (a.nv <= 8 && a.md <= 8) { fn = lane_main_packed<8, 8>; G = 8; }
+    else if (a.nv <= 16 && a.md <= 16) { fn = lane_main_packed<16, 16>; G = 4; }
+    else if (a.nv <= 24) { fn = lane_main_packed<24, 32>; G = 2; }
+    else if (a.nv <= 32) { fn = lane_main_packed<32, 32>; G = 2; }
+    if (G) blocks = (d->B + G - 1) / G;
+  }
+  for (long long b = 0; b < blocks; ++b) pinkhip::emu_run_block(b, fn, &a);
   return PINKHIP_OK;
 }
 

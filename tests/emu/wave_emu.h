@@ -19,10 +19,12 @@
 #include <cstring>
 
 #define __device__
+#define __host__
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
+#define PINKHIP_OCCUPANCY_PACKED(NV)
 
 namespace pinkhip {
 
@@ -158,6 +160,109 @@ inline int key_payload(double k) {
 }
 inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+
+inline bool wave_any(bool p) {
+  Emu &e = emu();
+  e.slot_i[e.cur] = p ? 1 : 0;
+  emu_rendezvous(14);
+  bool r = false;
+  for (int l = 0; l < kWave; ++l) r = r || e.slot_i[l];
+  emu_rendezvous(15);
+  return r;
+}
+inline double lane_shfl(double v, int src_lane) {
+  if (src_lane < 0 || src_lane >= kWave) {
+    std::fprintf(stderr, "wave emulator: lane_shfl from lane %d\n", src_lane);
+    std::abort();
+  }
+  return emu_exchange(v, src_lane, 16);
+}
+inline int lane_shfl_i(int v, int src_lane) {
+  Emu &e = emu();
+  if (src_lane < 0 || src_lane >= kWave) std::abort();
+  e.slot_i[e.cur] = v;
+  emu_rendezvous(18);
+  const int r = e.slot_i[src_lane];
+  emu_rendezvous(19);
+  return r;
+}
+template <int W>
+inline double group_bcast(double v, int src) {
+  if (src < 0 || src >= W) {
+    std::fprintf(stderr, "wave emulator: group_bcast<%d> from %d\n", W, src);
+    std::abort();
+  }
+  return lane_shfl(v, (emu().cur & ~(W - 1)) | src);
+}
+template <int W>
+inline int group_bcast_i(int v, int src) {
+  if (src < 0 || src >= W) std::abort();
+  return lane_shfl_i(v, (emu().cur & ~(W - 1)) | src);
+}
+template <int W, int K>
+inline double group_bcast_static(double v) {
+  static_assert(W <= 32 && K < W, "");
+  return lane_shfl(v, (emu().cur & ~(W - 1)) | K);
+}
+template <int W, class Op>
+inline double emu_group_reduce(double v, Op op, int tag) {
+  const int l = emu().cur;
+  v = op(v, emu_exchange(v, l ^ 1, tag));
+  v = op(v, emu_exchange(v, l ^ 2, tag));
+  v = op(v, emu_exchange(v, (l & ~7) | (7 - (l & 7)), tag));
+  if (W >= 16) v = op(v, emu_exchange(v, (l & ~15) | (15 - (l & 15)), tag));
+  if (W >= 32) v = op(v, emu_exchange(v, l ^ 16, tag));
+  return v;
+}
+template <int W>
+inline double group_sum(double v) {
+  return emu_group_reduce<W>(v, [](double a, double b) { return a + b; }, 20);
+}
+template <int W>
+inline double group_min(double v) {
+  return emu_group_reduce<W>(v, [](double a, double b) { return std::fmin(a, b); }, 22);
+}
+template <int W>
+inline int groups_max(int v) {
+  int m = bcast_i(v, 0);
+  for (int g = 1; g < kWave / W; ++g) {
+    const int o = bcast_i(v, g * W);
+    m = o > m ? o : m;
+  }
+  return m;
+}
+template <int W>
+inline int groups_min(int v) {
+  int m = bcast_i(v, 0);
+  for (int g = 1; g < kWave / W; ++g) {
+    const int o = bcast_i(v, g * W);
+    m = o < m ? o : m;
+  }
+  return m;
+}
+
+struct v4d {
+  double d[4];
+  double &operator[](int i) { return d[i]; }
+  const double &operator[](int i) const { return d[i]; }
+};
+// D(16x16) += A(16x4) B(4x16): lane l gives A[l&15][l>>4], B[l>>4][l&15], gets D[(l>>4)+4r][l&15]
+inline v4d mfma_f64_16x16x4(double a, double b, v4d c) {
+  Emu &e = emu();
+  static double A[kWave], B[kWave];
+  A[e.cur] = a;
+  B[e.cur] = b;
+  emu_rendezvous(24);
+  const int col = e.cur & 15, rq = e.cur >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = rq + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) acc += A[k * 16 + row] * B[k * 16 + col];
+    c[r] = acc;
+  }
+  emu_rendezvous(25);
+  return c;
+}
 
 inline double from_next_lane(double v) {
   Emu &e = emu();
