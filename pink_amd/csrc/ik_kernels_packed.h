@@ -42,7 +42,7 @@ struct LdsP {
 
 template <int NV, int W>
 __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) {
-  static_assert(W >= NV && (W == 8 || W == 16 || W == 32), "group width");
+  static_assert(W >= NV && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
   constexpr double INF = INFINITY;

@@ -106,6 +106,11 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
     if (a.nv <= 16 && a.md <= 16) return launch_packed<16, 16>(h, a);
     if (a.nv <= 24) return launch_packed<24, 32>(h, a);
     if (a.nv <= 32) return launch_packed<32, 32>(h, a);
+    // nv > 32: one QP per wavefront, same kernel (packed triangular L / R keeps LDS small)
+    if (a.nv <= 40) return launch_packed<40, 64>(h, a);
+    if (a.nv <= 48) return launch_packed<48, 64>(h, a);
+    if (a.nv <= 56) return launch_packed<56, 64>(h, a);
+    return launch_packed<64, 64>(h, a);
   }
   switch (pinkhip::padded_nv(a.nv)) {
     case 8: return launch_nv<8>(h, a, solve);

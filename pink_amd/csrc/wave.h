@@ -27,9 +27,10 @@
 #define PINKHIP_OCCUPANCY_ATTR(NV) \
   __attribute__((amdgpu_waves_per_eu((NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE, \
                                      (NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE)))
+#define PINKHIP_PACKED_WAVES(NV) \
+  ((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : (NV) <= 32 ? PINKHIP_WAVES_PACKED_LARGE : PINKHIP_WAVES_LARGE)
 #define PINKHIP_OCCUPANCY_PACKED(NV) \
-  __attribute__((amdgpu_waves_per_eu((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : PINKHIP_WAVES_PACKED_LARGE, \
-                                     (NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : PINKHIP_WAVES_PACKED_LARGE)))
+  __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
 
 namespace pinkhip {
 
@@ -176,7 +177,8 @@ __device__ __forceinline__ int group_bcast_i(int v, int src) {
 // Same with a compile-time source lane: ds_swizzle bit mode (no address register).
 template <int W, int K>
 __device__ __forceinline__ double group_bcast_static(double v) {
-  static_assert(W <= 32 && K < W, "ds_swizzle bit mode works inside 32 lanes");
+  static_assert(K < W, "source lane outside the group");
+  if constexpr (W == 64) return bcast(v, K);  // one group: plain v_readlane
   constexpr int pattern = ((~(W - 1)) & 0x1F) | (K << 5);
   const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
@@ -196,6 +198,7 @@ __device__ __forceinline__ double group_sum(double v) {
   v += dpp_mov<kDppHalfMirror>(v);
   if (W >= 16) v += dpp_mov<kDppMirror>(v);
   if (W >= 32) v += swizzle_xor16(v);
+  if (W == 64) v = bcast(v, 0) + bcast(v, 32);
   return v;
 }
 template <int W>
@@ -205,6 +208,7 @@ __device__ __forceinline__ double group_min(double v) {
   v = fmin(v, dpp_mov<kDppHalfMirror>(v));
   if (W >= 16) v = fmin(v, dpp_mov<kDppMirror>(v));
   if (W >= 32) v = fmin(v, swizzle_xor16(v));
+  if (W == 64) v = fmin(bcast(v, 0), bcast(v, 32));
   return v;
 }
 // max / min over the groups of a group-uniform int (one v_readlane per group).

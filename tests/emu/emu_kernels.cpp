@@ -112,6 +112,10 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
     else if (a.nv <= 16 && a.md <= 16) { fn = lane_main_packed<16, 16>; G = 4; }
     else if (a.nv <= 24) { fn = lane_main_packed<24, 32>; G = 2; }
     else if (a.nv <= 32) { fn = lane_main_packed<32, 32>; G = 2; }
+    else if (a.nv <= 40) { fn = lane_main_packed<40, 64>; G = 1; }
+    else if (a.nv <= 48) { fn = lane_main_packed<48, 64>; G = 1; }
+    else if (a.nv <= 56) { fn = lane_main_packed<56, 64>; G = 1; }
+    else { fn = lane_main_packed<64, 64>; G = 1; }
     if (G) blocks = (d->B + G - 1) / G;
   }
   for (long long b = 0; b < blocks; ++b) pinkhip::emu_run_block(b, fn, &a);

@@ -201,7 +201,8 @@ inline int group_bcast_i(int v, int src) {
 }
 template <int W, int K>
 inline double group_bcast_static(double v) {
-  static_assert(W <= 32 && K < W, "");
+  static_assert(K < W, "");
+  if (W == 64) return bcast(v, K);
   return lane_shfl(v, (emu().cur & ~(W - 1)) | K);
 }
 template <int W, class Op>
@@ -212,6 +213,7 @@ inline double emu_group_reduce(double v, Op op, int tag) {
   v = op(v, emu_exchange(v, (l & ~7) | (7 - (l & 7)), tag));
   if (W >= 16) v = op(v, emu_exchange(v, (l & ~15) | (15 - (l & 15)), tag));
   if (W >= 32) v = op(v, emu_exchange(v, l ^ 16, tag));
+  if (W == 64) v = op(bcast(v, 0), bcast(v, 32));
   return v;
 }
 template <int W>
