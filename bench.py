@@ -134,6 +134,24 @@ def main() -> None:
         except Exception as exc:  # noqa: BLE001  report, never lose the bench line
             gather_ms = f"failed: {exc}"
 
+    # other input regimes of the same config, kernel time only (HIP events), rank 0
+    regimes = {}
+    if rank == 0:
+        for label, kw in (("kinematic_bounds", dict(bounds="kinematic", jacobians="kinematic")),
+                          ("tracking_small_errors", dict(bounds="kinematic", jacobians="kinematic", error_scale=0.02))):
+            t2 = synthetic.make_terms(args.config, B, seed=seed + 7, **kw)
+            d2 = solver.upload(synthetic.pack(t2))
+            solver.solve_device(d2)
+            solver.sync()
+            solver.timer_start()
+            for _ in range(5):
+                solver.solve_device(d2)
+            ms2 = solver.timer_stop() / 5
+            r2 = solver.download(d2)
+            regimes[label] = {"kernel_ms": ms2, "solves_per_s": B / (ms2 * 1e-3), "iters_mean": float(r2.iters.mean()),
+                              "failed": int((r2.status != 0).sum())}
+            d2.free()
+
     # stack-only kernel: the HBM-streaming half (build_ik equivalent), same batch
     solver.stack_device(dev)
     solver.sync()
@@ -172,19 +190,21 @@ def main() -> None:
                 "workload": f"{args.config}-shaped stand-in: nv={nv}, {len(terms.dense_tasks)} FrameTask(6 rows)+PostureTask, "
                             f"box limits, md={batch.md} barrier rows, B={B} per GPU, bounds={args.bounds}, jacobians={args.jacobians}",
                 "batch_per_gpu": B, "global_batch": world * B, "nv": nv, "Kd": batch.Kd, "K": batch.K, "md": batch.md,
-                "parallelism": f"batch-sharded x{world}", "solver": "wave-per-QP Goldfarb-Idnani (HIP, fp64)",
+                "parallelism": f"batch-sharded x{world}",
+                "solver": "Goldfarb-Idnani dual active set, HIP fp64, 64/W QPs per wavefront (W = 32 lanes per QP at nv = 30)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ik_solve_kernel", "kernel_ms": kernel_ms, "bytes_per_qp": bytes_qp,
-                "note": "fused stack+solve is fp64-ALU/latency bound, not HBM bound (DESIGN.md); stack_only is the HBM-streaming kernel",
+                "kernel": "ik_solve_packed_kernel", "kernel_ms": kernel_ms, "bytes_per_qp": bytes_qp,
+                "note": "fused stack+solve is VALU-issue / LDS / latency bound, not HBM bound (DESIGN.md 3.1); stack_only is the HBM-streaming kernel",
             },
             "stack_only": {
-                "kernel": "ik_stack_kernel", "kernel_ms": stack_ms, "bytes_per_qp": batch.bytes_per_stack(),
+                "kernel": "ik_stack_mfma_kernel", "kernel_ms": stack_ms, "bytes_per_qp": batch.bytes_per_stack(),
                 "achieved": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9, "unit": "GB/s",
                 "frac": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            "other_regimes": regimes,
             "solver_stats": {"failed": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
             "gather_ms": gather_ms,
             "device": info.get("gcn_arch"),

@@ -25,14 +25,14 @@ struct LdsP {
   static constexpr int TRI = NV * (NV + 3) / 2;   // packed triangle with one sub-diagonal slot per column
   static constexpr int RC = (TRI / NV < 32) ? TRI / NV : 32;  // staged J rows per chunk (pitch NV)
   static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then R
-  static constexpr int oX = oT + TRI;             // NV   column scratch / x
-  static constexpr int oY = oX + NV;              // NV   forward-solve scratch / y
-  static constexpr int oD = oY + NV;              // NV   d = J^T n+  (also 1/diag(L))
-  static constexpr int oD2 = oD + NV;             // NV
-  static constexpr int oV = oD2 + NV;             // NV
-  static constexpr int oWa = oV + NV;             // RC
-  static constexpr int oGs = oWa + RC + (RC & 1);  // RC
-  static constexpr int oGd = oGs + RC + (RC & 1);  // md*GP
+  static constexpr int oD = oT + TRI;             // NV   d = J^T n+          (init: 1/diag(L))
+  static constexpr int oD2 = oD + NV;             // NV   d with d1 zeroed    (init: column scratch; x for dense rows)
+  static constexpr int oV = oD2 + NV;             // NV   Householder vector  (init: forward-solve scratch y)
+  static constexpr int oX = oD2;                  // aliases: live ranges do not overlap
+  static constexpr int oY = oV;
+  static constexpr int oWa = oD;                  // RC <= NV: stacking weights, dead before oD is used
+  static constexpr int oGs = oD2;
+  static constexpr int oGd = oV + NV;             // md*GP
   static __host__ __device__ inline int stride(int md) { return (oGd + md * GP + 1) & ~1; }  // doubles per QP
   static __host__ __device__ inline long long bytes(int md, int groups) { return 8LL * stride(md) * groups + 16; }
   // L: row i, entries 0..i at i(i+1)/2;  R: column k, rows 0..k+1 at k(k+3)/2
@@ -350,22 +350,6 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         pin(w);
       }
     }
-#ifdef PINKHIP_EXP_DUP_ZW  // timing experiment: z/w products twice
-    {
-      double z2 = 1e-300, w2 = 1e-300;
-      pin(z2);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        z2 += Jr[j] * d2s[j];
-        w2 += Jr[j] * vs[j];
-        if ((j & (kG - 1)) == kG - 1) {
-          pin(z2);
-          pin(w2);
-        }
-      }
-      if (z2 == 1.2345e300) z = z2 + w2;
-    }
-#endif
     // r = R^-1 d1
     double dp = dl;
     {
@@ -375,19 +359,6 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         if (li < k && k < q) dp -= Rs[S::rcol(k) + li] * rk;
       }
     }
-#ifdef PINKHIP_EXP_DUP_BACKSUB  // timing experiment: run the back-substitution twice
-    {
-      double dp2 = dl;
-      pin(dp2);
-      const int qmax = groups_max<W>(act ? q : 0);
-      for (int k = qmax - 1; k > 0; --k) {
-        const double rk = group_bcast<W>(dp2 * rdiag, k);
-        if (li < k && k < q) dp2 -= Rs[S::rcol(k) + li] * rk;
-      }
-      pin(dp2);
-      if (dp2 == 1.2345e300) dp = dp2;
-    }
-#endif
     const double rv = dp * rdiag;
     // (c) step lengths
     const bool blocking = act && li < q && rv > 0.0;

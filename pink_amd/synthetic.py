@@ -126,10 +126,13 @@ def make_terms(
     jacobians: str = "dense",
     seed: Optional[int] = None,
     damping: float = 1e-12,
+    error_scale: float = 1.0,
 ) -> Terms:
     """Draw one batch.  ``bounds``: ``"tight"`` (about 45 % of the boxes active,
     the solver stress case) or ``"kinematic"`` (realistic joint-limit geometry,
-    few active bounds); ``jacobians``: ``"dense"`` or ``"kinematic"``."""
+    few active bounds); ``jacobians``: ``"dense"`` or ``"kinematic"``.  ``error_scale``
+    shrinks the task errors: 1.0 asks for steps far beyond the limits (most bounds
+    saturate), 0.02 is a controller tracking a slowly moving target (few do)."""
     cfg = CONFIGS[name]
     nv, root_nv, dt = cfg["nv"], cfg["root_nv"], cfg["dt"]
     rng = np.random.default_rng(SEED0 + cfg["config_id"] if seed is None else seed)
@@ -137,11 +140,11 @@ def make_terms(
     Js = _frame_jacobians(rng, B, nv, root_nv, n_frames, jacobians)
     dense = []
     for Jt, (pc, oc) in zip(Js, cfg["frame_costs"]):
-        e = 0.1 * rng.normal(size=(B, 6))
+        e = error_scale * 0.1 * rng.normal(size=(B, 6))
         cost = np.array([pc] * 3 + [oc] * 3)  # frame_task.py:71-127: [pos x3, ori x3]
         dense.append(DenseTaskTerm(J=Jt, e=e, cost=cost, gain=1.0, lm_damping=cfg["frame_lm"]))
     n_act = nv - root_nv
-    e_post = rng.uniform(-1.0, 1.0, size=(B, n_act)) * (1.0 if name == "ur5" else 0.5)
+    e_post = error_scale * rng.uniform(-1.0, 1.0, size=(B, n_act)) * (1.0 if name == "ur5" else 0.5)
     diag = [DiagonalTaskTerm(col0=root_nv, e=e_post, cost=cfg["posture_cost"], gain=1.0, lm_damping=0.0)]
 
     idx = root_nv + np.arange(n_act)
@@ -175,7 +178,7 @@ def make_terms(
     return Terms(
         name=name, nv=nv, root_nv=root_nv, dt=dt, damping=damping, dense_tasks=dense,
         diag_tasks=diag, cfg_lo=cfg_lo, cfg_hi=cfg_hi, vel=vel, limit_idx=idx, barriers=barriers,
-        meta=dict(config=name, bounds=bounds, jacobians=jacobians, B=B),
+        meta=dict(config=name, bounds=bounds, jacobians=jacobians, B=B, error_scale=error_scale),
     )
 
 
