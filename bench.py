@@ -59,6 +59,7 @@ def main() -> None:
     ap.add_argument("--jacobians", default="dense", choices=["dense", "kinematic"])
     ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra regimes (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +137,7 @@ def main() -> None:
 
     # other input regimes of the same config, kernel time only (HIP events), rank 0
     regimes = {}
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         for label, kw in (("kinematic_bounds", dict(bounds="kinematic", jacobians="kinematic")),
                           ("tracking_small_errors", dict(bounds="kinematic", jacobians="kinematic", error_scale=0.02))):
             t2 = synthetic.make_terms(args.config, B, seed=seed + 7, **kw)

@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IN
            "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc/p$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> gpurun_out/pmc/p$i.err
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc/p$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only "$@" > /dev/null 2> gpurun_out/pmc/p$i.err
   tail -2 gpurun_out/pmc/p$i.err
 done
 python - <<'PY'
