@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# test hooks (tests/test_bench_dryrun.py runs the N > 1 control flow on CPU with gloo)
+DEVICE = os.environ.get("PINKHIP_BENCH_DEVICE", "cuda")
+BACKEND = os.environ.get("PINKHIP_BENCH_BACKEND", "nccl")
 
 
 def cpu_baseline(terms, sample: int):
@@ -71,10 +74,13 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    on_gpu = DEVICE == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if on_gpu else {}
+        dist.init_process_group(BACKEND, rank=rank, world_size=world, **kw)
 
     import __graft_entry__ as g
     from pink_amd import synthetic
@@ -90,15 +96,18 @@ def main() -> None:
 
     solver = BatchSolver(device_id=local_rank)
     info = solver.device_info()
-    dq_t = torch.empty((B, nv), dtype=torch.float64, device="cuda")
-    st_t = torch.empty((B,), dtype=torch.int32, device="cuda")
-    it_t = torch.empty((B,), dtype=torch.int32, device="cuda")
+    dq_t = torch.empty((B, nv), dtype=torch.float64, device=DEVICE)
+    st_t = torch.empty((B,), dtype=torch.int32, device=DEVICE)
+    it_t = torch.empty((B,), dtype=torch.int32, device=DEVICE)
     dev = solver.upload(batch, out_ptrs=(dq_t.data_ptr(), st_t.data_ptr(), it_t.data_ptr()))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        else:
+            solver.sync()
 
     for _ in range(args.warmup):
         solver.solve_device(dev)
@@ -111,7 +120,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=DEVICE)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -124,12 +133,13 @@ def main() -> None:
     if world > 1:
         try:
             parts = [torch.empty_like(dq_t) for _ in range(world)] if rank == 0 else None
-            torch.cuda.synchronize()
+            barrier()
             tg = time.perf_counter()
             dist.gather(dq_t, parts, dst=0)
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             gather_ms = (time.perf_counter() - tg) * 1e3
-            bad_t = torch.tensor([n_bad], dtype=torch.int64, device="cuda")
+            bad_t = torch.tensor([n_bad], dtype=torch.int64, device=DEVICE)
             dist.all_reduce(bad_t)
             n_bad = int(bad_t.item())
         except Exception as exc:  # noqa: BLE001  report, never lose the bench line
