@@ -37,7 +37,7 @@ extern "C" {
 #define PINKHIP_E_HIP (-2)         /* a HIP runtime call failed                 */
 #define PINKHIP_E_NOMEM (-3)       /* device or host allocation failed          */
 #define PINKHIP_E_NODEVICE (-4)    /* no usable gfx950 device                   */
-#define PINKHIP_E_UNSUPPORTED (-5) /* feature reserved in the ABI (n_eq > 0)    */
+#define PINKHIP_E_UNSUPPORTED (-5) /* combination not supported by the selected kernel */
 #define PINKHIP_E_COMM (-6)        /* RCCL failure                              */
 
 /* Per-instance outcome (status[b]); anything non-zero maps to
@@ -71,7 +71,8 @@ typedef struct pinkhip_desc {
   int32_t Kd;  /* rows of dense-task Jacobians per instance                     */
   int32_t K;   /* all task rows per instance (= task_rows[T])                   */
   int32_t md;  /* dense inequality rows per instance, 0..PINKHIP_MAX_MD         */
-  int32_t n_eq; /* reserved: equality rows (constraints=, solve_ik.py:125-149); must be 0 */
+  int32_t n_eq; /* the first n_eq dense rows are equalities Gd dq = hd (constraints=,
+                   pink/solve_ik.py:125-149: A = J, b = -gain e); 0..min(md, nv) */
   const int32_t *task_rows;  /* [T+1] host                                      */
   const int32_t *task_kind;  /* [T]   host, PINKHIP_TASK_*                      */
   const int32_t *task_col0;  /* [T]   host, first tangent column of a diagonal task */
@@ -94,7 +95,8 @@ typedef struct pinkhip_desc {
  *   lb, ub [B,nv]  box merged from every +-e_i limit row
  *                  (configuration_limit.py:117-120, velocity_limit.py:118-120);
  *                  -inf/+inf = coordinate without that bound
- *   Gd  [B,md,nv], hd [B,md]  remaining rows of G dq <= h (solve_ik.py:107-122)
+ *   Gd  [B,md,nv], hd [B,md]  equality rows A dq = b first (n_eq of them, solve_ik.py:140-149),
+ *                  then the remaining rows of G dq <= h (solve_ik.py:107-122)
  *   c_extra [B,nv] or NULL   extra linear term (barrier.py:201)
  */
 typedef struct pinkhip_problem {

@@ -35,14 +35,14 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_gi_work_size.restype = ctypes.c_long
         _lib.oracle_gi_work_size.argtypes = [ctypes.c_int, ctypes.c_int]
-        _lib.oracle_gi_solve.restype = ctypes.c_int
-        _lib.oracle_gi_solve.argtypes = [
-            ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _ip, ctypes.c_int, _dp,
+        _lib.oracle_gi_solve_eq.restype = ctypes.c_int
+        _lib.oracle_gi_solve_eq.argtypes = [
+            ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _ip, ctypes.c_int, _dp,
         ]
         _lib.oracle_solve_ik_batch.restype = ctypes.c_int
         _lib.oracle_solve_ik_batch.argtypes = [
             ctypes.c_long, ctypes.c_int, ctypes.c_int, _ip, _dp, _dp, _dp, ctypes.c_int, _dp, _dp,
-            ctypes.c_double, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _ip, _ip, _dp, _dp,
+            ctypes.c_double, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _ip, _ip, _dp, _dp,
             ctypes.c_int, ctypes.c_int,
         ]
     return _lib
@@ -56,8 +56,9 @@ def _i(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_ip)
 
 
-def gi_solve(P, q, G=None, h=None, max_iter: int = 0):
-    """One QP through the C Goldfarb-Idnani; returns (x, status, iters, lam)."""
+def gi_solve(P, q, G=None, h=None, max_iter: int = 0, meq: int = 0):
+    """One QP through the C Goldfarb-Idnani; returns (x, status, iters, lam).  The first
+    ``meq`` rows of ``(G, h)`` are equalities."""
     P = np.ascontiguousarray(P, dtype=np.float64)
     q = np.ascontiguousarray(q, dtype=np.float64)
     n = q.size
@@ -68,13 +69,13 @@ def gi_solve(P, q, G=None, h=None, max_iter: int = 0):
     lam = np.zeros(max(m, 1))
     it = ctypes.c_int(0)
     work = np.zeros(lib().oracle_gi_work_size(n, m))
-    st = lib().oracle_gi_solve(n, _d(P), _d(q), m, _d(Gc), _d(hc), _d(x), _d(lam), ctypes.byref(it), max_iter, _d(work))
+    st = lib().oracle_gi_solve_eq(n, _d(P), _d(q), m, int(meq), _d(Gc), _d(hc), _d(x), _d(lam), ctypes.byref(it), max_iter, _d(work))
     return x, st, it.value, lam[:m]
 
 
 def solve_ik_batch(
     J, e, cost, gain, lm, rows, damping, G=None, h=None, diag_extra=None, c_extra=None,
-    want_Hc: bool = False, solve: bool = True, nthreads: int = 1,
+    want_Hc: bool = False, solve: bool = True, nthreads: int = 1, meq: int = 0,
 ):
     """Pink-form batch -> dq.  Shapes: J [B,K,nv], e [B,K], cost [K] or [B,K],
     G [B,m,nv], h [B,m].  Returns dict(dq, status, iters[, H, c])."""
@@ -100,7 +101,7 @@ def solve_ik_batch(
     c = np.zeros((B, nv)) if want_Hc else None
     rc = lib().oracle_solve_ik_batch(
         B, nv, T, _i(rows), _d(J), _d(e), _d(cost), cost_batched, _d(gain), _d(lm), float(damping),
-        _d(de), _d(ce), m, _d(Gc), _d(hc), _d(dq), _i(status), _i(iters), _d(H), _d(c),
+        _d(de), _d(ce), m, int(meq), _d(Gc), _d(hc), _d(dq), _i(status), _i(iters), _d(H), _d(c),
         int(solve), int(nthreads),
     )
     if rc != 0:

@@ -43,14 +43,19 @@ long oracle_gi_work_size(int n, int m) {
 /*
  * min 1/2 x'Px + q'x   s.t.  G x <= h      (P: n x n row-major, G: m x n row-major)
  *
+ * The first `meq` rows are equalities G_i x = h_i (pink/solve_ik.py:140-149 builds them from
+ * `constraints=`; qpsolvers passes them to quadprog as its `meq` leading constraints): they are
+ * activated first, with the normal oriented so that the residual reads as a violation, and are
+ * never dropped.
+ *
  * Returns a status code; x[n], lam[m] (may be NULL), *iters (may be NULL).
  * Goldfarb-Idnani, SURVEY.md Appendix B.2.  Constraints are handled in the
  * form n_i' x >= b_i with n_i = -G_i, b_i = -h_i (qpsolvers -> quadprog
  * mapping, Appendix B.1).
  */
-int oracle_gi_solve(int n, const double *P, const double *q, int m, const double *G,
-                    const double *h, double *x, double *lam, int *iters, int max_iter,
-                    double *work) {
+int oracle_gi_solve_eq(int n, const double *P, const double *q, int m, int meq, const double *G,
+                       const double *h, double *x, double *lam, int *iters, int max_iter,
+                       double *work) {
   double *L = work;            /* n*n lower Cholesky factor            */
   double *J = L + (long)n * n; /* n*n, J = L^-T Q                      */
   double *R = J + (long)n * n; /* n*n upper triangular, leading qa*qa  */
@@ -64,7 +69,7 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
   double *uall = nrm + m;      /* m                                    */
   int *A = (int *)(uall + m);  /* n   active row indices (as ints)     */
   int *is_active = A + n + 2;  /* m                                    */
-  int it = 0, qa = 0;
+  int it = 0, qa = 0, eq_next = 0;
   const double tol = 1e-13;
 
   if (iters) *iters = 0;
@@ -115,24 +120,36 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
   }
 
   for (;;) {
-    /* Step 1: most violated constraint (violation / row norm, as quadprog) */
+    /* Step 1: pending equality first, else the most violated inequality (violation / row
+       norm, as quadprog) */
     int p = -1;
-    double worst = 0.0, sp = 0.0;
-    for (int i = 0; i < m; ++i) {
-      if (is_active[i]) continue;
-      double s = h[i]; /* slack s = h_i - G_i x; violated when s < 0 */
-      for (int k = 0; k < n; ++k) s -= G[(long)i * n + k] * x[k];
-      double sc = s / nrm[i];
-      double thr = -tol * (1.0 + fabs(h[i]) / nrm[i]);
-      if (sc < thr && (p < 0 || sc < worst)) {
-        p = i;
-        worst = sc;
-        sp = s;
+    double worst = 0.0, sp = 0.0, sgn = 1.0;
+    if (eq_next < meq) {
+      p = eq_next;
+      double s = h[p];
+      for (int k = 0; k < n; ++k) s -= G[(long)p * n + k] * x[k];
+      if (s > 0.0) {  /* orient the normal so that the residual is a violation */
+        sgn = -1.0;
+        s = -s;
+      }
+      sp = s;
+    } else {
+      for (int i = meq; i < m; ++i) {
+        if (is_active[i]) continue;
+        double s = h[i]; /* slack s = h_i - G_i x; violated when s < 0 */
+        for (int k = 0; k < n; ++k) s -= G[(long)i * n + k] * x[k];
+        double sc = s / nrm[i];
+        double thr = -tol * (1.0 + fabs(h[i]) / nrm[i]);
+        if (sc < thr && (p < 0 || sc < worst)) {
+          p = i;
+          worst = sc;
+          sp = s;
+        }
       }
     }
     if (p < 0) break; /* optimal */
 
-    for (int k = 0; k < n; ++k) np_[k] = -G[(long)p * n + k];
+    for (int k = 0; k < n; ++k) np_[k] = -sgn * G[(long)p * n + k];
     double uplus = 0.0;
 
     for (;;) {
@@ -163,6 +180,7 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
       double t1 = INFINITY, t2 = INFINITY;
       int drop = -1;
       for (int k = 0; k < qa; ++k) {
+        if (A[k] < meq) continue; /* equalities are never dropped */
         if (r[k] > 0.0) {
           double cand = u[k] / r[k];
           if (cand < t1) {
@@ -177,6 +195,11 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
         /* n+'x - b_p = h_p - G_p x = sp < 0.  The full step makes the row
            active: n+'(x + t z) = b_p  =>  t = -sp / (z'n+). */
         t2 = -sp / zn;
+      }
+      if (p < meq && !(t2 < INFINITY) && !(t1 < INFINITY) && fabs(sp) <= 1e-9 * (1.0 + fabs(h[p]))) {
+        /* equality implied by the active ones and already satisfied: nothing to add */
+        ++eq_next;
+        break;
       }
       double t = (t1 < t2) ? t1 : t2;
       if (!(t < INFINITY)) {
@@ -208,8 +231,9 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
           }
           for (int k = 0; k <= qa; ++k) R[(long)k * n + qa] = d[k];
           A[qa] = p;
-          u[qa] = uplus;
+          u[qa] = (p < meq) ? -sgn * uplus : uplus; /* multiplier of G_p x = h_p, either sign */
           is_active[p] = 1;
+          if (p < meq) ++eq_next;
           ++qa;
           break; /* back to step 1 */
         }
@@ -242,7 +266,7 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
       {
         double s = h[p];
         for (int k = 0; k < n; ++k) s -= G[(long)p * n + k] * x[k];
-        sp = s;
+        sp = sgn * s;
       }
     }
   }
@@ -250,6 +274,12 @@ int oracle_gi_solve(int n, const double *P, const double *q, int m, const double
   if (lam)
     for (int k = 0; k < qa; ++k) lam[A[k]] = u[k];
   return ORACLE_OPTIMAL;
+}
+
+int oracle_gi_solve(int n, const double *P, const double *q, int m, const double *G,
+                    const double *h, double *x, double *lam, int *iters, int max_iter,
+                    double *work) {
+  return oracle_gi_solve_eq(n, P, q, m, 0, G, h, x, lam, iters, max_iter, work);
 }
 
 /*
@@ -292,13 +322,14 @@ void oracle_task_objective(int k, int nv, const double *J, const double *e, cons
  *   gain, lm [T];  rows [T+1] row offsets
  *   diag_extra [B] or NULL -- sum over barriers of r_b / ||J_h,b||_F^2 (barrier.py:193-200)
  *   c_extra [B, nv] or NULL -- sum over barriers of -rho_b dq_safe,b (barrier.py:201)
- *   G [B, m, nv], h [B, m]   (solve_ik.py:107-122)
+ *   G [B, m, nv], h [B, m]   (solve_ik.py:107-122); the first meq rows are equalities
+ *                            A dq = b (solve_ik.py:140-149)
  * Outputs dq [B, nv], status [B], iters [B]; optional H_out [B, nv, nv], c_out [B, nv].
  */
 int oracle_solve_ik_batch(long B, int nv, int T, const int *rows, const double *J, const double *e,
                           const double *cost, int cost_batched, const double *gain,
                           const double *lm, double damping, const double *diag_extra,
-                          const double *c_extra, int m, const double *G, const double *h,
+                          const double *c_extra, int m, int meq, const double *G, const double *h,
                           double *dq, int *status, int *iters, double *H_out, double *c_out,
                           int solve, int nthreads) {
   const int K = rows[T];
@@ -340,8 +371,8 @@ int oracle_solve_ik_batch(long B, int nv, int T, const int *rows, const double *
       if (c_out) memcpy(c_out + b * nv, c, sizeof(double) * nv);
       if (solve) {
         int it = 0;
-        int st = oracle_gi_solve(nv, H, c, m, m ? G + b * m * nv : NULL, m ? h + b * m : NULL,
-                                 dq + b * nv, NULL, &it, 0, work);
+        int st = oracle_gi_solve_eq(nv, H, c, m, meq, m ? G + b * m * nv : NULL, m ? h + b * m : NULL,
+                                    dq + b * nv, NULL, &it, 0, work);
         status[b] = st;
         if (iters) iters[b] = it;
       }

@@ -154,7 +154,7 @@ class PackedArgs:
         if self.Gd.shape != (B, batch.md, nv) or self.hd.shape != (B, batch.md):
             raise ValueError("inconsistent dense-row shapes")
         d = Desc()
-        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, batch.T, batch.Kd, batch.K, batch.md, 0
+        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, batch.T, batch.Kd, batch.K, batch.md, int(batch.n_eq)
         d.task_rows = self.task_rows.ctypes.data_as(c_int32_p)
         d.task_kind = self.task_kind.ctypes.data_as(c_int32_p)
         d.task_col0 = self.task_col0.ctypes.data_as(c_int32_p)

@@ -103,6 +103,7 @@ class IKBatch:
     c_extra: Optional[np.ndarray] = None  # [B, nv]
     damping: float = 1e-12
     dt: float = 1e-3
+    n_eq: int = 0  # the first n_eq rows of Gd/hd are equalities (constraints=, solve_ik.py:125-149)
     meta: dict = field(default_factory=dict)
 
     @property
@@ -143,7 +144,7 @@ class IKBatch:
             self.nv, self.J[lo:hi], self.e[lo:hi], cost, self.task_rows, self.task_kind,
             self.task_col0, self.gain, self.lm_damping, self.lb[lo:hi], self.ub[lo:hi],
             self.Gd[lo:hi], self.hd[lo:hi], self.barrier_rows, self.barrier_safe_gain,
-            None if self.c_extra is None else self.c_extra[lo:hi], self.damping, self.dt,
+            None if self.c_extra is None else self.c_extra[lo:hi], self.damping, self.dt, self.n_eq,
             dict(self.meta),
         )
 
@@ -157,11 +158,14 @@ def pack_terms(
     dense_rows: Sequence[tuple] = (),
     barriers: Sequence[BarrierTerm] = (),
     batch_size: Optional[int] = None,
+    equality_rows: Sequence[tuple] = (),
 ) -> IKBatch:
     """Pack per-task / per-limit terms into an :class:`IKBatch`.
 
     ``boxes`` holds ``(lb, ub)`` pairs (``[B, nv]`` or ``[nv]``) that are
-    intersected; ``dense_rows`` holds ``(G [B, r, nv], h [B, r])`` pairs.
+    intersected; ``dense_rows`` holds ``(G [B, r, nv], h [B, r])`` pairs;
+    ``equality_rows`` holds ``(A [B, r, nv], b [B, r])`` pairs enforced as ``A dq = b``
+    (they become the leading dense rows).
     Dense tasks are moved ahead of diagonal ones (the objective is a sum, so
     the order is immaterial: ``pink/solve_ik.py:57-60``).
     """
@@ -236,8 +240,11 @@ def pack_terms(
         lb = np.maximum(lb, np.broadcast_to(np.asarray(blo, dtype=np.float64), (B, nv)))
         ub = np.minimum(ub, np.broadcast_to(np.asarray(bhi, dtype=np.float64), (B, nv)))
 
-    G_list = [np.asarray(G, dtype=np.float64) for G, _ in dense_rows]
-    h_list = [np.asarray(h, dtype=np.float64) for _, h in dense_rows]
+    G_list = [np.asarray(A, dtype=np.float64) for A, _ in equality_rows]
+    h_list = [np.asarray(bb, dtype=np.float64) for _, bb in equality_rows]
+    n_eq = sum(g.shape[1] for g in G_list)
+    G_list += [np.asarray(G, dtype=np.float64) for G, _ in dense_rows]
+    h_list += [np.asarray(h, dtype=np.float64) for _, h in dense_rows]
     brow = [sum(g.shape[1] for g in G_list)]
     bsafe: List[float] = []
     c_extra = None
@@ -276,6 +283,7 @@ def pack_terms(
         c_extra=None if c_extra is None else np.ascontiguousarray(c_extra),
         damping=float(damping),
         dt=float(dt),
+        n_eq=int(n_eq),
     )
 
 

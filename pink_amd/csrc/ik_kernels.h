@@ -64,6 +64,7 @@ constexpr int STATUS_NOT_PD = 3;
 struct KernelArgs {
   long long B;
   int nv, Kd, K, md;
+  int n_eq;          // the first n_eq dense rows are equalities Gd dq = hd (packed kernel only)
   int n_dtasks;      // diagonal tasks
   int n_barriers;
   int cost_batched;

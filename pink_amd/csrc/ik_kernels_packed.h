@@ -50,7 +50,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 
   const int lane = lane_id();
   const int g = lane / W, li = lane & (W - 1);
-  const int nv = a.nv, Kd = a.Kd, K = a.K, md = a.md;
+  const int nv = a.nv, Kd = a.Kd, K = a.K, md = a.md, n_eq = a.n_eq;
   long long b = block * G + g;
   const bool valid = b < a.B;
   if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
@@ -252,13 +252,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const double thr_lo = (in && lbv > -INF) ? -tol * (1.0 + fabs(lbv)) : -INF;
   const double thr_up = (in && ubv < INF) ? -tol * (1.0 + fabs(ubv)) : -INF;
   const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
-  int q = 0, it = 0;        // group-uniform
+  int q = 0, it = 0, eq_next = 0;  // group-uniform
   int bstate = 0, dactive = 0, A = 0;
   double u = 0.0, rdiag = 0.0;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
   int kind = 0, src = 0, bid = 0;
-  double sp = 0.0, uplus = 0.0;
+  double sp = 0.0, uplus = 0.0, hpend = 0.0;
 
   for (;;) {
     // (a) selection, for the groups that have no pending constraint
@@ -275,15 +275,33 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           for (int j = 0; j < nv; ++j) s -= Gs[li * GP + j] * xs[j];
           sd = s;
           const double sc = s * ginv;
-          if (!dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) best = key_pack(sc, 128 + li);
+          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best)
+            best = key_pack(sc, 128 + li);
         }
         wave_sync();
       }
       best = group_min<W>(best);
       const bool sel = running && need_sel;
       const bool none = !(best < 0.0);
-      if (sel && none) running = false;  // optimal
-      if (sel && !none) {
+      // equalities (the first n_eq dense rows; pink/solve_ik.py:140-149) are activated first, in
+      // order, with the normal oriented so that the residual reads as a violation (kind 3 = +g)
+      const bool eqsel = sel && eq_next < n_eq;
+      double sdp = 0.0, hvp = 0.0;
+      if (n_eq > 0) {
+        sdp = group_bcast<W>(sd, eq_next < n_eq ? eq_next : 0);
+        hvp = group_bcast<W>(hv, eq_next < n_eq ? eq_next : 0);
+      }
+      if (eqsel) {
+        hpend = hvp;
+        kind = (sdp > 0.0) ? 3 : 2;
+        src = eq_next;
+        bid = (kind << 6) | eq_next;
+        uplus = 0.0;
+        need_sel = false;
+        sp = -fabs(sdp);
+      }
+      if (sel && !eqsel && none) running = false;  // optimal
+      if (sel && !eqsel && !none) {
         bid = key_payload(best);
         kind = bid >> 6;
         src = bid & 63;
@@ -292,7 +310,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
       const double cand = (kind == 0) ? slo : (kind == 1) ? sup : sd;
       const double spn = group_bcast<W>(cand, src & (W - 1));
-      if (sel && !none) sp = spn;
+      if (sel && !eqsel && !none) sp = spn;
     }
     if (running) {
       if (++it > max_iter) {
@@ -314,9 +332,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       const double rowv = (li < NV) ? ds[lv] : 0.0;
       if (act && kind < 2) dl = (kind == 0) ? rowv : -rowv;
     }
-    if (md > 0 && wave_any(act && kind == 2)) {
-      const bool dn = act && kind == 2;
-      const double gi = (in && dn) ? -Gs[(src & 31) * GP + li] : 0.0;
+    if (md > 0 && wave_any(act && kind >= 2)) {
+      const bool dn = act && kind >= 2;
+      const double gi = (in && dn) ? ((kind == 3) ? Gs[(src & 31) * GP + li] : -Gs[(src & 31) * GP + li]) : 0.0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const double s = group_sum<W>(Jr[j] * gi);
@@ -324,9 +342,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
     }
     double dd = group_bcast<W>(rown2, src & (W - 1));
-    if (md > 0 && wave_any(act && kind == 2)) {
+    if (md > 0 && wave_any(act && kind >= 2)) {
       const double dds = group_sum<W>(dl * dl);
-      if (kind == 2) dd = dds;
+      if (kind >= 2) dd = dds;
     }
     const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
     const bool lin_dep = !(d2n > 1e-24 * dd);
@@ -361,7 +379,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     }
     const double rv = dp * rdiag;
     // (c) step lengths
-    const bool blocking = act && li < q && rv > 0.0;
+    const bool eq_pos = (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
+    const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
     const double ratio = blocking ? u * fast_rcp(rv) : BIG;
     const double k1 = group_min<W>(blocking ? key_pack(ratio, li) : BIG);
     const int kd = key_payload(k1) & (W - 1);
@@ -370,10 +389,16 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
     const double t = (t1 < t2) ? t1 : t2;
     if (act && !(t < INF)) {
-      status = STATUS_INFEASIBLE;
-      running = false;
+      if (kind >= 2 && src < n_eq && fabs(sp) <= 1e-9 * (1.0 + fabs(hpend))) {
+        // equality implied by the active ones and already satisfied: nothing to add
+        ++eq_next;
+        need_sel = true;
+      } else {
+        status = STATUS_INFEASIBLE;
+        running = false;
+      }
     }
-    const bool act2 = act && running;
+    const bool act2 = act && running && (t < INF);
     const bool dual_only = act2 && !(t2 < INF);
     const bool do_add = act2 && (t2 < INF) && (t2 <= t1);
     const bool do_drop = act2 && !do_add;
@@ -404,7 +429,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           if (kind == 0) bstate = 1;
           else if (kind == 1) bstate = 2;
         }
-        if (kind == 2 && li == (src & 31)) dactive = 1;
+        if (kind >= 2 && li == (src & 31)) dactive = 1;
+        if (kind >= 2 && src < n_eq) ++eq_next;
         ++q;
         need_sel = true;
       }

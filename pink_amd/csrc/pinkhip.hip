@@ -131,7 +131,9 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   if (!d) return fail(h, PINKHIP_E_INVALID, "null descriptor");
   pinkhip::HostTables t;
   const std::string why = pinkhip::build_tables(*d, t);
-  if (!why.empty()) return fail(h, d->n_eq != 0 ? PINKHIP_E_UNSUPPORTED : PINKHIP_E_INVALID, why);
+  if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
+  if (d->n_eq > 0 && !h->packed)
+    return fail(h, PINKHIP_E_UNSUPPORTED, "equality constraints need the packed kernel (unset PINKHIP_KERNEL=wave)");
   PH_HIP(h, hipSetDevice(h->device));
 
   // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
@@ -172,6 +174,7 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   a.Kd = d->Kd;
   a.K = d->K;
   a.md = d->md;
+  a.n_eq = d->n_eq;
   a.n_dtasks = static_cast<int>(nd);
   a.n_barriers = static_cast<int>(nb);
   a.cost_batched = d->cost_is_batched;

@@ -27,10 +27,10 @@ class IKProblem:
     kernel.  ``batch`` is the packed single-instance batch handed to the solver.
     """
 
-    def __init__(self, batch: IKBatch, G: Optional[np.ndarray], h: Optional[np.ndarray]):
+    def __init__(self, batch: IKBatch, G: Optional[np.ndarray], h: Optional[np.ndarray], A=None, b=None):
         self.batch = batch
         self.G, self.h = G, h
-        self.A = self.b = None
+        self.A, self.b = A, b
         self._Pq: Optional[Tuple[np.ndarray, np.ndarray]] = None
 
     def _stack(self):
@@ -98,17 +98,26 @@ def _pink_rows(configuration, dt, limits, barriers):
     return np.vstack(G_list), np.hstack(h_list)
 
 
+def _equalities(configuration, constraints):
+    """``A = J``, ``b = -gain e`` of the tasks to enforce strictly (``pink/solve_ik.py:125-149``)."""
+    if not constraints:
+        return None, None
+    A_list = [np.asarray(t.compute_jacobian(configuration), dtype=float) for t in constraints]
+    b_list = [-t.gain * np.asarray(t.compute_error(configuration), dtype=float) for t in constraints]
+    return np.vstack(A_list), np.hstack(b_list)
+
+
 def build_ik(configuration, tasks: Iterable, dt: float, damping: float = 1e-12, limits=None, barriers=None,
              constraints=None) -> IKProblem:
     """Build the QP of one IK step (``pink/solve_ik.py:152-203``)."""
-    if constraints:
-        raise PinkError("equality constraints (constraints=) are reserved in the MI355X ABI (n_eq must be 0)")
     tasks = list(tasks)
     nv, task_terms, lb, ub, dense_rows, barrier_terms, limits = _collect_terms(configuration, tasks, dt, limits, barriers)
+    A, b = _equalities(configuration, constraints)
     batch = pack_terms(nv, task_terms, dt, damping, boxes=[(lb[None], ub[None])], dense_rows=dense_rows,
-                       barriers=barrier_terms, batch_size=1)
+                       barriers=barrier_terms, batch_size=1,
+                       equality_rows=[(A[None], b[None])] if A is not None else ())
     G, h = _pink_rows(configuration, dt, limits, barriers)
-    return IKProblem(batch, G, h)
+    return IKProblem(batch, G, h, A, b)
 
 
 def solve_ik(configuration, tasks: Iterable, dt: float, solver: str = "mi355x", damping: float = 1e-12, limits=None,

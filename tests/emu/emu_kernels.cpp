@@ -61,6 +61,7 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   a.Kd = d->Kd;
   a.K = d->K;
   a.md = d->md;
+  a.n_eq = d->n_eq;
   a.n_dtasks = static_cast<int>(t.dtask_k.size());
   a.n_barriers = d->n_barriers;
   a.cost_batched = d->cost_is_batched;
@@ -98,6 +99,10 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   long long blocks = d->B;
   const char *k = std::getenv("PINKHIP_KERNEL");
   const bool packed = !(k && std::strcmp(k, "wave") == 0);
+  if (d->n_eq > 0 && !packed) {
+    g_err = "equality constraints need the packed kernel";
+    return PINKHIP_E_UNSUPPORTED;
+  }
   if (!solve && packed) {
     switch ((a.nv + 15) / 16) {
       case 1: fn = lane_main_stack_mfma<1>; break;

@@ -190,3 +190,46 @@ def unconstrained(solver):
     assert np.abs(out.dq - ref["dq"]).max() <= TOL_DQ
     x = -np.linalg.solve(ref["H"], ref["c"][..., None])[..., 0]
     assert np.abs(out.dq - x).max() <= 1e-9
+
+
+def equality_constraints(solver, nv, n_eq, md_ineq, B, seed):
+    """constraints= (pink/solve_ik.py:125-149): A dq = b rows are the leading dense rows."""
+    rng = np.random.default_rng(seed)
+    J = rng.normal(0, 0.5, size=(B, 6, nv))
+    e = 0.1 * rng.normal(size=(B, 6))
+    ep = rng.uniform(-0.5, 0.5, size=(B, nv))
+    A = rng.normal(size=(B, n_eq, nv))
+    bvec = 0.01 * rng.normal(size=(B, n_eq))
+    lb = -rng.uniform(0.01, 0.05, size=(B, nv))
+    ub = rng.uniform(0.01, 0.05, size=(B, nv))
+    Gi = rng.normal(size=(B, md_ineq, nv))
+    hi = rng.uniform(0.0, 0.05, size=(B, md_ineq))
+    batch = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0), DiagonalTaskTerm(col0=0, e=ep, cost=0.1)], 0.005, 1e-12,
+                       boxes=[(lb, ub)], dense_rows=[(Gi, hi)] if md_ineq else (), equality_rows=[(A, bvec)], batch_size=B)
+    assert batch.n_eq == n_eq and batch.md == n_eq + md_ineq
+    out = solver.solve(batch)
+    eye = np.eye(nv)
+    G = np.concatenate([A, np.broadcast_to(eye, (B, nv, nv)), np.broadcast_to(-eye, (B, nv, nv)), Gi], axis=1)
+    h = np.concatenate([bvec, ub, -lb, hi], axis=1)
+    ref = c_oracle.solve_ik_batch(np.concatenate([J, np.broadcast_to(eye, (B, nv, nv))], axis=1),
+                                  np.concatenate([e, ep], axis=1), np.concatenate([np.ones(6), np.full(nv, 0.1)]),
+                                  np.ones(2), np.zeros(2), np.array([0, 6, 6 + nv], np.int32), 1e-12, G, h, meq=n_eq,
+                                  nthreads=0)
+    ok = ref["status"] == 0
+    assert (out.status == ref["status"]).all()
+    assert np.abs(out.dq[ok] - ref["dq"][ok]).max() <= TOL_DQ
+    assert np.abs(np.einsum("bmj,bj->bm", A, out.dq)[ok] - bvec[ok]).max() < 1e-12
+
+
+def equality_edge_cases(solver):
+    """A duplicated (consistent) equality is skipped; an inconsistent one reports status 2."""
+    nv, B = 5, 2
+    t = [DiagonalTaskTerm(col0=0, e=np.ones((B, nv)), cost=1.0)]
+    A = np.zeros((B, 2, nv))
+    A[:, 0, :2] = 1.0
+    A[:, 1, :2] = 2.0
+    box = [(-np.ones((B, nv)), np.ones((B, nv)))]
+    ok = solver.solve(pack_terms(nv, t, 0.01, 1e-12, boxes=box, equality_rows=[(A, np.tile([0.2, 0.4], (B, 1)))], batch_size=B))
+    assert (ok.status == 0).all() and np.abs(ok.dq[:, 0] + ok.dq[:, 1] - 0.2).max() < 1e-13
+    bad = solver.solve(pack_terms(nv, t, 0.01, 1e-12, boxes=box, equality_rows=[(A, np.tile([0.2, 0.5], (B, 1)))], batch_size=B))
+    assert (bad.status == 2).all()

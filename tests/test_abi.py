@@ -60,7 +60,7 @@ def test_descriptor_validation(emu):
     for mut, word in [
         (lambda a: setattr(a.desc, "nv", 65), "nv"),
         (lambda a: setattr(a.desc, "md", 33), "md"),
-        (lambda a: setattr(a.desc, "n_eq", 1), "equality"),
+        (lambda a: setattr(a.desc, "n_eq", 1), "n_eq"),
         (lambda a: setattr(a.desc, "dt", 0.0), "dt"),
         (lambda a: setattr(a.desc, "K", 13), "task_rows"),
         (lambda a: setattr(a.desc, "Kd", 5), "Kd"),

@@ -189,6 +189,39 @@ def test_solve_ik_batch_equals_loop_and_reports_failures(backend):
         solve_ik(cfgs[0], [task], 5e-3, solver="quadprog")
 
 
+def test_equality_constraints_via_constraints_argument(backend):
+    """pink/solve_ik.py:125-149: a task passed in constraints= is enforced exactly: J dq = -gain e."""
+    m, cfg = _arm()
+    hold = FrameTask("tool0", 1.0, 0.0)  # keep the tool position ...
+    hold.set_target_from_configuration(cfg)
+    post = PostureTask(cost=1.0)  # ... while the posture task pulls the joints to zero
+    post.set_target(np.zeros(6))
+    dt = 5e-3
+
+    class PositionOnly(pink_amd.Task):
+        def __init__(self, inner):
+            super().__init__(gain=1.0)
+            self.inner = inner
+
+        def compute_error(self, configuration):
+            return self.inner.compute_error(configuration)[:3]
+
+        def compute_jacobian(self, configuration):
+            return self.inner.compute_jacobian(configuration)[:3]
+
+        def __repr__(self):
+            return "PositionOnly()"
+
+    con = PositionOnly(hold)
+    prob = build_ik(cfg, [post], dt, constraints=[con])
+    assert prob.A.shape == (3, 6) and prob.b.shape == (3,) and prob.batch.n_eq == 3
+    v = solve_ik(cfg, [post], dt, constraints=[con])
+    assert np.abs(con.compute_jacobian(cfg) @ (v * dt) + con.compute_error(cfg)).max() < 1e-12
+    assert np.linalg.norm(v) > 1e-3  # the posture task still moves the arm in the null space
+    v_free = solve_ik(cfg, [post], dt)
+    assert np.linalg.norm(con.compute_jacobian(cfg) @ v_free) > 1e-3  # without the constraint the tool moves
+
+
 def test_urdf_reader_on_reference_robots():
     import os
 

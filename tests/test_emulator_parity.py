@@ -76,3 +76,12 @@ def test_empty_batch(emu):
 
 def test_unconstrained(emu):
     ps.unconstrained(emu)
+
+
+@pytest.mark.parametrize("nv,n_eq,md", [(6, 2, 0), (12, 3, 2), (30, 6, 3), (50, 4, 2)])
+def test_equality_constraints(emu, nv, n_eq, md):
+    ps.equality_constraints(emu, nv, n_eq, md, B=3, seed=900 + nv)
+
+
+def test_equality_edge_cases(emu):
+    ps.equality_edge_cases(emu)

@@ -57,6 +57,12 @@ def test_edge_cases(gpu_solver):
     ps.unconstrained(gpu_solver)
 
 
+@pytest.mark.parametrize("nv,n_eq,md", [(6, 2, 0), (12, 3, 2), (30, 6, 3), (50, 4, 2)])
+def test_equality_constraints(gpu_solver, nv, n_eq, md):
+    ps.equality_constraints(gpu_solver, nv, n_eq, md, B=512, seed=900 + nv)
+    ps.equality_edge_cases(gpu_solver)
+
+
 def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
     """Vectorised KKT check for box (+ dense) QPs; returns (stationarity, violation)."""
     g = np.einsum("bij,bj->bi", H, dq) + c
