@@ -158,6 +158,20 @@ int pinkhip_stack_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
 int pinkhip_stack_device(pinkhip_handle *h, const pinkhip_desc *desc,
                          const pinkhip_problem *dev_in, double *H_out, double *c_out);
 
+/* ---- upstream of the stack: batched FrameTask terms --------------------- */
+/* For B instances of one FrameTask: e = log6(T_frame^-1 T_target) (body twist, [linear; angular];
+ * pink/tasks/frame_task.py:176-193) and J = -Jlog6(T_target^-1 T_frame) J_body
+ * (frame_task.py:217-227), replacing pin.log / pin.Jlog6 + the 6x6 by 6xnv product per instance.
+ *   T_frame, T_target [B,12]  poses: rotation row-major (9) then translation (3)
+ *   J_body [B,6,nv]           Configuration.get_frame_jacobian (LOCAL frame)
+ *   e_out [B,6], J_out [B,6,nv]  directly usable as rows of pinkhip_problem.e / .J */
+int pinkhip_frame_task_host(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                            const double *T_target, const double *J_body, double *e_out,
+                            double *J_out);
+int pinkhip_frame_task_device(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                              const double *T_target, const double *J_body, double *e_out,
+                              double *J_out);
+
 /* ---- device memory, stream, timing ------------------------------------- */
 int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
 int pinkhip_free(pinkhip_handle *h, void *dptr);

@@ -153,6 +153,24 @@ class BatchSolver:
         self._check(self._lib.pinkhip_stack_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), H.ctypes.data, c.ctypes.data))
         return H, c
 
+    def frame_task_terms(self, T_frame: np.ndarray, T_target: np.ndarray, J_body: np.ndarray):
+        """Batched FrameTask error and Jacobian on the GPU (``frame_task.py:148-227``).
+
+        ``T_frame``, ``T_target``: ``[B, 12]`` poses (rotation row-major, then translation);
+        ``J_body``: ``[B, 6, nv]`` body Jacobians.  Returns ``(e [B, 6], J [B, 6, nv])``.
+        """
+        Tf = np.ascontiguousarray(T_frame, dtype=np.float64).reshape(-1, 12)
+        Tt = np.ascontiguousarray(T_target, dtype=np.float64).reshape(-1, 12)
+        Jb = np.ascontiguousarray(J_body, dtype=np.float64)
+        B, _, nv = Jb.shape
+        if Tf.shape[0] != B or Tt.shape[0] != B or Jb.shape[1] != 6:
+            raise ValueError("inconsistent frame-task shapes")
+        e = np.zeros((B, 6))
+        J = np.zeros((B, 6, nv))
+        self._check(self._lib.pinkhip_frame_task_host(self._h, B, nv, Tf.ctypes.data, Tt.ctypes.data, Jb.ctypes.data,
+                                                      e.ctypes.data, J.ctypes.data))
+        return e, J
+
     # -- HBM-resident path -----------------------------------------------------
     def upload(self, batch: IKBatch, max_iter: int = 0, out_ptrs=None) -> DeviceBatch:
         """Copy a batch to HBM.  ``out_ptrs = (dq, status, iters)`` device addresses

@@ -17,6 +17,7 @@
 #include "ik_kernels.h"
 #include "ik_kernels_packed.h"
 #include "ik_stack_mfma.h"
+#include "ik_frame_task.h"
 #include "host_tables.h"
 // clang-format on
 
@@ -418,6 +419,55 @@ int pinkhip_stack_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
   if ((rc = launch(h, a, false))) return rc;
   PH_HIP(h, hipMemcpyAsync(H_out, a.H_out, 8 * B * nv * nv, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipMemcpyAsync(c_out, a.c_out, 8 * B * nv, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_frame_task_device(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                              const double *T_target, const double *J_body, double *e_out,
+                              double *J_out) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (B < 0 || nv < 1 || nv > PINKHIP_MAX_NV) return fail(h, PINKHIP_E_INVALID, "bad B / nv");
+  if (B == 0) return PINKHIP_OK;
+  if (!T_frame || !T_target || !J_body || !e_out || !J_out) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  if (B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "B exceeds the grid limit");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::FrameTaskArgs a{B, nv, T_frame, T_target, J_body, e_out, J_out};
+  const dim3 block(pinkhip::kWave);
+  if (nv <= 8) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<8>, dim3((unsigned)((B + 7) / 8)), block, 0, h->stream, a);
+  } else if (nv <= 16) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<16>, dim3((unsigned)((B + 3) / 4)), block, 0, h->stream, a);
+  } else if (nv <= 32) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<32>, dim3((unsigned)((B + 1) / 2)), block, 0, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<64>, dim3((unsigned)B), block, 0, h->stream, a);
+  }
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_frame_task_host(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                            const double *T_target, const double *J_body, double *e_out,
+                            double *J_out) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (B < 0 || nv < 1 || nv > PINKHIP_MAX_NV) return fail(h, PINKHIP_E_INVALID, "bad B / nv");
+  if (B == 0) return PINKHIP_OK;
+  if (!T_frame || !T_target || !J_body || !e_out || !J_out) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  PH_HIP(h, hipSetDevice(h->device));
+  const size_t nT = align256(8 * (size_t)B * 12), nJ = align256(8 * (size_t)B * 6 * nv), nE = align256(8 * (size_t)B * 6);
+  int rc = ensure_arena(h, 2 * nT + 2 * nJ + nE);
+  if (rc) return rc;
+  char *p = h->arena;
+  double *dTf = reinterpret_cast<double *>(p), *dTt = reinterpret_cast<double *>(p + nT);
+  double *dJb = reinterpret_cast<double *>(p + 2 * nT), *dJo = reinterpret_cast<double *>(p + 2 * nT + nJ);
+  double *dE = reinterpret_cast<double *>(p + 2 * nT + 2 * nJ);
+  PH_HIP(h, hipMemcpyAsync(dTf, T_frame, 8 * (size_t)B * 12, hipMemcpyHostToDevice, h->stream));
+  PH_HIP(h, hipMemcpyAsync(dTt, T_target, 8 * (size_t)B * 12, hipMemcpyHostToDevice, h->stream));
+  PH_HIP(h, hipMemcpyAsync(dJb, J_body, 8 * (size_t)B * 6 * nv, hipMemcpyHostToDevice, h->stream));
+  if ((rc = pinkhip_frame_task_device(h, B, nv, dTf, dTt, dJb, dE, dJo))) return rc;
+  PH_HIP(h, hipMemcpyAsync(e_out, dE, 8 * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipMemcpyAsync(J_out, dJo, 8 * (size_t)B * 6 * nv, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
   return PINKHIP_OK;
 }

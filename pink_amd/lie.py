@@ -24,20 +24,27 @@ def exp3(w: np.ndarray) -> np.ndarray:
 
 
 def log3(R: np.ndarray) -> np.ndarray:
-    c = 0.5 * (np.trace(R) - 1.0)
-    c = min(1.0, max(-1.0, c))
-    th = float(np.arccos(c))
+    """Rotation vector of ``R``.  ``theta = atan2(|v|/2, (tr R - 1)/2)`` (well conditioned on the
+    whole range, unlike ``acos`` next to ``pi``); close to ``pi`` the axis comes from the symmetric
+    part ``c I + (1 - c) a a^T`` as Pinocchio does."""
     v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    c = 0.5 * (np.trace(R) - 1.0)
+    s = 0.5 * float(np.linalg.norm(v))
+    th = float(np.arctan2(s, c))
     if th < 1e-8:
         return 0.5 * v
-    if np.pi - th < 1e-6:  # near pi: recover the axis from the symmetric part
-        A = 0.5 * (R + np.eye(3))
-        k = int(np.argmax(np.diag(A)))
-        axis = A[:, k] / np.sqrt(max(A[k, k], 1e-300))
+    if np.pi - th < 1e-2:
+        k = int(np.argmax(np.diag(R)))
+        one_c = 1.0 - c
+        axis = np.zeros(3)
+        axis[k] = np.sqrt(max((R[k, k] - c) / one_c, 0.0))
+        for j in range(3):
+            if j != k:
+                axis[j] = (R[k, j] + R[j, k]) / (2.0 * one_c * axis[k])
         if axis @ v < 0:
             axis = -axis
         return th * axis
-    return (th / (2.0 * np.sin(th))) * v
+    return (th / (2.0 * s)) * v
 
 
 class SE3:

@@ -136,34 +136,61 @@ def solve_ik(configuration, tasks: Iterable, dt: float, solver: str = "mi355x", 
     return result.dq[0] / dt
 
 
+def _pose12(T) -> np.ndarray:
+    return np.hstack([np.asarray(T.rotation, dtype=float).ravel(), np.asarray(T.translation, dtype=float)])
+
+
 def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, damping: float = 1e-12, limits=None,
-                        barriers=None) -> IKBatch:
+                        barriers=None, solver_handle=None, gpu_frame_tasks: bool = True) -> IKBatch:
     """Evaluate the same task / limit / barrier objects at every configuration and
     pack the batch.  The task list may also be a list of per-instance lists (one
-    target per instance): ``tasks[b]`` is then used for ``configurations[b]``."""
+    target per instance): ``tasks[b]`` is then used for ``configurations[b]``.
+
+    FrameTasks are evaluated for the whole batch by the HIP frame-task kernel
+    (``log6`` / ``Jlog6`` / ``-Jlog6 J_body``, ``pink/tasks/frame_task.py:176-227``) when
+    ``gpu_frame_tasks`` is set: the host only gathers poses and body Jacobians.
+    """
+    from .tasks.frame_task import FrameTask
+
     B = len(configurations)
-    per_instance = B > 0 and len(tasks) == B and isinstance(tasks[0], (list, tuple))
-    cols = None
-    lbs, ubs, dense, bterms = [], [], [], []
     nv = configurations[0].model.nv if B else 0
-    for b, cfg in enumerate(configurations):
-        tl = tasks[b] if per_instance else tasks
-        _, tt, lb, ub, dr, bt, _ = _collect_terms(cfg, tl, dt, limits, barriers)
-        if cols is None:
-            cols = [[t] for t in tt]
-        else:
-            for c, t in zip(cols, tt):
-                c.append(t)
-        lbs.append(lb), ubs.append(ub), dense.append(dr), bterms.append(bt)
+    per_instance = B > 0 and len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    n_tasks = len(tasks[0]) if per_instance else len(tasks)
     merged = []
-    for c in cols or []:
-        t0 = c[0]
-        e = np.concatenate([t.e for t in c], axis=0)
-        if isinstance(t0, DiagonalTaskTerm):
-            merged.append(DiagonalTaskTerm(col0=t0.col0, e=e, cost=t0.cost, gain=t0.gain, lm_damping=t0.lm_damping))
+    for k in range(n_tasks):
+        tk = [tasks[b][k] for b in range(B)] if per_instance else [tasks[k]] * B
+        t0 = tk[0]
+        costs = [np.asarray(t.cost if t.cost is not None else 1.0, dtype=float) for t in tk]
+        same_cost = all(c.shape == costs[0].shape and np.array_equal(c, costs[0]) for c in costs)
+        if any(t.gain != t0.gain or t.lm_damping != t0.lm_damping for t in tk):
+            raise PinkError("gain / lm_damping of one task slot must be the same for every instance of a batch")
+        if gpu_frame_tasks and all(isinstance(t, FrameTask) for t in tk):
+            from .exceptions import TargetNotSet
+            from .runtime import default_solver
+
+            for t in tk:
+                if t.transform_target_to_world is None:
+                    raise TargetNotSet(f"no target set for frame '{t.frame}'")
+            Tf = np.array([_pose12(cfg.get_transform_frame_to_world(t.frame)) for cfg, t in zip(configurations, tk)])
+            Tt = np.array([_pose12(t.transform_target_to_world) for t in tk])
+            Jb = np.array([cfg.get_frame_jacobian(t.frame) for cfg, t in zip(configurations, tk)])
+            e, J = (solver_handle or default_solver()).frame_task_terms(Tf, Tt, Jb)
+            cost = costs[0] if same_cost else np.array([np.broadcast_to(c, (6,)) for c in costs])
+            merged.append(DenseTaskTerm(J=J, e=e, cost=cost, gain=t0.gain, lm_damping=t0.lm_damping))
+            continue
+        terms = [t.as_term(cfg) for cfg, t in zip(configurations, tk)]
+        e = np.concatenate([t.e for t in terms], axis=0)
+        kk = e.shape[1]
+        cost = t0.cost if same_cost else np.array([np.broadcast_to(c, (kk,)) for c in costs])
+        if isinstance(terms[0], DiagonalTaskTerm):
+            merged.append(DiagonalTaskTerm(col0=terms[0].col0, e=e, cost=cost, gain=t0.gain, lm_damping=t0.lm_damping))
         else:
-            merged.append(DenseTaskTerm(J=np.concatenate([t.J for t in c], axis=0), e=e, cost=t0.cost, gain=t0.gain,
+            merged.append(DenseTaskTerm(J=np.concatenate([t.J for t in terms], axis=0), e=e, cost=cost, gain=t0.gain,
                                         lm_damping=t0.lm_damping))
+    lbs, ubs, dense, bterms = [], [], [], []
+    for cfg in configurations:
+        _, _, lb, ub, dr, bt, _ = _collect_terms(cfg, [], dt, limits, barriers)
+        lbs.append(lb), ubs.append(ub), dense.append(dr), bterms.append(bt)
     dense_rows = []
     if B and dense[0]:
         for k in range(len(dense[0])):
@@ -192,7 +219,8 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
 
     for cfg in configurations:
         cfg.check_limits(safety_break=safety_break)
-    batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers)
+    batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, solver_handle,
+                                gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)))
     result = (solver_handle or default_solver()).solve(batch, max_iter=int(kwargs.get("max_iter", 0)))
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])

@@ -33,6 +33,7 @@ def emu(built):
     lib.pinkhip_emu_solve_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)]
     lib.pinkhip_emu_stack_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.c_void_p, ctypes.c_void_p]
     lib.pinkhip_emu_last_error.restype = ctypes.c_char_p
+    lib.pinkhip_emu_frame_task_host.argtypes = [ctypes.c_longlong, ctypes.c_int] + [ctypes.c_void_p] * 5
     return EmuSolver(lib)
 
 
@@ -57,6 +58,17 @@ class EmuSolver:
         if rc != 0:
             raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
         return BatchResult(dq, st, it)
+
+    def frame_task_terms(self, T_frame, T_target, J_body):
+        Tf = np.ascontiguousarray(T_frame, dtype=np.float64).reshape(-1, 12)
+        Tt = np.ascontiguousarray(T_target, dtype=np.float64).reshape(-1, 12)
+        Jb = np.ascontiguousarray(J_body, dtype=np.float64)
+        B, _, nv = Jb.shape
+        e = np.zeros((B, 6))
+        J = np.zeros((B, 6, nv))
+        self.lib.pinkhip_emu_frame_task_host.argtypes = [ctypes.c_longlong, ctypes.c_int] + [ctypes.c_void_p] * 5
+        self.lib.pinkhip_emu_frame_task_host(B, nv, Tf.ctypes.data, Tt.ctypes.data, Jb.ctypes.data, e.ctypes.data, J.ctypes.data)
+        return e, J
 
     def stack(self, batch):
         from pink_amd._lib import PackedArgs

@@ -6,6 +6,7 @@
 #include "../../pink_amd/csrc/ik_kernels.h"
 #include "../../pink_amd/csrc/ik_kernels_packed.h"
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
+#include "../../pink_amd/csrc/ik_frame_task.h"
 #include "../../pink_amd/csrc/host_tables.h"
 // clang-format on
 
@@ -129,7 +130,24 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
 
 }  // namespace
 
+template <int W>
+void lane_main_frame(void *p) {
+  pinkhip::ik_frame_task_instance<W>(*static_cast<const pinkhip::FrameTaskArgs *>(p), pinkhip::block_id());
+}
+
 extern "C" {
+int pinkhip_emu_frame_task_host(long long B, int nv, const double *T_frame, const double *T_target,
+                                const double *J_body, double *e_out, double *J_out) {
+  pinkhip::FrameTaskArgs a{B, nv, T_frame, T_target, J_body, e_out, J_out};
+  pinkhip::LaneFn fn;
+  int G;
+  if (nv <= 8) { fn = lane_main_frame<8>; G = 8; }
+  else if (nv <= 16) { fn = lane_main_frame<16>; G = 4; }
+  else if (nv <= 32) { fn = lane_main_frame<32>; G = 2; }
+  else { fn = lane_main_frame<64>; G = 1; }
+  for (long long b = 0; b < (B + G - 1) / G; ++b) pinkhip::emu_run_block(b, fn, &a);
+  return PINKHIP_OK;
+}
 int pinkhip_emu_solve_host(const pinkhip_desc *d, const pinkhip_problem *in,
                            const pinkhip_result *out) {
   return run(d, in, out, nullptr, nullptr, true);

@@ -174,7 +174,10 @@ def test_solve_ik_batch_equals_loop_and_reports_failures(backend):
     post.set_target(Q0)
     V = solve_ik_batch(cfgs, [task, post], 5e-3)
     for b, cfg in enumerate(cfgs):
-        assert np.array_equal(V[b], solve_ik(cfg, [task, post], 5e-3))
+        assert np.abs(V[b] - solve_ik(cfg, [task, post], 5e-3)).max() < 1e-9  # frame terms from the GPU kernel
+    Vh = solve_ik_batch(cfgs, [task, post], 5e-3, gpu_frame_tasks=False)
+    for b, cfg in enumerate(cfgs):
+        assert np.array_equal(Vh[b], solve_ik(cfg, [task, post], 5e-3))  # host-evaluated terms: bitwise
 
     class Crossed(pink_amd.limits.Limit):
         def compute_qp_inequalities(self, configuration, dt):
@@ -220,6 +223,55 @@ def test_equality_constraints_via_constraints_argument(backend):
     assert np.linalg.norm(v) > 1e-3  # the posture task still moves the arm in the null space
     v_free = solve_ik(cfg, [post], dt)
     assert np.linalg.norm(con.compute_jacobian(cfg) @ v_free) > 1e-3  # without the constraint the tool moves
+
+
+def test_frame_task_kernel_matches_host_lie_and_oracle(backend):
+    """pink/tasks/frame_task.py:176-227 evaluated for a batch by the HIP frame-task kernel."""
+    from oracle import se3_oracle
+    from pink_amd.lie import Jlog6, exp6
+    from pink_amd.runtime import default_solver
+    from pink_amd.solve_ik import _pose12
+
+    rng = np.random.default_rng(5)
+    for nv in (6, 13, 30, 50):
+        B = 9
+        frames = [exp6(rng.normal(size=6)) for _ in range(B)]
+        offs = [exp6(rng.normal(size=6) * [0.1, 0.1, 0.1, 0.6, 0.6, 0.6]) for _ in range(B)]
+        offs[0] = SE3()  # zero error
+        offs[1] = exp6(np.array([0.0, 0.0, 0.0, 0.0, 0.0, 3.14159]))  # rotation close to pi
+        targets = [f * o for f, o in zip(frames, offs)]
+        Jb = rng.normal(size=(B, 6, nv))
+        Tf = np.array([_pose12(f) for f in frames])
+        Tt = np.array([_pose12(t) for t in targets])
+        e, J = default_solver().frame_task_terms(Tf, Tt, Jb)
+        for b in range(B):  # host closed forms (pink_amd.lie, what FrameTask uses per instance)
+            assert np.abs(e[b] - log6(frames[b].actInv(targets[b]))).max() < 1e-12
+            assert np.abs(J[b] + Jlog6(targets[b].actInv(frames[b])) @ Jb[b]).max() < 1e-11
+        eo, Jo = se3_oracle.frame_task_terms(Tf[2:], Tt[2:], Jb[2:])  # independent: logm + finite differences
+        assert np.abs(e[2:] - eo).max() < 1e-12 and np.abs(J[2:] - Jo).max() < 1e-7
+        assert np.array_equal(J[0], -Jb[0]) and not e[0].any()  # tests/test_frame_task.py:112-121
+
+
+def test_batched_frame_tasks_on_gpu_equal_host_evaluation(backend):
+    m = build_chain(6)
+    rng = np.random.default_rng(7)
+    cfgs = [Configuration(m, Q0 + 0.3 * rng.normal(size=6)) for _ in range(6)]
+    task = FrameTask("tool0", [1.0, 2.0, 3.0], 0.5, lm_damping=0.2)
+    post = PostureTask(cost=1e-2)
+    task.set_target(cfgs[0].get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.05, 0.1, 0.0]))
+    post.set_target(Q0)
+    Vg = solve_ik_batch(cfgs, [task, post], 5e-3, gpu_frame_tasks=True)
+    Vh = solve_ik_batch(cfgs, [task, post], 5e-3, gpu_frame_tasks=False)
+    assert np.abs(Vg - Vh).max() < 1e-9
+    # per-instance targets: one task list per configuration
+    per = []
+    for cfg in cfgs:
+        t = FrameTask("tool0", 1.0, 1.0)
+        t.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), 0.05 * rng.normal(size=3)))
+        per.append([t, post])
+    Vp = solve_ik_batch(cfgs, per, 5e-3)
+    for b, cfg in enumerate(cfgs):
+        assert np.abs(Vp[b] - solve_ik(cfg, per[b], 5e-3)).max() < 1e-9
 
 
 def test_urdf_reader_on_reference_robots():
