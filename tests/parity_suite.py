@@ -233,3 +233,58 @@ def equality_edge_cases(solver):
     assert (ok.status == 0).all() and np.abs(ok.dq[:, 0] + ok.dq[:, 1] - 0.2).max() < 1e-13
     bad = solver.solve(pack_terms(nv, t, 0.01, 1e-12, boxes=box, equality_rows=[(A, np.tile([0.2, 0.5], (B, 1)))], batch_size=B))
     assert (bad.status == 2).all()
+
+
+def fuzz(solver, seeds):
+    """Random mixes of box bounds (some missing, some with lb == ub), dense inequality rows (some
+    duplicated), equalities, LM damping and dimensions; infeasible draws must be reported as such
+    by both sides."""
+    n_checked = 0
+    for sd in seeds:
+        rng = np.random.default_rng(sd)
+        nv = int(rng.integers(1, 34))
+        B = int(rng.integers(1, 7))
+        neq = int(rng.integers(0, min(3, nv) + 1)) if rng.random() < 0.4 else 0
+        mdi = int(rng.integers(0, 5)) if rng.random() < 0.5 else 0
+        k = int(rng.integers(1, 7))
+        J = rng.normal(0, 0.5, size=(B, k, nv))
+        e = 0.1 * rng.normal(size=(B, k))
+        ep = rng.uniform(-0.5, 0.5, size=(B, nv))
+        tight = 10 ** rng.uniform(-3, -1)
+        lb = -rng.uniform(0.2 * tight, tight, size=(B, nv))
+        ub = rng.uniform(0.2 * tight, tight, size=(B, nv))
+        m = rng.random(size=(B, nv))
+        lb[m < 0.1] = -np.inf
+        ub[(m > 0.1) & (m < 0.2)] = np.inf
+        pinned = rng.random(size=(B, nv)) < 0.05
+        lb[pinned] = ub[pinned] = 0.0
+        A = rng.normal(size=(B, neq, nv))
+        bv = 0.01 * rng.normal(size=(B, neq))
+        Gi = rng.normal(size=(B, mdi, nv))
+        hi = rng.uniform(-0.01, 0.05, size=(B, mdi))
+        if mdi >= 2 and rng.random() < 0.3:
+            Gi[:, 1], hi[:, 1] = Gi[:, 0], hi[:, 0] + 0.01
+        lm = float(rng.choice([0.0, 0.5]))
+        cost = rng.uniform(0.5, 2, size=k)
+        batch = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=cost, lm_damping=lm), DiagonalTaskTerm(col0=0, e=ep, cost=0.1)],
+                           0.005, 1e-12, boxes=[(lb, ub)], dense_rows=[(Gi, hi)] if mdi else (),
+                           equality_rows=[(A, bv)] if neq else (), batch_size=B)
+        out = solver.solve(batch)
+        eye = np.eye(nv)
+        hb = np.concatenate([ub, -lb], axis=1)
+        hb = np.where(np.isfinite(hb), hb, 1e30)
+        G = np.concatenate([A, np.broadcast_to(eye, (B, nv, nv)), np.broadcast_to(-eye, (B, nv, nv)), Gi], axis=1)
+        h = np.concatenate([bv, hb, hi], axis=1)
+        ref = c_oracle.solve_ik_batch(np.concatenate([J, np.broadcast_to(eye, (B, nv, nv))], axis=1),
+                                      np.concatenate([e, ep], axis=1), np.concatenate([cost, np.full(nv, 0.1)]),
+                                      np.ones(2), np.array([lm, 0.0]), np.array([0, k, k + nv], np.int32), 1e-12, G, h,
+                                      meq=neq, want_Hc=True)
+        assert np.array_equal(out.status, ref["status"]), (sd, out.status, ref["status"])
+        ok = ref["status"] == 0
+        if ok.any():
+            cond = np.linalg.cond(ref["H"][ok])
+            xmax = np.abs(ref["dq"][ok]).max(axis=1)
+            err = np.abs(out.dq[ok] - ref["dq"][ok]).max(axis=1)
+            assert (err <= np.maximum(TOL_DQ, 100 * np.finfo(float).eps * cond * xmax)).all(), (sd, err.max())
+            n_checked += int(ok.sum())
+    return n_checked

@@ -85,3 +85,7 @@ def test_equality_constraints(emu, nv, n_eq, md):
 
 def test_equality_edge_cases(emu):
     ps.equality_edge_cases(emu)
+
+
+def test_fuzz(emu):
+    assert ps.fuzz(emu, range(5000, 5060)) > 100

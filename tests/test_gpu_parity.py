@@ -63,6 +63,10 @@ def test_equality_constraints(gpu_solver, nv, n_eq, md):
     ps.equality_edge_cases(gpu_solver)
 
 
+def test_fuzz(gpu_solver):
+    assert ps.fuzz(gpu_solver, range(7000, 7400)) > 1000
+
+
 def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
     """Vectorised KKT check for box (+ dense) QPs; returns (stationarity, violation)."""
     g = np.einsum("bij,bj->bi", H, dq) + c
