@@ -206,12 +206,6 @@ void set_problem(KernelArgs &a, const pinkhip_problem *in) {
   a.c_extra = in->c_extra;
 }
 
-struct ArenaPlan {
-  size_t off[8];
-  size_t bytes[8];
-  size_t out_dq, out_status, out_iters, out_H, out_c, total;
-};
-
 size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 int ensure_arena(pinkhip_handle *h, size_t bytes) {

@@ -41,6 +41,16 @@ for name, B in (("draco3", 65536), ("ur5", 65536), ("jvrc", 32768)):
         print(f"TIMING {name} {bounds} B={B}: solve {ms:.3f} ms -> {B/ms*1e3/1e6:.2f} M solves/s; iters mean {r.iters.mean():.1f}; "
               f"stack {ms_stack:.3f} ms -> {B*pk.bytes_per_stack()/ms_stack/1e6:.1f} GB/s; bytes/qp {pk.bytes_per_qp()}")
         out[f"time_{name}_{bounds}"] = dict(ms=ms, msolves=B / ms * 1e3 / 1e6, ms_stack=ms_stack)
+        if name == "draco3" and bounds == "tight":
+            # PCIe-inclusive: host buffers in, host buffers out (pinkhip_solve_host)
+            s.solve(pk)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                s.solve(pk)
+            host_ms = (time.perf_counter() - t0) / 3 * 1e3
+            print(f"HOST-PATH {name} B={B}: {host_ms:.2f} ms per call incl. H2D/D2H -> {B/host_ms*1e3/1e6:.2f} M solves/s "
+                  f"({dev.nbytes/1e6:.0f} MB in)")
+            out["host_path_ms"] = host_ms
         dev.free()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gpu_check.json"), "w"), indent=1)
