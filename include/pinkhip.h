@@ -172,6 +172,22 @@ int pinkhip_frame_task_device(pinkhip_handle *h, int64_t B, int32_t nv, const do
                               const double *T_target, const double *J_body, double *e_out,
                               double *J_out);
 
+/* ---- multi-GPU: gather of dq over RCCL / xGMI --------------------------- */
+/* Instances are independent, so a batch is sharded over one handle per GPU (one process per
+ * GPU) and solved without any exchange; the only collective of the workload is the gather of
+ * the dq shards to one rank.  RCCL is loaded lazily (dlopen), the library works without it.
+ *   pinkhip_comm_get_unique_id  rank 0 creates the 128-byte id; the caller ships it to every rank
+ *                               (environment, file, any bootstrap channel)
+ *   pinkhip_comm_init           every rank joins (collective call)
+ *   pinkhip_comm_gather         count doubles from every rank's d_send to root's d_recv
+ *                               [nranks * count] (device pointers; d_recv ignored off root);
+ *                               enqueued on the handle's stream */
+#define PINKHIP_COMM_ID_BYTES 128
+int pinkhip_comm_get_unique_id(char *id /* [PINKHIP_COMM_ID_BYTES] */);
+int pinkhip_comm_init(pinkhip_handle *h, const char *id, int rank, int nranks);
+int pinkhip_comm_gather(pinkhip_handle *h, const double *d_send, double *d_recv, int64_t count, int root);
+int pinkhip_comm_destroy(pinkhip_handle *h);
+
 /* ---- device memory, stream, timing ------------------------------------- */
 int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
 int pinkhip_free(pinkhip_handle *h, void *dptr);

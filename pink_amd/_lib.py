@@ -88,6 +88,7 @@ ABI_SYMBOLS = (
     "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
     "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
+    "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_destroy",
     "pinkhip_malloc", "pinkhip_free",
     "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_sync", "pinkhip_timer_start",
     "pinkhip_timer_stop",
@@ -121,6 +122,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), vp, vp]
     for name in ("pinkhip_frame_task_host", "pinkhip_frame_task_device"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, vp]
+    lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]
+    lib.pinkhip_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    lib.pinkhip_comm_gather.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int]
+    lib.pinkhip_comm_destroy.argtypes = [vp]
     lib.pinkhip_malloc.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_int64]
     lib.pinkhip_free.argtypes = [vp, vp]
     lib.pinkhip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_int64]

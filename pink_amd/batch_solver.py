@@ -208,6 +208,24 @@ class BatchSolver:
             self._d2h(c, dev.d_c)
         return H, c
 
+    # -- RCCL gather of dq (one handle per GPU / process) ----------------------------
+    def comm_unique_id(self) -> bytes:
+        """128-byte RCCL id, created on one rank and shipped to the others by the caller."""
+        buf = ctypes.create_string_buffer(128)
+        self._check(self._lib.pinkhip_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int) -> None:
+        self._check(self._lib.pinkhip_comm_init(self._h, unique_id, int(rank), int(nranks)))
+
+    def comm_gather(self, d_send: int, d_recv: Optional[int], count: int, root: int = 0) -> None:
+        """``count`` doubles from every rank's device buffer to ``root``'s ``[nranks * count]``."""
+        self._check(self._lib.pinkhip_comm_gather(self._h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv or 0),
+                                                  int(count), int(root)))
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.pinkhip_comm_destroy(self._h))
+
     def sync(self) -> None:
         self._check(self._lib.pinkhip_sync(self._h))
 

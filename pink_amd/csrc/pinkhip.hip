@@ -4,6 +4,7 @@
 // table area for the per-descriptor broadcast constants, and a grow-only device
 // arena used by the *_host entry points.  No exceptions cross the ABI.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,8 @@ struct pinkhip_handle {
   size_t arena_bytes = 0;
   hipDeviceProp_t prop;
   bool packed = true;                // PINKHIP_KERNEL=wave forces one QP per wavefront
+  void *comm = nullptr;              // ncclComm_t once pinkhip_comm_init succeeded
+  int comm_rank = 0, comm_size = 0;
 };
 
 namespace {
@@ -59,6 +62,11 @@ int fail(pinkhip_handle *h, int code, const std::string &msg) {
   } while (0)
 
 using pinkhip::KernelArgs;
+
+// ncclUniqueId is passed by value to ncclCommInitRank: same layout, no RCCL header needed
+struct pinkhip_unique_id_t {
+  char internal[PINKHIP_COMM_ID_BYTES];
+};
 
 template <int NV>
 int launch_nv(pinkhip_handle *h, const KernelArgs &a, bool solve) {
@@ -312,6 +320,7 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (!h) return PINKHIP_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) pinkhip_comm_destroy(h);
   if (h->arena) (void)hipFree(h->arena);
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -463,6 +472,91 @@ int pinkhip_frame_task_host(pinkhip_handle *h, int64_t B, int32_t nv, const doub
   PH_HIP(h, hipMemcpyAsync(e_out, dE, 8 * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipMemcpyAsync(J_out, dJo, 8 * (size_t)B * 6 * nv, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+// ---- RCCL, loaded on demand so that single-GPU users never need it ------------------------
+namespace {
+struct Rccl {
+  void *so = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, pinkhip_unique_id_t, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*Gather)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl &rccl() {
+  static Rccl r;
+  return r;
+}
+int rccl_load(pinkhip_handle *h) {
+  Rccl &r = rccl();
+  if (r.so) return PINKHIP_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names)
+    if ((r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!r.so) return fail(h, PINKHIP_E_COMM, std::string("cannot load librccl: ") + dlerror());
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
+  r.Gather = reinterpret_cast<decltype(r.Gather)>(dlsym(r.so, "ncclGather"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather || !r.GetErrorString) {
+    r.so = nullptr;
+    return fail(h, PINKHIP_E_COMM, "librccl lacks ncclGather / ncclCommInitRank");
+  }
+  return PINKHIP_OK;
+}
+int rccl_fail(pinkhip_handle *h, const char *what, int rc) {
+  return fail(h, PINKHIP_E_COMM, std::string(what) + ": " + rccl().GetErrorString(rc));
+}
+}  // namespace
+
+int pinkhip_comm_get_unique_id(char *id) {
+  if (!id) return fail(nullptr, PINKHIP_E_INVALID, "null id");
+  int rc = rccl_load(nullptr);
+  if (rc) return rc;
+  pinkhip_unique_id_t uid;
+  if ((rc = rccl().GetUniqueId(&uid))) return rccl_fail(nullptr, "ncclGetUniqueId", rc);
+  std::memcpy(id, uid.internal, PINKHIP_COMM_ID_BYTES);
+  return PINKHIP_OK;
+}
+
+int pinkhip_comm_init(pinkhip_handle *h, const char *id, int rank, int nranks) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (h->comm) return fail(h, PINKHIP_E_INVALID, "communicator already initialised");
+  int rc = rccl_load(h);
+  if (rc) return rc;
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip_unique_id_t uid;
+  std::memcpy(uid.internal, id, PINKHIP_COMM_ID_BYTES);
+  if ((rc = rccl().CommInitRank(&h->comm, nranks, uid, rank))) {
+    h->comm = nullptr;
+    return rccl_fail(h, "ncclCommInitRank", rc);
+  }
+  h->comm_rank = rank;
+  h->comm_size = nranks;
+  return PINKHIP_OK;
+}
+
+int pinkhip_comm_gather(pinkhip_handle *h, const double *d_send, double *d_recv, int64_t count, int root) {
+  if (!h || !h->comm) return fail(h, PINKHIP_E_INVALID, "communicator not initialised");
+  if (count < 0 || root < 0 || root >= h->comm_size || !d_send || (h->comm_rank == root && !d_recv))
+    return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (count == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  const int rc = rccl().Gather(d_send, d_recv, static_cast<size_t>(count), 8 /* ncclDouble */, root, h->comm, h->stream);
+  if (rc) return rccl_fail(h, "ncclGather", rc);
+  return PINKHIP_OK;
+}
+
+int pinkhip_comm_destroy(pinkhip_handle *h) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (h->comm) {
+    (void)hipStreamSynchronize(h->stream);
+    rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
   return PINKHIP_OK;
 }
 

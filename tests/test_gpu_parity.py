@@ -131,6 +131,33 @@ def test_full_size_properties(gpu_solver, name, B):
     assert np.array_equal(out3.dq, out.dq[perm])
 
 
+def test_rccl_gather_single_rank(gpu_solver):
+    """pinkhip_comm_*: the dq gather over RCCL, exercised with a one-rank communicator (the
+    only size a 1-GPU box allows); multi-rank use follows the same calls with the id shipped
+    to every process."""
+    s = gpu_solver
+    batch, _ = config_case("ur5", "tight", "dense", 256)
+    dev = s.upload(batch)
+    s.solve_device(dev)
+    s.sync()
+    out = s.download(dev)
+    uid = s.comm_unique_id()
+    assert len(uid) == 128
+    s.comm_init(uid, 0, 1)
+    try:
+        n = 256 * 6
+        recv = s._malloc(8 * n)
+        s.comm_gather(dev.d_dq, recv, n, root=0)
+        s.sync()
+        got = np.zeros((256, 6))
+        s._d2h(got, recv)
+        assert np.array_equal(got, out.dq)
+        s._free(recv)
+    finally:
+        s.comm_destroy()
+        dev.free()
+
+
 def test_api_errors(gpu_solver):
     from pink_amd._lib import PinkHipError
 
