@@ -172,6 +172,55 @@ int pinkhip_frame_task_device(pinkhip_handle *h, int64_t B, int32_t nv, const do
                               const double *T_target, const double *J_body, double *e_out,
                               double *J_out);
 
+/* Same with explicit strides (in doubles) between consecutive instances, so that one frame of a
+ * [B, nf, ...] array can be read and the result written straight into the rows of the packed
+ * e [B, K] / J [B, Kd, nv] streams of pinkhip_problem. */
+int pinkhip_frame_task_strided_device(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                                      int64_t sT_frame, const double *T_target, int64_t sT_target,
+                                      const double *J_body, int64_t sJ_body, double *e_out, int64_t sE,
+                                      double *J_out, int64_t sJ_out);
+
+/* ---- closed loop on the device: kinematics around the IK step ---------- */
+/* A kinematic tree of revolute / prismatic joints with an optional free-flyer root (joints in
+ * topological order; free-flyer: q = [p, quat xyzw], tangent = body twist).  Replaces, for B
+ * instances and without host round trips, what Pink asks Pinocchio for in its control loop:
+ *   pinkhip_fk_device              pink/configuration.py:131-164,203-254  (FK, body frame Jacobians)
+ *   pinkhip_limits_posture_device  limits/configuration_limit.py:111-120 + velocity_limit.py:118-120
+ *                                  merged into lb/ub, and PostureTask's q (-) q* (posture_task.py:100-107)
+ *   pinkhip_integrate_device       pink/configuration.py:273-293 (q <- q (+) dq)            */
+#define PINKHIP_JOINT_REVOLUTE 0
+#define PINKHIP_JOINT_PRISMATIC 1
+#define PINKHIP_JOINT_FREE_FLYER 2
+typedef struct pinkhip_model pinkhip_model;
+typedef struct pinkhip_model_desc {
+  int32_t nj, nq, nv, nf, root_nv;
+  const int32_t *parent;       /* [nj] parent joint, -1 = world                      */
+  const int32_t *jtype;        /* [nj] PINKHIP_JOINT_*                               */
+  const int32_t *idx_q;        /* [nj]                                               */
+  const int32_t *idx_v;        /* [nj]                                               */
+  const double *placement;     /* [nj,12] joint frame in its parent joint frame      */
+  const double *axis;          /* [nj,3]                                             */
+  const int32_t *frame_joint;  /* [nf] joint a frame is attached to, -1 = world      */
+  const double *frame_placement; /* [nf,12]                                          */
+  const double *q_min;         /* [nq] model.lowerPositionLimit                      */
+  const double *q_max;         /* [nq] model.upperPositionLimit                      */
+  const double *v_max;         /* [nv] model.velocityLimit                           */
+} pinkhip_model_desc;
+int pinkhip_model_create(pinkhip_handle *h, const pinkhip_model_desc *desc, pinkhip_model **model);
+int pinkhip_model_destroy(pinkhip_handle *h, pinkhip_model *model);
+/* q [B,nq] -> T_frames [B,nf,12], J_body [B,nf,6,nv] (device pointers) */
+int pinkhip_fk_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const double *q,
+                      double *T_frames, double *J_body);
+/* q [B,nq], q_target [nq] or [B,nq] -> lb, ub [B,nv]; posture error written into e [B,K] at columns
+ * e_off .. e_off + nv - root_nv (e may be NULL) */
+int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double dt,
+                                  double config_limit_gain, const double *q, const double *q_target,
+                                  int32_t target_batched, double *lb, double *ub, double *e, int32_t K,
+                                  int32_t e_off);
+/* q [B,nq] <- q (+) dq [B,nv], in place */
+int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double *q,
+                             const double *dq);
+
 /* ---- multi-GPU: gather of dq over RCCL / xGMI --------------------------- */
 /* Instances are independent, so a batch is sharded over one handle per GPU (one process per
  * GPU) and solved without any exchange; the only collective of the workload is the gather of

@@ -88,6 +88,8 @@ ABI_SYMBOLS = (
     "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
     "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
+    "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
+    "pinkhip_limits_posture_device", "pinkhip_integrate_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_destroy",
     "pinkhip_malloc", "pinkhip_free",
     "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_sync", "pinkhip_timer_start",
@@ -122,6 +124,13 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), vp, vp]
     for name in ("pinkhip_frame_task_host", "pinkhip_frame_task_device"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, vp]
+    i64, i32, f64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+    lib.pinkhip_frame_task_strided_device.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64]
+    lib.pinkhip_model_create.argtypes = [vp, vp, ctypes.POINTER(vp)]
+    lib.pinkhip_model_destroy.argtypes = [vp, vp]
+    lib.pinkhip_fk_device.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
+    lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.pinkhip_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.pinkhip_comm_gather.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int]

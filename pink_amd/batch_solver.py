@@ -208,6 +208,44 @@ class BatchSolver:
             self._d2h(c, dev.d_c)
         return H, c
 
+    # -- raw device-pointer interface used by pink_amd.rollout.DeviceRollout ------------
+    def alloc(self, nbytes: int) -> int:
+        return self._malloc(max(int(nbytes), 8))
+
+    def release(self, ptr: int) -> None:
+        if ptr:
+            self._free(ptr)
+
+    def put(self, ptr: int, arr: np.ndarray) -> None:
+        self._h2d(ptr, np.ascontiguousarray(arr))
+
+    def get(self, arr: np.ndarray, ptr: int) -> None:
+        self._d2h(arr, ptr)
+
+    def model_create(self, desc) -> int:
+        m = ctypes.c_void_p()
+        self._check(self._lib.pinkhip_model_create(self._h, ctypes.byref(desc), ctypes.byref(m)))
+        return m.value
+
+    def model_destroy(self, model: int) -> None:
+        self._check(self._lib.pinkhip_model_destroy(self._h, ctypes.c_void_p(model)))
+
+    def fk(self, model: int, B: int, q: int, T_frames: int, J_body: int) -> None:
+        self._check(self._lib.pinkhip_fk_device(self._h, ctypes.c_void_p(model), B, q, T_frames, J_body))
+
+    def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ) -> None:
+        self._check(self._lib.pinkhip_frame_task_strided_device(self._h, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ))
+
+    def limits_posture(self, model, B, dt, gain, q, q_target, batched, lb, ub, e, K, e_off) -> None:
+        self._check(self._lib.pinkhip_limits_posture_device(self._h, ctypes.c_void_p(model), B, dt, gain, q, q_target,
+                                                            batched, lb, ub, e, K, e_off))
+
+    def integrate(self, model, B, q, dq) -> None:
+        self._check(self._lib.pinkhip_integrate_device(self._h, ctypes.c_void_p(model), B, q, dq))
+
+    def solve_raw(self, desc, problem, result) -> None:
+        self._check(self._lib.pinkhip_solve_device(self._h, ctypes.byref(desc), ctypes.byref(problem), ctypes.byref(result)))
+
     # -- RCCL gather of dq (one handle per GPU / process) ----------------------------
     def comm_unique_id(self) -> bytes:
         """128-byte RCCL id, created on one rank and shipped to the others by the caller."""

@@ -25,6 +25,10 @@ struct FrameTaskArgs {
   const double *J_body;    // [B, 6, nv]
   double *e_out;           // [B, 6]
   double *J_out;           // [B, 6, nv]
+  // strides between consecutive instances, in doubles (0 = densely packed as documented above);
+  // lets the kernel read one frame out of [B, nf, ...] arrays and write straight into the rows
+  // of the packed e [B, K] / J [B, Kd, nv] streams of the solve kernel
+  long long sTf = 0, sTt = 0, sJb = 0, sE = 0, sJo = 0;
 };
 
 // A^T B for rotations stored row-major, and A^T (pb - pa)
@@ -153,11 +157,13 @@ __device__ inline void ik_frame_task_instance(const FrameTaskArgs &a, long long 
   const long long b = block * G + g;
   if (b >= a.B) return;  // no cross-lane primitive below: early exit is safe
   const int nv = a.nv;
+  const long long sTf = a.sTf ? a.sTf : 12, sTt = a.sTt ? a.sTt : 12, sJb = a.sJb ? a.sJb : 6LL * nv;
+  const long long sE = a.sE ? a.sE : 6, sJo = a.sJo ? a.sJo : 6LL * nv;
   double Tf[12], Tt[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    Tf[i] = a.T_frame[b * 12 + i];
-    Tt[i] = a.T_target[b * 12 + i];
+    Tf[i] = a.T_frame[b * sTf + i];
+    Tt[i] = a.T_target[b * sTt + i];
   }
   double R[9], p[3];
   if (li == 0) {  // e = log6(T_frame^-1 T_target), frame_task.py:181-193
@@ -165,14 +171,14 @@ __device__ inline void ik_frame_task_instance(const FrameTaskArgs &a, long long 
     se3_act_inv(Tf, Tt, R, p);
     log6(R, p, xi);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a.e_out[b * 6 + i] = xi[i];
+    for (int i = 0; i < 6; ++i) a.e_out[b * sE + i] = xi[i];
   }
   // J = -Jlog6(T_target^-1 T_frame) J_body, frame_task.py:222-227; lane = column
   se3_act_inv(Tt, Tf, R, p);
   double Jl[36];
   jlog6(R, p, Jl);
-  const double *Jb = a.J_body + b * 6LL * nv;
-  double *Jo = a.J_out + b * 6LL * nv;
+  const double *Jb = a.J_body + b * sJb;
+  double *Jo = a.J_out + b * sJo;
   for (int j = li; j < nv; j += W) {
     double col[6];
 #pragma unroll

@@ -1,0 +1,319 @@
+// Device-side kinematics around the IK step, so that a whole "differential IK iterated to
+// convergence" rollout (reference examples/inverse_kinematics_ur10.py:75-91, the loop of
+// tests/test_solve_ik.py:160-210) runs without host round trips:
+//
+//   ik_fk_kernel            q -> frame poses and body (LOCAL) frame Jacobians
+//                           (pink/configuration.py:131-164, 203-254: computeJointJacobians,
+//                            updateFramePlacements, getFrameJacobian)
+//   ik_limits_posture_kernel  q -> merged box of ConfigurationLimit + VelocityLimit
+//                           (configuration_limit.py:111-120, velocity_limit.py:118-120) and the
+//                           PostureTask error q (-) q* (posture_task.py:100-107)
+//   ik_integrate_kernel     q <- q (+) dq   (pink/configuration.py:273-293: pin.integrate)
+//
+// Models are kinematic trees of revolute / prismatic joints with an optional free-flyer root
+// (q = [p, quat xyzw], tangent = body twist), joints in topological order.  Conventions as in
+// twists are [linear; angular], Jacobians are body Jacobians.
+#pragma once
+
+#include "ik_frame_task.h"
+
+namespace pinkhip {
+
+constexpr int JOINT_REVOLUTE = 0;
+constexpr int JOINT_PRISMATIC = 1;
+constexpr int JOINT_FREE_FLYER = 2;
+
+// Model tables, all in device memory (built by pinkhip_model_create).
+struct ModelDev {
+  int nj, nq, nv, nf, root_nv;
+  const int *parent;        // [nj]  -1 = world
+  const int *jtype;         // [nj]
+  const int *idx_q;         // [nj]
+  const int *idx_v;         // [nj]
+  const double *placement;  // [nj, 12]  joint frame in the parent joint frame at q = 0
+  const double *axis;       // [nj, 3]
+  const int *frame_joint;   // [nf]  -1 = world
+  const double *frame_placement;  // [nf, 12]
+  const int *dof_joint;     // [nv]  joint owning tangent column j
+  const int *dof_sub;       // [nv]  index inside that joint's tangent (0..5 for the free-flyer)
+  const unsigned char *anc; // [nf, nj]  joint is the frame's joint or one of its ancestors
+  const double *q_min, *q_max;  // [nq]
+  const double *v_max;          // [nv]
+};
+
+// C = A * B for 12-double poses (rotation row-major, translation)
+__device__ inline void se3_mul(const double *A, const double *Bm, double *C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * Bm[j] + A[3 * i + 1] * Bm[3 + j] + A[3 * i + 2] * Bm[6 + j];
+    C[9 + i] = A[3 * i] * Bm[9] + A[3 * i + 1] * Bm[10] + A[3 * i + 2] * Bm[11] + A[9 + i];
+  }
+}
+
+// rotation about unit axis u by angle t (Rodrigues), row-major
+__device__ inline void rot_axis(const double *u, double t, double *R) {
+  const double s = sin(t), c = cos(t), v = 1.0 - c;
+  R[0] = c + v * u[0] * u[0];
+  R[1] = v * u[0] * u[1] - s * u[2];
+  R[2] = v * u[0] * u[2] + s * u[1];
+  R[3] = v * u[1] * u[0] + s * u[2];
+  R[4] = c + v * u[1] * u[1];
+  R[5] = v * u[1] * u[2] - s * u[0];
+  R[6] = v * u[2] * u[0] - s * u[1];
+  R[7] = v * u[2] * u[1] + s * u[0];
+  R[8] = c + v * u[2] * u[2];
+}
+
+__device__ inline void quat_to_rot(const double *qv, double *R) {  // (x, y, z, w)
+  const double n = 1.0 / sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]);
+  const double x = qv[0] * n, y = qv[1] * n, z = qv[2] * n, w = qv[3] * n;
+  R[0] = 1 - 2 * (y * y + z * z);
+  R[1] = 2 * (x * y - z * w);
+  R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);
+  R[4] = 1 - 2 * (x * x + z * z);
+  R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);
+  R[7] = 2 * (y * z + x * w);
+  R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// local transform of joint a at configuration q
+__device__ inline void joint_transform(const ModelDev &m, int a, const double *q, double *T) {
+  const int t = m.jtype[a], iq = m.idx_q[a];
+  if (t == JOINT_REVOLUTE) {
+    rot_axis(m.axis + 3 * a, q[iq], T);
+    T[9] = T[10] = T[11] = 0.0;
+  } else if (t == JOINT_PRISMATIC) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    T[9] = m.axis[3 * a] * q[iq];
+    T[10] = m.axis[3 * a + 1] * q[iq];
+    T[11] = m.axis[3 * a + 2] * q[iq];
+  } else {
+    quat_to_rot(q + iq + 3, T);
+    T[9] = q[iq];
+    T[10] = q[iq + 1];
+    T[11] = q[iq + 2];
+  }
+}
+
+struct FkArgs {
+  ModelDev m;
+  long long B;
+  const double *q;   // [B, nq]
+  double *T_frames;  // [B, nf, 12]
+  double *J_body;    // [B, nf, 6, nv]
+};
+
+// LDS per instance: oM [nj, 12] + inverse frame poses [nf, 12]
+__device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj + nf); }
+
+template <int W>
+__device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
+  constexpr int G = kWave / W;
+  const ModelDev &m = a.m;
+  const int lane = lane_id();
+  const int g = lane / W, li = lane & (W - 1);
+  long long b = block * G + g;
+  const bool valid = b < a.B;
+  if (!valid) b = a.B - 1;
+  double *oM = shared_base() + (long long)g * fk_lds_doubles(m.nj, m.nf);
+  double *fMo = oM + 12 * m.nj;  // frame-from-world transforms
+  const double *q = a.q + b * (long long)m.nq;
+
+  // forward kinematics along the tree (sequential, one lane; 60 flops per joint)
+  if (li == 0) {
+    for (int j = 0; j < m.nj; ++j) {
+      double X[12], Tj[12], P[12];
+      joint_transform(m, j, q, Tj);
+      se3_mul(m.placement + 12 * j, Tj, X);
+      if (m.parent[j] >= 0) {
+        se3_mul(oM + 12 * m.parent[j], X, P);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) oM[12 * j + i] = P[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) oM[12 * j + i] = X[i];
+      }
+    }
+  }
+  wave_sync();
+  for (int f = li; f < m.nf; f += W) {
+    double F[12];
+    const int fj = m.frame_joint[f];
+    if (fj >= 0) {
+      se3_mul(oM + 12 * fj, m.frame_placement + 12 * f, F);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) F[i] = m.frame_placement[12 * f + i];
+    }
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.T_frames[(b * m.nf + f) * 12 + i] = F[i];
+    }
+    // inverse: (R^T, -R^T p)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fMo[12 * f + 3 * i + j] = F[3 * j + i];
+      fMo[12 * f + 9 + i] = -(F[i] * F[9] + F[3 + i] * F[10] + F[6 + i] * F[11]);
+    }
+  }
+  wave_sync();
+  // body Jacobians: lane = tangent column
+  for (int j = li; j < m.nv; j += W) {
+    const int jt = m.dof_joint[j], sub = m.dof_sub[j], ty = m.jtype[jt];
+    for (int f = 0; f < m.nf; ++f) {
+      double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (m.anc[f * m.nj + jt]) {
+        double X[12];
+        se3_mul(fMo + 12 * f, oM + 12 * jt, X);  // joint frame -> frame
+        double u[3];
+        if (ty == JOINT_FREE_FLYER) {
+          const int k = sub % 3;
+          u[0] = X[k];
+          u[1] = X[3 + k];
+          u[2] = X[6 + k];  // R[:, k]
+        } else {
+          const double *ax = m.axis + 3 * jt;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) u[i] = X[3 * i] * ax[0] + X[3 * i + 1] * ax[1] + X[3 * i + 2] * ax[2];
+        }
+        const bool angular = (ty == JOINT_REVOLUTE) || (ty == JOINT_FREE_FLYER && sub >= 3);
+        if (angular) {  // [p x (R u); R u]
+          col[0] = X[10] * u[2] - X[11] * u[1];
+          col[1] = X[11] * u[0] - X[9] * u[2];
+          col[2] = X[9] * u[1] - X[10] * u[0];
+          col[3] = u[0];
+          col[4] = u[1];
+          col[5] = u[2];
+        } else {  // [R u; 0]
+          col[0] = u[0];
+          col[1] = u[1];
+          col[2] = u[2];
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a.J_body[((b * m.nf + f) * 6 + r) * m.nv + j] = col[r];
+      }
+    }
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kWave) ik_fk_kernel(FkArgs a) {
+  ik_fk_instance<W>(a, block_id());
+}
+
+struct LimitsPostureArgs {
+  ModelDev m;
+  long long B;
+  double dt, config_limit_gain;
+  const double *q;         // [B, nq]
+  const double *q_target;  // [B, nq] or [nq] (target_batched)
+  int target_batched;
+  double *lb, *ub;         // [B, nv]
+  double *e;               // [B, K]: posture rows written at e_off .. e_off + nv - root_nv, or NULL
+  int K, e_off;
+};
+
+// one thread per (instance, tangent coordinate)
+__device__ inline void ik_limits_posture_thread(const LimitsPostureArgs &a, long long t) {
+  const ModelDev &m = a.m;
+  if (t >= a.B * m.nv) return;
+  const long long b = t / m.nv;
+  const int j = (int)(t - b * m.nv);
+  const int jt = m.dof_joint[j];
+  double lo = -INFINITY, hi = INFINITY;
+  if (m.jtype[jt] != JOINT_FREE_FLYER) {
+    const int iq = m.idx_q[jt];
+    const double qi = a.q[b * m.nq + iq];
+    const double qmin = m.q_min[iq], qmax = m.q_max[iq], vmax = m.v_max[j];
+    if (qmax < 1e20 && qmax > qmin + 1e-10) {  // configuration_limit.py:50-56, 111-120
+      lo = a.config_limit_gain * (qmin - qi);
+      hi = a.config_limit_gain * (qmax - qi);
+    }
+    if (vmax < 1e20 && vmax > 1e-10) {  // velocity_limit.py:61-64, 118-120
+      lo = fmax(lo, -a.dt * vmax);
+      hi = fmin(hi, a.dt * vmax);
+    }
+    if (a.e && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q* on the actuated coordinates
+      const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
+      a.e[b * a.K + a.e_off + (j - m.root_nv)] = qi - qt;
+    }
+  }
+  a.lb[b * m.nv + j] = lo;
+  a.ub[b * m.nv + j] = hi;
+}
+
+__global__ void __launch_bounds__(256) ik_limits_posture_kernel(LimitsPostureArgs a) {
+  ik_limits_posture_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+struct IntegrateArgs {
+  ModelDev m;
+  long long B;
+  double *q;         // [B, nq] in place
+  const double *dq;  // [B, nv]
+};
+
+// one thread per (instance, joint): q <- q (+) dq
+__device__ inline void ik_integrate_thread(const IntegrateArgs &a, long long t) {
+  const ModelDev &m = a.m;
+  if (t >= a.B * m.nj) return;
+  const long long b = t / m.nj;
+  const int j = (int)(t - b * m.nj);
+  double *q = a.q + b * m.nq + m.idx_q[j];
+  const double *v = a.dq + b * m.nv + m.idx_v[j];
+  if (m.jtype[j] != JOINT_FREE_FLYER) {
+    q[0] += v[0];
+    return;
+  }
+  // M <- M exp6(v): p += R V(w) v_lin, quat <- quat * exp(w / 2)
+  double R[9];
+  quat_to_rot(q + 3, R);
+  const double wx = v[3], wy = v[4], wz = v[5];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  double A, Bc;  // V = I + A [w]x + Bc [w]x^2
+  if (th < 1e-8) {
+    A = 0.5;
+    Bc = 1.0 / 6.0;
+  } else {
+    A = (1.0 - cos(th)) / th2;
+    Bc = (th - sin(th)) / (th2 * th);
+  }
+  const double cx = wy * v[2] - wz * v[1], cy = wz * v[0] - wx * v[2], cz = wx * v[1] - wy * v[0];  // w x v
+  const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;          // w x (w x v)
+  const double tx = v[0] + A * cx + Bc * ccx, ty = v[1] + A * cy + Bc * ccy, tz = v[2] + A * cz + Bc * ccz;
+  q[0] += R[0] * tx + R[1] * ty + R[2] * tz;
+  q[1] += R[3] * tx + R[4] * ty + R[5] * tz;
+  q[2] += R[6] * tx + R[7] * ty + R[8] * tz;
+  double s_h, c_h;  // unit quaternion of exp(w): (sin(th/2)/th w, cos(th/2))
+  if (th < 1e-8) {
+    s_h = 0.5;
+    c_h = 1.0;
+  } else {
+    s_h = sin(0.5 * th) / th;
+    c_h = cos(0.5 * th);
+  }
+  const double dx = s_h * wx, dy = s_h * wy, dz = s_h * wz, dw = c_h;
+  const double x = q[3], y = q[4], z = q[5], w = q[6];
+  double nx = w * dx + x * dw + y * dz - z * dy;
+  double ny = w * dy - x * dz + y * dw + z * dx;
+  double nz = w * dz + x * dy - y * dx + z * dw;
+  double nw = w * dw - x * dx - y * dy - z * dz;
+  const double n = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  q[3] = nx * n;
+  q[4] = ny * n;
+  q[5] = nz * n;
+  q[6] = nw * n;
+}
+
+__global__ void __launch_bounds__(256) ik_integrate_kernel(IntegrateArgs a) {
+  ik_integrate_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+}  // namespace pinkhip

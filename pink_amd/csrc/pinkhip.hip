@@ -19,7 +19,9 @@
 #include "ik_kernels_packed.h"
 #include "ik_stack_mfma.h"
 #include "ik_frame_task.h"
+#include "ik_kinematics.h"
 #include "host_tables.h"
+#include "model_tables.h"
 // clang-format on
 
 namespace {
@@ -29,6 +31,12 @@ thread_local std::string g_last_error;
 constexpr size_t kTableBytes = 64 * 1024;
 
 }  // namespace
+
+struct pinkhip_model {
+  pinkhip::ModelImage image;
+  char *d_base = nullptr;
+  pinkhip::ModelDev dev;
+};
 
 struct pinkhip_handle {
   int device = -1;
@@ -472,6 +480,115 @@ int pinkhip_frame_task_host(pinkhip_handle *h, int64_t B, int32_t nv, const doub
   PH_HIP(h, hipMemcpyAsync(e_out, dE, 8 * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipMemcpyAsync(J_out, dJo, 8 * (size_t)B * 6 * nv, hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_frame_task_strided_device(pinkhip_handle *h, int64_t B, int32_t nv, const double *T_frame,
+                                      int64_t sT_frame, const double *T_target, int64_t sT_target,
+                                      const double *J_body, int64_t sJ_body, double *e_out, int64_t sE,
+                                      double *J_out, int64_t sJ_out) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (B < 0 || nv < 1 || nv > PINKHIP_MAX_NV) return fail(h, PINKHIP_E_INVALID, "bad B / nv");
+  if (B == 0) return PINKHIP_OK;
+  if (!T_frame || !T_target || !J_body || !e_out || !J_out) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  if (B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "B exceeds the grid limit");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::FrameTaskArgs a{B, nv, T_frame, T_target, J_body, e_out, J_out, sT_frame, sT_target, sJ_body, sE, sJ_out};
+  const dim3 block(pinkhip::kWave);
+  if (nv <= 8) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<8>, dim3((unsigned)((B + 7) / 8)), block, 0, h->stream, a);
+  } else if (nv <= 16) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<16>, dim3((unsigned)((B + 3) / 4)), block, 0, h->stream, a);
+  } else if (nv <= 32) {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<32>, dim3((unsigned)((B + 1) / 2)), block, 0, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(pinkhip::ik_frame_task_kernel<64>, dim3((unsigned)B), block, 0, h->stream, a);
+  }
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_model_create(pinkhip_handle *h, const pinkhip_model_desc *desc, pinkhip_model **out) {
+  if (!h || !desc || !out) return fail(h, PINKHIP_E_INVALID, "null argument");
+  *out = nullptr;
+  pinkhip_model *m = new (std::nothrow) pinkhip_model();
+  if (!m) return fail(h, PINKHIP_E_NOMEM, "out of host memory");
+  const std::string why = pinkhip::build_model_image(*desc, m->image);
+  if (!why.empty()) {
+    delete m;
+    return fail(h, PINKHIP_E_INVALID, why);
+  }
+  hipError_t e = hipSetDevice(h->device);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_base), m->image.bytes.size());
+  if (e == hipSuccess) e = hipMemcpy(m->d_base, m->image.bytes.data(), m->image.bytes.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->d_base) (void)hipFree(m->d_base);
+    delete m;
+    return fail(h, PINKHIP_E_HIP, std::string("pinkhip_model_create: ") + hipGetErrorString(e));
+  }
+  m->dev = pinkhip::model_view<pinkhip::ModelDev>(m->image, m->d_base);
+  *out = m;
+  return PINKHIP_OK;
+}
+
+int pinkhip_model_destroy(pinkhip_handle *h, pinkhip_model *m) {
+  if (!m) return PINKHIP_OK;
+  if (h) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+  }
+  if (m->d_base) (void)hipFree(m->d_base);
+  delete m;
+  return PINKHIP_OK;
+}
+
+int pinkhip_fk_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, const double *q, double *T_frames,
+                      double *J_body) {
+  if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
+  if (B < 0 || B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "bad B");
+  if (B == 0) return PINKHIP_OK;
+  if (!q || (m->dev.nf > 0 && (!T_frames || !J_body))) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::FkArgs a{m->dev, B, q, T_frames, J_body};
+  const int per = pinkhip::fk_lds_doubles(m->dev.nj, m->dev.nf);
+  const dim3 block(pinkhip::kWave);
+  if (m->dev.nv <= 32) {
+    hipLaunchKernelGGL(pinkhip::ik_fk_kernel<32>, dim3((unsigned)((B + 1) / 2)), block, 8 * 2 * per + 16, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(pinkhip::ik_fk_kernel<64>, dim3((unsigned)B), block, 8 * per + 16, h->stream, a);
+  }
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, double dt,
+                                  double config_limit_gain, const double *q, const double *q_target,
+                                  int32_t target_batched, double *lb, double *ub, double *e, int32_t K,
+                                  int32_t e_off) {
+  if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
+  if (B < 0) return fail(h, PINKHIP_E_INVALID, "bad B");
+  if (B == 0) return PINKHIP_OK;
+  if (!q || !lb || !ub || (e && !q_target)) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  if (e && (e_off < 0 || e_off + m->dev.nv - m->dev.root_nv > K)) return fail(h, PINKHIP_E_INVALID, "posture rows exceed K");
+  if (!(dt > 0.0) || !(config_limit_gain > 0.0 && config_limit_gain <= 1.0)) return fail(h, PINKHIP_E_INVALID, "bad dt / gain");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::LimitsPostureArgs a{m->dev, B, dt, config_limit_gain, q, q_target, target_batched, lb, ub, e, K, e_off};
+  const long long n = B * m->dev.nv;
+  hipLaunchKernelGGL(pinkhip::ik_limits_posture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, double *q, const double *dq) {
+  if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
+  if (B < 0) return fail(h, PINKHIP_E_INVALID, "bad B");
+  if (B == 0) return PINKHIP_OK;
+  if (!q || !dq) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::IntegrateArgs a{m->dev, B, q, dq};
+  const long long n = B * m->dev.nj;
+  hipLaunchKernelGGL(pinkhip::ik_integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  PH_HIP(h, hipGetLastError());
   return PINKHIP_OK;
 }
 

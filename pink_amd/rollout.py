@@ -1,0 +1,214 @@
+"""Closed-loop differential IK on the device.
+
+The reference iterates ``solve_ik`` + ``configuration.integrate_inplace`` on the host, one
+robot at a time (``examples/inverse_kinematics_ur10.py:75-91``, ``tests/test_solve_ik.py
+:160-210``).  ``DeviceRollout`` keeps ``B`` robots resident in HBM and runs every stage of a
+step as a HIP kernel, with no host round trip between steps:
+
+    forward kinematics + body Jacobians      pinkhip_fk_device
+    FrameTask e, J (log6 / Jlog6)            pinkhip_frame_task_strided_device (one launch per task)
+    box limits + PostureTask error           pinkhip_limits_posture_device
+    stack + QP solve                         pinkhip_solve_device
+    q <- q (+) dq                            pinkhip_integrate_device
+
+The task stack is the one of Pink's humanoid / arm examples: any number of FrameTasks plus an
+optional PostureTask, the model's configuration and velocity limits.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ._lib import Desc, Problem, Result, c_double_p, c_int32_p
+from .configuration import Model
+from .utils import get_root_joint_dim
+
+_JT = {"revolute": 0, "prismatic": 1, "free_flyer": 2}
+
+
+class ModelDesc(ctypes.Structure):
+    """``pinkhip_model_desc``."""
+
+    _fields_ = [
+        ("nj", ctypes.c_int32), ("nq", ctypes.c_int32), ("nv", ctypes.c_int32), ("nf", ctypes.c_int32),
+        ("root_nv", ctypes.c_int32),
+        ("parent", c_int32_p), ("jtype", c_int32_p), ("idx_q", c_int32_p), ("idx_v", c_int32_p),
+        ("placement", c_double_p), ("axis", c_double_p), ("frame_joint", c_int32_p),
+        ("frame_placement", c_double_p), ("q_min", c_double_p), ("q_max", c_double_p), ("v_max", c_double_p),
+    ]
+
+
+def pose12(T) -> np.ndarray:
+    """12-double pose: rotation row-major, then translation."""
+    return np.hstack([np.asarray(T.rotation, dtype=float).ravel(), np.asarray(T.translation, dtype=float)])
+
+
+class ModelArrays:
+    """NumPy tables of a :class:`pink_amd.configuration.Model` for ``pinkhip_model_create``;
+    ``frames`` lists the frame names the rollout needs (their order is the frame index)."""
+
+    def __init__(self, model: Model, frames: Sequence[str]):
+        self.model = model
+        self.frames = list(frames)
+        js = model.joints
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)  # noqa: E731
+        self.parent = i32([j.parent for j in js])
+        self.jtype = i32([_JT[j.kind] for j in js])
+        self.idx_q = i32([j.idx_q for j in js])
+        self.idx_v = i32([j.idx_v for j in js])
+        self.placement = np.ascontiguousarray([pose12(j.placement) for j in js], dtype=np.float64)
+        self.axis = np.ascontiguousarray([np.zeros(3) if j.axis is None else j.axis for j in js], dtype=np.float64)
+        fr = [model.frames[model.getFrameId(n)] for n in self.frames]
+        self.frame_joint = i32([f.joint for f in fr]) if fr else np.zeros(1, np.int32)
+        self.frame_placement = (np.ascontiguousarray([pose12(f.placement) for f in fr], dtype=np.float64)
+                                if fr else np.zeros((1, 12)))
+        self.q_min = np.ascontiguousarray(model.lowerPositionLimit, dtype=np.float64)
+        self.q_max = np.ascontiguousarray(model.upperPositionLimit, dtype=np.float64)
+        self.v_max = np.ascontiguousarray(model.velocityLimit, dtype=np.float64)
+        d = ModelDesc()
+        d.nj, d.nq, d.nv, d.nf = len(js), model.nq, model.nv, len(fr)
+        d.root_nv = get_root_joint_dim(model)[1]
+        d.parent = self.parent.ctypes.data_as(c_int32_p)
+        d.jtype = self.jtype.ctypes.data_as(c_int32_p)
+        d.idx_q = self.idx_q.ctypes.data_as(c_int32_p)
+        d.idx_v = self.idx_v.ctypes.data_as(c_int32_p)
+        d.placement = self.placement.ctypes.data_as(c_double_p)
+        d.axis = self.axis.ctypes.data_as(c_double_p)
+        d.frame_joint = self.frame_joint.ctypes.data_as(c_int32_p)
+        d.frame_placement = self.frame_placement.ctypes.data_as(c_double_p)
+        d.q_min = self.q_min.ctypes.data_as(c_double_p)
+        d.q_max = self.q_max.ctypes.data_as(c_double_p)
+        d.v_max = self.v_max.ctypes.data_as(c_double_p)
+        self.desc = d
+
+
+class DeviceRollout:
+    """``B`` robots iterating differential IK on the device.
+
+    ``api`` is a :class:`pink_amd.batch_solver.BatchSolver` (or anything with the same raw-pointer
+    methods: the test suite passes the CPU wave emulator).  ``frame_tasks`` is a list of
+    ``(frame_name, position_cost, orientation_cost, gain, lm_damping)``; ``posture_cost`` enables a
+    PostureTask toward ``q_posture`` (default: the initial configuration of each robot).
+    """
+
+    _BUFFERS = ("d_q", "d_T", "d_Jb", "d_Tt", "d_J", "d_e", "d_cost", "d_lb", "d_ub", "d_dq", "d_status", "d_iters", "d_qt")
+
+    def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
+                 posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
+                 config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0):
+        self.api, self.model, self.dt = api, model, float(dt)
+        self.B = B = int(q0.shape[0])
+        self.nv, self.nq = model.nv, model.nq
+        self.frames = [ft[0] for ft in frame_tasks]
+        self.arrays = ModelArrays(model, self.frames)
+        self.dmodel = api.model_create(self.arrays.desc)
+        nf, nv, nq = len(self.frames), self.nv, self.nq
+        root_nv = get_root_joint_dim(model)[1]
+        self.Kd = 6 * nf
+        n_post = nv - root_nv if posture_cost is not None else 0
+        self.K = self.Kd + n_post
+        # task tables of the QP (include/pinkhip.h: dense tasks first, then the diagonal one)
+        T = nf + (1 if n_post else 0)
+        self.task_rows = np.ascontiguousarray([6 * i for i in range(nf + 1)] + ([self.K] if n_post else []), dtype=np.int32)
+        self.task_kind = np.ascontiguousarray([0] * nf + ([1] if n_post else []), dtype=np.int32)
+        self.task_col0 = np.ascontiguousarray([0] * nf + ([root_nv] if n_post else []), dtype=np.int32)
+        self.gain = np.ascontiguousarray([ft[3] for ft in frame_tasks] + ([posture_gain] if n_post else []), dtype=np.float64)
+        self.lm = np.ascontiguousarray([ft[4] for ft in frame_tasks] + ([0.0] if n_post else []), dtype=np.float64)
+        cost = []
+        for ft in frame_tasks:
+            cost += list(np.broadcast_to(np.asarray(ft[1], float), (3,))) + list(np.broadcast_to(np.asarray(ft[2], float), (3,)))
+        cost += [float(posture_cost)] * n_post
+        self.cost = np.ascontiguousarray(cost if cost else [0.0], dtype=np.float64)
+        self.brow = np.zeros(1, dtype=np.int32)
+        self.bsafe = np.zeros(1, dtype=np.float64)
+        d = Desc()
+        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, T, self.Kd, self.K, 0, 0
+        d.task_rows = self.task_rows.ctypes.data_as(c_int32_p)
+        d.task_kind = self.task_kind.ctypes.data_as(c_int32_p)
+        d.task_col0 = self.task_col0.ctypes.data_as(c_int32_p)
+        d.gain = self.gain.ctypes.data_as(c_double_p)
+        d.lm_damping = self.lm.ctypes.data_as(c_double_p)
+        d.n_barriers = 0
+        d.barrier_rows = self.brow.ctypes.data_as(c_int32_p)
+        d.barrier_safe_gain = self.bsafe.ctypes.data_as(c_double_p)
+        d.damping, d.dt, d.cost_is_batched, d.max_iter = float(damping), self.dt, 0, int(max_iter)
+        self.desc = d
+        self.config_limit_gain = float(config_limit_gain)
+        self.n_post = n_post
+        a = api
+        f8 = lambda *shape: a.alloc(8 * max(int(np.prod(shape)), 1))  # noqa: E731
+        self.d_q = f8(B, nq)
+        self.d_T = f8(B, max(nf, 1), 12)
+        self.d_Jb = f8(B, max(nf, 1), 6, nv)
+        self.d_Tt = f8(B, max(nf, 1), 12)
+        self.d_J = f8(B, max(self.Kd, 1), nv)
+        self.d_e = f8(B, max(self.K, 1))
+        self.d_cost = f8(max(self.K, 1))
+        self.d_lb, self.d_ub, self.d_dq = f8(B, nv), f8(B, nv), f8(B, nv)
+        self.d_status, self.d_iters = a.alloc(4 * B), a.alloc(4 * B)
+        self.d_qt = f8(B, nq)
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        a.put(self.d_q, q0)
+        a.put(self.d_qt, q0 if q_posture is None else np.ascontiguousarray(np.broadcast_to(q_posture, (B, nq)), dtype=np.float64))
+        a.put(self.d_cost, self.cost)
+        p = Problem()
+        p.J, p.e, p.cost, p.lb, p.ub = self.d_J, self.d_e, self.d_cost, self.d_lb, self.d_ub
+        p.Gd, p.hd, p.c_extra = None, None, None
+        self.problem = p
+        r = Result()
+        r.dq, r.status, r.iters = self.d_dq, self.d_status, self.d_iters
+        self.result = r
+        self.steps_done = 0
+
+    def set_targets(self, targets: np.ndarray) -> None:
+        """Frame targets, ``[B, n_frame_tasks, 12]`` poses (rotation row-major, translation)."""
+        t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, len(self.frames), 12)
+        self.api.put(self.d_Tt, t)
+
+    def step(self) -> None:
+        """Enqueue one IK step for every robot (asynchronous)."""
+        a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
+        a.fk(self.dmodel, B, self.d_q, self.d_T, self.d_Jb)
+        for t in range(nf):
+            a.frame_task_strided(B, nv, self.d_T + 8 * 12 * t, 12 * nf, self.d_Tt + 8 * 12 * t, 12 * nf,
+                                 self.d_Jb + 8 * 6 * nv * t, 6 * nv * nf, self.d_e + 8 * 6 * t, self.K,
+                                 self.d_J + 8 * 6 * nv * t, self.Kd * nv)
+        a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
+                         self.d_e if self.n_post else None, self.K, self.Kd)
+        a.solve_raw(self.desc, self.problem, self.result)
+        a.integrate(self.dmodel, B, self.d_q, self.d_dq)
+        self.steps_done += 1
+
+    def run(self, steps: int) -> None:
+        for _ in range(steps):
+            self.step()
+        self.api.sync()
+
+    def configurations(self) -> np.ndarray:
+        q = np.zeros((self.B, self.nq))
+        self.api.get(q, self.d_q)
+        return q
+
+    def last_step(self):
+        """``(dq, status, iters)`` of the most recent step."""
+        dq = np.zeros((self.B, self.nv))
+        st = np.zeros(self.B, np.int32)
+        it = np.zeros(self.B, np.int32)
+        self.api.get(dq, self.d_dq)
+        self.api.get(st, self.d_status)
+        self.api.get(it, self.d_iters)
+        return dq, st, it
+
+    def frame_poses(self) -> np.ndarray:
+        """Frame poses computed by the last forward-kinematics launch, ``[B, nf, 12]``."""
+        T = np.zeros((self.B, max(len(self.frames), 1), 12))
+        self.api.get(T, self.d_T)
+        return T
+
+    def free(self) -> None:
+        for name in self._BUFFERS:
+            self.api.release(getattr(self, name))
+        self.api.model_destroy(self.dmodel)

@@ -70,6 +70,69 @@ class EmuSolver:
         self.lib.pinkhip_emu_frame_task_host(B, nv, Tf.ctypes.data, Tt.ctypes.data, Jb.ctypes.data, e.ctypes.data, J.ctypes.data)
         return e, J
 
+    # -- raw "device" pointer interface of pink_amd.rollout.DeviceRollout, on host memory ----
+    def _bufs(self):
+        if not hasattr(self, "_mem"):
+            self._mem = {}
+        return self._mem
+
+    def alloc(self, nbytes):
+        buf = np.zeros(max(int(nbytes), 8) // 8 + 1, dtype=np.float64)
+        buf[:] = np.nan  # never-written device memory is garbage: make it visible
+        self._bufs()[buf.ctypes.data] = buf
+        return buf.ctypes.data
+
+    def release(self, ptr):
+        self._bufs().pop(ptr, None)
+
+    def put(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        ctypes.memmove(ptr, arr.ctypes.data, arr.nbytes)
+
+    def get(self, arr, ptr):
+        ctypes.memmove(arr.ctypes.data, ptr, arr.nbytes)
+
+    def sync(self):
+        pass
+
+    def model_create(self, desc):
+        m = ctypes.c_void_p()
+        self.lib.pinkhip_emu_model_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        rc = self.lib.pinkhip_emu_model_create(ctypes.byref(desc), ctypes.byref(m))
+        if rc != 0:
+            raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
+        return m.value
+
+    def model_destroy(self, model):
+        self.lib.pinkhip_emu_model_destroy.argtypes = [ctypes.c_void_p]
+        self.lib.pinkhip_emu_model_destroy(ctypes.c_void_p(model))
+
+    def fk(self, model, B, q, T_frames, J_body):
+        vp = ctypes.c_void_p
+        self.lib.pinkhip_emu_fk.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
+        self.lib.pinkhip_emu_fk(model, B, q, T_frames, J_body)
+
+    def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ):
+        vp, ll = ctypes.c_void_p, ctypes.c_longlong
+        self.lib.pinkhip_emu_frame_task_strided.argtypes = [ll, ctypes.c_int, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll]
+        self.lib.pinkhip_emu_frame_task_strided(B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ)
+
+    def limits_posture(self, model, B, dt, gain, q, q_target, batched, lb, ub, e, K, e_off):
+        vp = ctypes.c_void_p
+        self.lib.pinkhip_emu_limits_posture.argtypes = [vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, vp, vp,
+                                                        ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
+        self.lib.pinkhip_emu_limits_posture(model, B, dt, gain, q, q_target, batched, lb, ub, e, K, e_off)
+
+    def integrate(self, model, B, q, dq):
+        vp = ctypes.c_void_p
+        self.lib.pinkhip_emu_integrate.argtypes = [vp, ctypes.c_longlong, vp, vp]
+        self.lib.pinkhip_emu_integrate(model, B, q, dq)
+
+    def solve_raw(self, desc, problem, result):
+        rc = self.lib.pinkhip_emu_solve_host(ctypes.byref(desc), ctypes.byref(problem), ctypes.byref(result))
+        if rc != 0:
+            raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
+
     def stack(self, batch):
         from pink_amd._lib import PackedArgs
 

@@ -7,6 +7,8 @@
 #include "../../pink_amd/csrc/ik_kernels_packed.h"
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/ik_frame_task.h"
+#include "../../pink_amd/csrc/ik_kinematics.h"
+#include "../../pink_amd/csrc/model_tables.h"
 #include "../../pink_amd/csrc/host_tables.h"
 // clang-format on
 
@@ -135,7 +137,70 @@ void lane_main_frame(void *p) {
   pinkhip::ik_frame_task_instance<W>(*static_cast<const pinkhip::FrameTaskArgs *>(p), pinkhip::block_id());
 }
 
+template <int W>
+void lane_main_fk(void *p) {
+  pinkhip::ik_fk_instance<W>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
+}
+
+struct EmuModel {
+  pinkhip::ModelImage image;
+  pinkhip::ModelDev dev;
+};
+
 extern "C" {
+// kinematics entry points mirroring pinkhip_model_create / _fk_device / ... on host memory
+int pinkhip_emu_model_create(const pinkhip_model_desc *d, void **out) {
+  EmuModel *m = new EmuModel();
+  g_err = pinkhip::build_model_image(*d, m->image);
+  if (!g_err.empty()) {
+    delete m;
+    return PINKHIP_E_INVALID;
+  }
+  m->dev = pinkhip::model_view<pinkhip::ModelDev>(m->image, m->image.bytes.data());
+  *out = m;
+  return PINKHIP_OK;
+}
+int pinkhip_emu_model_destroy(void *m) {
+  delete static_cast<EmuModel *>(m);
+  return PINKHIP_OK;
+}
+int pinkhip_emu_fk(void *mp, long long B, const double *q, double *T_frames, double *J_body) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::FkArgs a{m->dev, B, q, T_frames, J_body};
+  if (m->dev.nv <= 32) {
+    for (long long b = 0; b < (B + 1) / 2; ++b) pinkhip::emu_run_block(b, lane_main_fk<32>, &a);
+  } else {
+    for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_fk<64>, &a);
+  }
+  return PINKHIP_OK;
+}
+int pinkhip_emu_limits_posture(void *mp, long long B, double dt, double gain, const double *q,
+                               const double *q_target, int target_batched, double *lb, double *ub, double *e,
+                               int K, int e_off) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::LimitsPostureArgs a{m->dev, B, dt, gain, q, q_target, target_batched, lb, ub, e, K, e_off};
+  for (long long t = 0; t < B * m->dev.nv; ++t) pinkhip::ik_limits_posture_thread(a, t);
+  return PINKHIP_OK;
+}
+int pinkhip_emu_integrate(void *mp, long long B, double *q, const double *dq) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::IntegrateArgs a{m->dev, B, q, dq};
+  for (long long t = 0; t < B * m->dev.nj; ++t) pinkhip::ik_integrate_thread(a, t);
+  return PINKHIP_OK;
+}
+int pinkhip_emu_frame_task_strided(long long B, int nv, const double *T_frame, long long sTf, const double *T_target,
+                                   long long sTt, const double *J_body, long long sJb, double *e_out, long long sE,
+                                   double *J_out, long long sJo) {
+  pinkhip::FrameTaskArgs a{B, nv, T_frame, T_target, J_body, e_out, J_out, sTf, sTt, sJb, sE, sJo};
+  pinkhip::LaneFn fn;
+  int G;
+  if (nv <= 8) { fn = lane_main_frame<8>; G = 8; }
+  else if (nv <= 16) { fn = lane_main_frame<16>; G = 4; }
+  else if (nv <= 32) { fn = lane_main_frame<32>; G = 2; }
+  else { fn = lane_main_frame<64>; G = 1; }
+  for (long long b = 0; b < (B + G - 1) / G; ++b) pinkhip::emu_run_block(b, fn, &a);
+  return PINKHIP_OK;
+}
 int pinkhip_emu_frame_task_host(long long B, int nv, const double *T_frame, const double *T_target,
                                 const double *J_body, double *e_out, double *J_out) {
   pinkhip::FrameTaskArgs a{B, nv, T_frame, T_target, J_body, e_out, J_out};

@@ -26,6 +26,13 @@
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV)
 
+// element-wise kernels use blockIdx / threadIdx directly; the emulator calls their per-thread
+// bodies in a plain loop and only needs the names to exist
+struct EmuDim3 {
+  unsigned x = 0, y = 0, z = 0;
+};
+static EmuDim3 blockIdx, threadIdx;
+
 namespace pinkhip {
 
 constexpr int kWave = 64;

@@ -1,0 +1,141 @@
+"""Device-side kinematics and the closed IK loop against the host
+pipeline (NumPy Configuration + per-instance solve_ik), on the CPU wave emulator and on the GPU."""
+import numpy as np
+import pytest
+
+import pink_amd
+from pink_amd import Configuration, FrameTask, PostureTask, build_chain, solve_ik
+from pink_amd.lie import SE3, exp6
+from pink_amd.rollout import DeviceRollout, ModelArrays, pose12
+from pink_amd.runtime import set_default_solver
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def api(request):
+    s = request.getfixturevalue("emu" if request.param == "emu" else "gpu_solver")
+    set_default_solver(s)
+    yield s
+    set_default_solver(None)
+
+
+def _models():
+    arm = build_chain(6)
+    humanoid = build_chain(9, free_flyer=True, seed=3)  # free-flyer root + 9 revolute joints: nv = 15
+    humanoid.add_frame("mid", 4, SE3(np.eye(3), [0.05, 0.0, 0.1]))
+    return [(arm, ["tool0"]), (humanoid, ["tool0", "mid"])]
+
+
+def _random_q(model, B, rng):
+    q = np.tile(model.neutral(), (B, 1))
+    for j in model.joints:
+        if j.kind == "free_flyer":
+            for b in range(B):
+                M = exp6(rng.normal(size=6) * 0.5)
+                q[b, j.idx_q:j.idx_q + 3] = M.translation
+                from pink_amd.configuration import _rot_to_quat
+                q[b, j.idx_q + 3:j.idx_q + 7] = _rot_to_quat(M.rotation)
+        else:
+            q[:, j.idx_q] = rng.uniform(-1.2, 1.2, size=B)
+    return q
+
+
+def test_fk_frame_jacobians_limits_integrate_match_host(api):
+    rng = np.random.default_rng(0)
+    for model, frames in _models():
+        B = 5
+        q = _random_q(model, B, rng)
+        arrays = ModelArrays(model, frames)
+        dm = api.model_create(arrays.desc)
+        nf, nv, nq = len(frames), model.nv, model.nq
+        d_q, d_T, d_J = api.alloc(8 * B * nq), api.alloc(8 * B * nf * 12), api.alloc(8 * B * nf * 6 * nv)
+        api.put(d_q, q)
+        api.fk(dm, B, d_q, d_T, d_J)
+        api.sync()
+        T = np.zeros((B, nf, 12))
+        J = np.zeros((B, nf, 6, nv))
+        api.get(T, d_T)
+        api.get(J, d_J)
+        cfgs = [Configuration(model, q[b]) for b in range(B)]
+        for b, cfg in enumerate(cfgs):
+            for f, name in enumerate(frames):
+                assert np.abs(T[b, f] - pose12(cfg.get_transform_frame_to_world(name))).max() < 1e-13
+                assert np.abs(J[b, f] - cfg.get_frame_jacobian(name)).max() < 1e-13
+        # limits + posture error
+        d_lb, d_ub, d_e, d_qt = api.alloc(8 * B * nv), api.alloc(8 * B * nv), api.alloc(8 * B * nv), api.alloc(8 * nq)
+        qt = model.neutral()
+        api.put(d_qt, qt)
+        root_nv = pink_amd.utils.get_root_joint_dim(model)[1]
+        api.limits_posture(dm, B, 5e-3, 0.5, d_q, d_qt, 0, d_lb, d_ub, d_e, nv, 0)
+        api.sync()
+        lb, ub, e = np.zeros((B, nv)), np.zeros((B, nv)), np.zeros((B, nv))
+        api.get(lb, d_lb), api.get(ub, d_ub), api.get(e, d_e)
+        for b, cfg in enumerate(cfgs):
+            lo, hi = np.full(nv, -np.inf), np.full(nv, np.inf)
+            for lim in (model.configuration_limit, model.velocity_limit):
+                idx, l_, u_ = lim.compute_box(cfg, 5e-3)
+                lo[idx], hi[idx] = np.maximum(lo[idx], l_), np.minimum(hi[idx], u_)
+            assert np.array_equal(lb[b], lo) and np.array_equal(ub[b], hi)
+            post = PostureTask(cost=1.0)
+            post.set_target(qt)
+            assert np.abs(e[b, :nv - root_nv] - post.compute_error(cfg)).max() < 1e-15
+        # integrate
+        dq = 0.1 * rng.normal(size=(B, nv))
+        d_dq = api.alloc(8 * B * nv)
+        api.put(d_dq, dq)
+        api.integrate(dm, B, d_q, d_dq)
+        api.sync()
+        q2 = np.zeros((B, nq))
+        api.get(q2, d_q)
+        for b in range(B):
+            ref = model.integrate(q[b], dq[b])
+            for j in model.joints:  # quaternions are defined up to sign: compare the transforms
+                a_ = model.joint_transform(j, q2[b])
+                r_ = model.joint_transform(j, ref)
+                assert np.abs(a_.rotation - r_.rotation).max() < 1e-13 and np.abs(a_.translation - r_.translation).max() < 1e-13
+        for p in (d_q, d_T, d_J, d_lb, d_ub, d_e, d_qt, d_dq):
+            api.release(p)
+        api.model_destroy(dm)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_closed_loop_matches_host_loop_and_converges(api, which):
+    """tests/test_solve_ik.py:160-210 / examples/inverse_kinematics_ur10.py:75-91, batched."""
+    model, frames = _models()[which]
+    rng = np.random.default_rng(10 + which)
+    B, dt, steps = 4, 5e-3, 40
+    q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
+    if which == 1:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    cfgs = [Configuration(model, q0[b]) for b in range(B)]
+    specs = [(f, 1.0, 0.5 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
+    targets = np.zeros((B, len(frames), 12))
+    host_tasks = []
+    for b, cfg in enumerate(cfgs):
+        tl = []
+        for i, (f, pc, oc, gain, lm) in enumerate(specs):
+            t = FrameTask(f, pc, oc, lm_damping=lm, gain=gain)
+            tgt = cfg.get_transform_frame_to_world(f) * SE3(np.eye(3), 0.05 * rng.normal(size=3))
+            t.set_target(tgt)
+            targets[b, i] = pose12(tgt)
+            tl.append(t)
+        p = PostureTask(cost=1e-2)
+        p.set_target(q0[b])
+        tl.append(p)
+        host_tasks.append(tl)
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-2)
+    ro.set_targets(targets)
+    ro.run(steps)
+    qd = ro.configurations()
+    _, st, _ = ro.last_step()
+    assert (st == 0).all()
+    # host loop: same steps with per-instance solve_ik + integrate_inplace
+    for b, cfg in enumerate(cfgs):
+        e0 = np.linalg.norm(host_tasks[b][0].compute_error(cfg))
+        for _ in range(steps):
+            cfg.integrate_inplace(solve_ik(cfg, host_tasks[b], dt), dt)
+        cd = Configuration(model, qd[b])
+        for f in frames:
+            Ta, Tb = cd.get_transform_frame_to_world(f), cfg.get_transform_frame_to_world(f)
+            assert np.abs(Ta.translation - Tb.translation).max() < 1e-8 and np.abs(Ta.rotation - Tb.rotation).max() < 1e-8
+        assert np.linalg.norm(host_tasks[b][0].compute_error(cd)) < e0  # the loop makes progress on every robot
+    ro.free()
