@@ -123,19 +123,23 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   double *fMo = oM + 12 * m.nj;  // frame-from-world transforms
   const double *q = a.q + b * (long long)m.nq;
 
-  // forward kinematics along the tree (sequential, one lane; 60 flops per joint)
+  // forward kinematics: the local transforms (sin / cos) in parallel, one joint per lane, then
+  // the composition along the tree by one lane (39 FMAs per joint, parents precede children)
+  for (int j = li; j < m.nj; j += W) {
+    double X[12], Tj[12];
+    joint_transform(m, j, q, Tj);
+    se3_mul(m.placement + 12 * j, Tj, X);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) oM[12 * j + i] = X[i];
+  }
+  wave_sync();
   if (li == 0) {
     for (int j = 0; j < m.nj; ++j) {
-      double X[12], Tj[12], P[12];
-      joint_transform(m, j, q, Tj);
-      se3_mul(m.placement + 12 * j, Tj, X);
       if (m.parent[j] >= 0) {
-        se3_mul(oM + 12 * m.parent[j], X, P);
+        double P[12];
+        se3_mul(oM + 12 * m.parent[j], oM + 12 * j, P);
 #pragma unroll
         for (int i = 0; i < 12; ++i) oM[12 * j + i] = P[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) oM[12 * j + i] = X[i];
       }
     }
   }

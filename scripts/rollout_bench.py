@@ -1,0 +1,41 @@
+"""Throughput of the device-resident closed loop (FK -> frame tasks -> limits -> QP -> integrate)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from pink_amd import Configuration, build_chain
+from pink_amd.batch_solver import BatchSolver
+from pink_amd.lie import SE3
+from pink_amd.rollout import DeviceRollout, pose12
+
+s = BatchSolver(0)
+out = {}
+for label, model, frames in (("arm6", build_chain(6), ["tool0"]),
+                             ("floating_base_nv30", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"])):
+    B = 65536
+    rng = np.random.default_rng(1)
+    q0 = np.tile(model.neutral(), (B, 1))
+    for j in model.joints:
+        if j.kind != "free_flyer":
+            q0[:, j.idx_q] = rng.uniform(-0.8, 0.8, size=B)
+    cfg = Configuration(model, q0[0])
+    specs = [(f, 1.0, 1.0 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
+    ro = DeviceRollout(s, model, q0, specs, 5e-3, posture_cost=1e-1)
+    # targets: each robot's own initial frame poses displaced by a few centimetres
+    ro.step(); s.sync()
+    T = ro.frame_poses()
+    T[:, :, 9:12] += 0.05 * rng.normal(size=(B, len(frames), 3))
+    ro.set_targets(T)
+    ro.run(5)
+    steps = 50
+    s.timer_start()
+    for _ in range(steps):
+        ro.step()
+    ms = s.timer_stop() / steps
+    _, st, it = ro.last_step()
+    print(f"{label}: nv={model.nv} B={B}: {ms:.3f} ms per closed-loop step -> {B/ms/1e3:.1f} M robot-steps/s; failed={(st!=0).sum()} qp iters mean {it.mean():.2f}")
+    out[label] = dict(nv=model.nv, B=B, ms_per_step=ms, robot_steps_per_s=B / (ms * 1e-3), qp_iters_mean=float(it.mean()), failed=int((st != 0).sum()),
+                      frame_tasks=len(frames))
+    ro.free()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "rollout_bench.json"), "w"), indent=1)
