@@ -274,6 +274,49 @@ def test_batched_frame_tasks_on_gpu_equal_host_evaluation(backend):
         assert np.abs(Vp[b] - solve_ik(cfg, per[b], 5e-3)).max() < 1e-9
 
 
+def test_acceleration_limit(backend):
+    """tests/test_acceleration_limit.py:34-94: shapes, None for limit-less models, self-consistency
+    for joints without configuration limits, and the limit changes the IK solution."""
+    from pink_amd.limits import AccelerationLimit
+
+    m, cfg = _arm()
+    lim = AccelerationLimit(m, np.full(6, 14.0))
+    assert lim.projection_matrix.shape == (6, 6)
+    G, h = lim.compute_qp_inequalities(cfg, 5e-3)
+    assert G.shape == (12, 6) and h.shape == (12,)
+    free = build_chain(1, limit=np.inf, velocity=np.inf)  # a "continuous" joint
+    cf = Configuration(free, np.zeros(1))
+    lf = AccelerationLimit(free, np.array([14.0]))
+    lf.set_last_integration(np.array([3.0]), 5e-3)
+    G, h = lf.compute_qp_inequalities(cf, 5e-3)
+    assert (-h[1:] <= h[:1]).all()  # lower bound not above upper bound
+    assert AccelerationLimit(free, np.array([np.inf])).compute_qp_inequalities(cf, 5e-3) is None
+    task = FrameTask("tool0", 1.0, 1.0)
+    task.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.0, 0.3, 0.0]))
+    dt = 5e-3
+    v_free = solve_ik(cfg, [task], dt, damping=1e-6, limits=[])
+    v_lim = solve_ik(cfg, [task], dt, damping=1e-6, limits=[lim])
+    assert np.abs(v_lim).max() <= 14.0 * dt + 1e-9 and np.abs(v_free).max() > np.abs(v_lim).max()
+
+
+def test_floating_base_velocity_limit(backend):
+    """tests/test_floating_base_velocity_limit.py: rows only touch the root columns; the base twist obeys the bound."""
+    from pink_amd.limits import FloatingBaseVelocityLimit
+
+    m = build_chain(4, free_flyer=True)
+    cfg = Configuration(m, m.neutral())
+    lim = FloatingBaseVelocityLimit(m, None, max_linear_velocity=0.1, max_angular_velocity=[0.2, np.inf, 0.2])
+    G, h = lim.compute_qp_inequalities(cfg, 1e-2)
+    assert G.shape == (10, m.nv) and not G[:, 6:].any() and np.allclose(h[:3], 1e-3)
+    with pytest.raises(ValueError):
+        FloatingBaseVelocityLimit(build_chain(3), None, 1.0, 1.0)
+    task = FrameTask("tool0", 1.0, 0.0)
+    task.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.5, 0.2, 0.1]))
+    v = solve_ik(cfg, [task], 1e-2, damping=1e-6, limits=[lim])
+    assert np.abs(v[:3]).max() <= 0.1 + 1e-9 and abs(v[3]) <= 0.2 + 1e-9 and abs(v[5]) <= 0.2 + 1e-9
+    assert np.abs(v[:3]).max() > 0.09  # the bound is active: the target is far
+
+
 def test_urdf_reader_on_reference_robots():
     import os
 
