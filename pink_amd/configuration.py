@@ -170,6 +170,10 @@ class Model:
         out = np.zeros(self.nv)
         for j in self.joints:
             if j.kind == "free_flyer":
+                sl = slice(j.idx_q, j.idx_q + 7)
+                if not (np.isfinite(q0[sl]).all() and np.isfinite(q1[sl]).all()):
+                    out[j.idx_v:j.idx_v + 6] = np.inf  # "difference to an infinite limit": no limit
+                    continue
                 out[j.idx_v:j.idx_v + 6] = log6(self.joint_transform(j, q0).actInv(self.joint_transform(j, q1)))
             else:
                 out[j.idx_v] = q1[j.idx_q] - q0[j.idx_q]

@@ -97,6 +97,42 @@ def test_fk_frame_jacobians_limits_integrate_match_host(api):
         api.model_destroy(dm)
 
 
+def test_fk_and_integrate_against_the_independent_oracle(api):
+    """Device kinematics vs oracle/kinematics_oracle.py (expm products, finite-difference Jacobians)."""
+    from oracle import kinematics_oracle as ko
+
+    rng = np.random.default_rng(4)
+    for model, frames in _models():
+        B = 3
+        q = _random_q(model, B, rng)
+        arr = ModelArrays(model, frames)
+        dm = api.model_create(arr.desc)
+        nf, nv, nq = len(frames), model.nv, model.nq
+        d_q, d_T, d_J, d_dq = api.alloc(8 * B * nq), api.alloc(8 * B * nf * 12), api.alloc(8 * B * nf * 6 * nv), api.alloc(8 * B * nv)
+        api.put(d_q, q)
+        api.fk(dm, B, d_q, d_T, d_J)
+        api.sync()
+        T, J = np.zeros((B, nf, 12)), np.zeros((B, nf, 6, nv))
+        api.get(T, d_T), api.get(J, d_J)
+        for b in range(B):
+            Tr = ko.frame_poses(arr, q[b])
+            for f in range(nf):
+                assert np.abs(T[b, f, :9].reshape(3, 3) - Tr[f][:3, :3]).max() < 1e-12
+                assert np.abs(T[b, f, 9:] - Tr[f][:3, 3]).max() < 1e-12
+            assert np.abs(J[b] - ko.frame_jacobians_fd(arr, q[b])).max() < 1e-6  # tests/test_jacobians.py tolerance 1e-5
+        dq = 0.2 * rng.normal(size=(B, nv))
+        api.put(d_dq, dq)
+        api.integrate(dm, B, d_q, d_dq)
+        api.sync()
+        q2 = np.zeros((B, nq))
+        api.get(q2, d_q)
+        for b in range(B):
+            assert np.abs(ko.frame_poses(arr, q2[b]) - ko.frame_poses(arr, ko.integrate(arr, q[b], dq[b]))).max() < 1e-12
+        for p in (d_q, d_T, d_J, d_dq):
+            api.release(p)
+        api.model_destroy(dm)
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_closed_loop_matches_host_loop_and_converges(api, which):
     """tests/test_solve_ik.py:160-210 / examples/inverse_kinematics_ur10.py:75-91, batched."""
