@@ -86,7 +86,11 @@ def main() -> None:
     from pink_amd import synthetic
     from pink_amd.batch_solver import BatchSolver
 
-    g.build_hip()
+    # the library travels prebuilt; if it is stale only rank 0 rebuilds it (hipcc), the others wait
+    if rank == 0:
+        g.build_hip()
+    if world > 1:
+        dist.barrier()
     B = args.batch
     # every rank draws its own shard of the global batch (seeded by rank): weak scaling
     seed = synthetic.SEED0 + synthetic.CONFIGS[args.config]["config_id"] + 1000 * rank
