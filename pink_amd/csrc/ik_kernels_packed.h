@@ -358,14 +358,21 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       vs[li] = (li > q) ? dl : (li == q ? dq_ + sgq * nrm2 : 0.0);
     }
     wave_sync();
+    // columns below every group's q carry zeros in d2 and v: skip them eight at a time
+    const int qlow = groups_min<W>(act ? q : NV);
     double z = 0.0, w = 0.0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      z += Jr[j] * d2s[j];
-      w += Jr[j] * vs[j];
-      if ((j & (kG - 1)) == kG - 1) {
-        pin(z);
-        pin(w);
+    for (int j0 = 0; j0 < NV; j0 += 8) {
+      if (j0 + 8 > qlow) {
+#pragma unroll
+        for (int j = j0; j < j0 + 8; ++j) {
+          z += Jr[j] * d2s[j];
+          w += Jr[j] * vs[j];
+          if ((j & (kG - 1)) == kG - 1) {
+            pin(z);
+            pin(w);
+          }
+        }
       }
     }
     // r = R^-1 d1
@@ -411,11 +418,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (wave_any(do_add)) {
       const double wb = do_add ? beta * w : 0.0;
 #pragma unroll
-      for (int j0 = 0; j0 < NV; j0 += kG) {
+      for (int j0 = 0; j0 < NV; j0 += 8) {
+        if (j0 + 8 > qlow) {
 #pragma unroll
-        for (int j = j0; j < j0 + kG; ++j) Jr[j] -= wb * vs[j];
+          for (int j = j0; j < j0 + 8; ++j) Jr[j] -= wb * vs[j];
 #pragma unroll
-        for (int j = j0; j < j0 + kG; ++j) pin(Jr[j]);
+          for (int j = j0; j < j0 + 8; ++j) pin(Jr[j]);
+        }
       }
       if (do_add) {
         if (li < q) Rs[S::rcol(q) + li] = dl;
