@@ -184,6 +184,13 @@ __device__ __forceinline__ double group_bcast_static(double v) {
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
   return __hiloint2double(hi, lo);
 }
+template <int W, int K>
+__device__ __forceinline__ int group_bcast_static_i(int v) {
+  static_assert(K < W, "source lane outside the group");
+  if constexpr (W == 64) return bcast_i(v, K);
+  constexpr int pattern = ((~(W - 1)) & 0x1F) | (K << 5);
+  return __builtin_amdgcn_ds_swizzle(v, pattern);
+}
 __device__ __forceinline__ double swizzle_xor16(double v) {
   constexpr int pattern = (0x10 << 10) | 0x1F;
   const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
