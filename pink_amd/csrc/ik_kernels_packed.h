@@ -494,10 +494,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       // old position l+1, i.e. of +- row i of J (already carrying the earlier rotations), or
       // J1^T n for a dense row.  P~ = P without row kd gets the same rotations on its columns; lane
       // li produces NEW row li from old row li (li < kd) or li + 1.
+      // rotation indices any group needs: two wave-uniform bounds, tested per l on the scalar unit
+      const int l0 = groups_min<W>(do_drop ? kd : NV);
+      const int l1 = groups_max<W>(do_drop ? q - 1 : 0);
       static_for<0, NV - 1>([&](auto L) {
         constexpr int l = decltype(L)::value;
         const bool rot = do_drop && l >= kd && l < q - 1;
-        if (wave_any(rot)) {
+        if (l >= l0 && l < l1) {
           const int idn = group_bcast_static_i<W, (l + 1 < W ? l + 1 : 0)>(A);
           const int kn = idn >> 6;
           const double xa = group_bcast<W>(Jr[l], idn & (W - 1));
