@@ -17,13 +17,14 @@
 
 #include "ik_kernels.h"
 
-// PINKHIP_PINV = 1: keep P = R^-1 (instead of R) in LDS.  The dual direction r = P d1 becomes a
-// chain-free matrix-vector product, a new column of P costs one LDS write per lane, and on a drop the
-// Givens coefficients are read off the rows of J (for a box constraint column k of R is +- row i_k
-// of J), so R itself is never stored.
-#ifndef PINKHIP_PINV
-#define PINKHIP_PINV 1  // measured on MI355X: 2.38 -> 2.27 ms per 65 536 QPs at nv = 30 (0 = keep R, back-substitute)
-#endif
+// The triangular factor of the active set is kept as P = R^-1 (R itself is never stored): the dual
+// direction r = P d1 is a chain-free matrix-vector product, a new column of P costs one LDS write per
+// lane, and on a drop the Givens coefficients are read off the rows of J (for a box constraint column
+// k of R is +- row i_k of J).  Measured on MI355X against R + back-substitution: 2.38 -> 2.27 ms per
+// 65 536 QPs at nv = 30.  P is stored by diagonals (LdsP::doff): lane li reads P[li][li + m] at a
+// compile-time offset for every m, next to d1[li + m] from a zero-padded copy of d1, so the product
+// needs neither a predicate nor an address computation; what a lane reads past the end of its row is
+// finite and meets a zero of the padding.
 
 namespace pinkhip {
 
@@ -32,9 +33,10 @@ struct LdsP {
   static constexpr int GP = NV + 1;               // row pitch of the dense inequality rows
   static constexpr int TRI = NV * (NV + 3) / 2;   // packed triangle with one sub-diagonal slot per column
   static constexpr int RC = (TRI / NV < 32) ? TRI / NV : 32;  // staged J rows per chunk (pitch NV)
-  static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then R
-  static constexpr int oD = oT + TRI;             // NV   d = J^T n+          (init: 1/diag(L))
-  static constexpr int oD2 = oD + NV;             // NV   d with d1 zeroed    (init: column scratch; x for dense rows)
+  static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then P = R^-1
+  static constexpr int oD = oT + TRI;             // NV   row of J, then d1   (init: 1/diag(L))
+  static constexpr int oZ = oD + NV;              // NV   zeros: d1 read at [li + m] runs into them
+  static constexpr int oD2 = oZ + NV;             // NV   d with d1 zeroed    (init: column scratch; x for dense rows)
   static constexpr int oV = oD2 + NV;             // NV   Householder vector  (init: forward-solve scratch y)
   static constexpr int oX = oD2;                  // aliases: live ranges do not overlap
   static constexpr int oY = oV;
@@ -43,9 +45,11 @@ struct LdsP {
   static constexpr int oGd = oV + NV;             // md*GP
   static __host__ __device__ inline int stride(int md) { return (oGd + md * GP + 1) & ~1; }  // doubles per QP
   static __host__ __device__ inline long long bytes(int md, int groups) { return 8LL * stride(md) * groups + 16; }
-  // L: row i, entries 0..i at i(i+1)/2;  R: column k, rows 0..k+1 at k(k+3)/2
+  // L: row i, entries 0..i at i(i+1)/2
   static __host__ __device__ constexpr int lrow(int i) { return i * (i + 1) / 2; }
-  static __host__ __device__ constexpr int rcol(int k) { return k * (k + 3) / 2; }
+  // P (upper triangular) by diagonals: P[r][c] at doff(c - r) + r = doff(c) + c r + prow(r)
+  static __host__ __device__ constexpr int doff(int m) { return m * (2 * NV + 1 - m) / 2; }
+  static __host__ __device__ constexpr int prow(int r) { return -((r * (2 * NV - 1 + r)) / 2); }
 };
 
 template <int NV, int W>
@@ -70,6 +74,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   double *ds = sm + S::oD;
   double *d2s = sm + S::oD2;
   double *vs = sm + S::oV;
+  double *zs = sm + S::oZ;
   double *was = sm + S::oWa;
   double *gs = sm + S::oGs;
   double *Gs = sm + S::oGd;
@@ -77,7 +82,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const bool in = li < nv;
   const int lc = in ? li : 0;
   const int lv = li < NV ? li : 0;
-  const int rcl = S::rcol(lv);  // this lane's column of R (lane = column) / row offset helper
+  double *Pl = sm + S::oT + lv;                 // P[li][li + m] = Pl[doff(m)]
+  double *Pk = sm + S::oT + S::prow(lv);        // P[li][c]      = Pk[doff(c) + c * li]
+  const double *d1l = sm + S::oD + lv;          // d1[li + m]
 
   // ------------------------------------------------------------------ stack (task.py:145-167)
   double M[NV];
@@ -251,9 +258,12 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if ((j & (kG - 1)) == kG - 1) pin(x);
   }
   wave_sync();
+  if (li < NV) {  // L is dead: what the P product may read before it is written has to be finite
+    zs[li] = 0.0;
+    Ts[S::TRI - NV + li] = 0.0;
+  }
 
   // ------------------------------------------------------------------ Goldfarb-Idnani, flat
-  double *Rs = Ts;
   const double lbv = in ? a.lb[b * (long long)nv + li] : -INF;
   const double ubv = in ? a.ub[b * (long long)nv + li] : INF;
   const double tol = 1e-13;
@@ -262,7 +272,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
   int q = 0, it = 0, eq_next = 0;  // group-uniform
   int bstate = 0, dactive = 0, A = 0;
-  double u = 0.0, rdiag = 0.0;
+  double u = 0.0;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
   int kind = 0, src = 0, bid = 0;
@@ -362,9 +372,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
     const double beta = lin_dep ? 0.0 : rn2 * fast_rcp(lin_dep ? 1.0 : nrm2 + fabs(dq_));
     if (li < NV) {
-#if PINKHIP_PINV
-      ds[li] = dl;  // full signed d, read back group-uniformly by the r = P d1 product
-#endif
+      ds[li] = (li < q) ? dl : 0.0;  // d1, followed by the zeros of zs
       d2s[li] = (li >= q) ? dl : 0.0;
       vs[li] = (li > q) ? dl : (li == q ? dq_ + sgq * nrm2 : 0.0);
     }
@@ -386,26 +394,21 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
     }
-#if PINKHIP_PINV
-    // r = P d1 with P = R^-1 upper triangular, column-major in LDS: no dependency chain
+    // r = P d1, P = R^-1 upper triangular: r_li = sum_m P[li][li + m] d1[li + m], no dependency chain
     double rv = 0.0;
     {
       const int qmax = groups_max<W>(act ? q : 0);
-      for (int k = 0; k < qmax; ++k)
-        if (li <= k && k < q) rv += Rs[S::rcol(k) + li] * ds[k];
-    }
-#else
-    // r = R^-1 d1
-    double dp = dl;
-    {
-      const int qmax = groups_max<W>(act ? q : 0);
-      for (int k = qmax - 1; k > 0; --k) {
-        const double rk = group_bcast<W>(dp * rdiag, k);
-        if (li < k && k < q) dp -= Rs[S::rcol(k) + li] * rk;
+#pragma unroll
+      for (int m0 = 0; m0 < NV; m0 += 8) {
+        if (m0 < qmax) {
+#pragma unroll
+          for (int m = m0; m < m0 + 8; ++m) {
+            rv += Pl[S::doff(m)] * d1l[m];
+            if ((m & (kG - 1)) == kG - 1) pin(rv);
+          }
+        }
       }
     }
-    const double rv = dp * rdiag;
-#endif
     // (c) step lengths
     const bool eq_pos = (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
     const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
@@ -448,24 +451,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
       if (do_add) {
-#if PINKHIP_PINV
         // [R d1; 0 rho]^-1 = [P, -P d1 / rho; 0, 1 / rho] with P d1 = r, rho = -sgq |d2|
         const double rqinv = -sgq * rn2;
-        if (li < q) Rs[S::rcol(q) + li] = -rv * rqinv;
+        if (li <= q && li < NV) Pk[((q * (2 * NV + 1 - q)) >> 1) + q * li] = (li < q) ? -rv * rqinv : rqinv;
         if (li == q) {
-          Rs[S::rcol(q) + q] = rqinv;
           A = bid;
           u = uplus;
         }
-#else
-        if (li < q) Rs[S::rcol(q) + li] = dl;
-        if (li == q) {
-          Rs[S::rcol(q) + q] = -sgq * nrm2;
-          rdiag = -sgq * rn2;
-          A = bid;
-          u = uplus;
-        }
-#endif
         if (li == src) {
           if (kind == 0) bstate = 1;
           else if (kind == 1) bstate = 2;
@@ -488,7 +480,6 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
       wave_sync();
-#if PINKHIP_PINV
       // Rotations l = kd .. q-2 restore the triangular form after removing column kd of R.  Their
       // coefficients (R~[l][l], R~[l+1][l]) are entries l, l+1 of the column of the constraint at
       // old position l+1, i.e. of +- row i of J (already carrying the earlier rotations), or
@@ -497,6 +488,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       // rotation indices any group needs: two wave-uniform bounds, tested per l on the scalar unit
       const int l0 = groups_min<W>(do_drop ? kd : NV);
       const int l1 = groups_max<W>(do_drop ? q - 1 : 0);
+      const int ro = (li < kd) ? lv : (lv + 1 < NV ? lv + 1 : 0);
+      double *Po = sm + S::oT + S::prow(ro);  // P[ro][c] = Po[doff(c) + c * ro]
       static_for<0, NV - 1>([&](auto L) {
         constexpr int l = decltype(L)::value;
         const bool rot = do_drop && l >= kd && l < q - 1;
@@ -518,21 +511,23 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           const bool nz = rot && gb != 0.0;
           const double rh = fast_rsqrt(nz ? ga * ga + gb * gb : 1.0);
           const double cc = nz ? ga * rh : 1.0, ss = nz ? gb * rh : 0.0;
-          const int ro = (li < kd) ? li : li + 1;
           const bool prow = rot && li < q - 1;
           double pa = 0.0, pb = 0.0;
+          int lik = lv, rok = ro;  // pinned: keeps the 2 (NV - 1) lane addresses from being hoisted out of the
+          pin(lik);                // active-set loop, where they would live in (spilled) registers
+          pin(rok);
           if (prow) {
             if (l == kd) {
-              if (ro <= l) pa = Rs[S::rcol(l) + ro];  // column kd still sits at the old row positions
+              if (ro <= l) pa = Po[S::doff(l) + l * rok];  // column kd still sits at the old row positions
             } else if (li <= l) {
-              pa = Rs[S::rcol(l) + li];  // written at the new positions by the previous rotation
+              pa = Pk[S::doff(l) + l * lik];  // written at the new positions by the previous rotation
             }
-            if (ro <= l + 1) pb = Rs[S::rcol(l + 1) + ro];
+            if (ro <= l + 1) pb = Po[S::doff(l + 1) + (l + 1) * rok];
           }
           wave_sync();  // every lane has read: old rows are other lanes' new rows
           if (prow) {
-            if (li <= l) Rs[S::rcol(l) + li] = cc * pa + ss * pb;
-            if (li <= l + 1) Rs[S::rcol(l + 1) + li] = -ss * pa + cc * pb;
+            if (li <= l) Pk[S::doff(l) + l * lik] = cc * pa + ss * pb;
+            if (li <= l + 1) Pk[S::doff(l + 1) + (l + 1) * lik] = -ss * pa + cc * pb;
           }
           wave_sync();
           const double ja = Jr[l], jb = Jr[l + 1];
@@ -550,48 +545,6 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
       if (do_drop) --q;
       wave_sync();
-#else
-      {
-        const int c0 = groups_min<W>(do_drop ? kd : NV);
-        const int c1 = groups_max<W>(do_drop ? q - 1 : 0);
-        for (int col = c0; col < c1; ++col)
-          if (do_drop && col >= kd && col < q - 1 && li <= col + 1)
-            Rs[S::rcol(col) + li] = Rs[S::rcol(col + 1) + li];
-      }
-      {
-        const double un = from_next_lane(u);
-        const int An = from_next_lane_i(A);
-        if (do_drop && li >= kd && li < q - 1) {
-          u = un;
-          A = An;
-        }
-      }
-      if (do_drop) --q;
-      wave_sync();
-      static_for<0, NV - 1>([&](auto L) {
-        constexpr int l = decltype(L)::value;
-        const bool rot = do_drop && l >= kd && l < q;
-        if (wave_any(rot)) {
-          const bool mine = rot && li >= l && li < q;
-          const double ra = mine ? Rs[rcl + l] : 0.0;
-          const double rb = mine ? Rs[rcl + l + 1] : 0.0;
-          const double ga = group_bcast_static<W, l>(ra);
-          const double gb = group_bcast_static<W, l>(rb);
-          const bool nz = rot && gb != 0.0;
-          const double rh = fast_rsqrt(nz ? ga * ga + gb * gb : 1.0);
-          const double cc = nz ? ga * rh : 1.0, ss = nz ? gb * rh : 0.0;
-          if (mine && nz) {
-            Rs[rcl + l] = cc * ra + ss * rb;
-            Rs[rcl + l + 1] = -ss * ra + cc * rb;
-          }
-          const double ja = Jr[l], jb = Jr[l + 1];
-          Jr[l] = cc * ja + ss * jb;
-          Jr[l + 1] = -ss * ja + cc * jb;
-        }
-      });
-      if (do_drop && li >= kd && li < q) rdiag = fast_rcp(Rs[rcl + li]);
-      wave_sync();
-#endif
       // slack of the pending constraint at the new x (same n+ next trip)
       const double cand = (kind == 0) ? x - lbv : ubv - x;
       const double spn = group_bcast<W>(cand, src & (W - 1));
