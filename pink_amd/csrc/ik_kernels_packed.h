@@ -26,6 +26,22 @@
 // needs neither a predicate nor an address computation; what a lane reads past the end of its row is
 // finite and meets a zero of the padding.
 
+// Profiling builds only (scripts/section_clock.py compiles with -DPINKHIP_SECTION_CLOCK): every 64th
+// wave adds the s_memtime cycles it spends in each section of the kernel to pinkhip_clock[].
+#ifdef PINKHIP_SECTION_CLOCK
+__device__ unsigned long long pinkhip_clock[16];
+#define PINKHIP_TICK(k)                                                        \
+  do {                                                                         \
+    if (clock_on) {                                                            \
+      const unsigned long long now_ = __builtin_readcyclecounter();            \
+      if (lane == 0) atomicAdd(&pinkhip_clock[k], now_ - clock_prev);          \
+      clock_prev = __builtin_readcyclecounter();                               \
+    }                                                                          \
+  } while (0)
+#else
+#define PINKHIP_TICK(k)
+#endif
+
 namespace pinkhip {
 
 template <int NV>
@@ -63,6 +79,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const int lane = lane_id();
   const int g = lane / W, li = lane & (W - 1);
   const int nv = a.nv, Kd = a.Kd, K = a.K, md = a.md, n_eq = a.n_eq;
+#ifdef PINKHIP_SECTION_CLOCK
+  const bool clock_on = (block & 63) == 0;
+  unsigned long long clock_prev = __builtin_readcyclecounter();
+#endif
   long long b = block * G + g;
   const bool valid = b < a.B;
   if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
@@ -188,6 +208,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     }
   }
   diag += dadd;
+  PINKHIP_TICK(0);  // stacking
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     if (j >= nv || !in) M[j] = 0.0;
@@ -233,6 +254,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   }
   if (li < NV) xs[li] = cp;  // y
   wave_sync();
+  PINKHIP_TICK(1);  // Cholesky
   // J = L^-T
   double Jr[NV];
 #pragma unroll
@@ -258,6 +280,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if ((j & (kG - 1)) == kG - 1) pin(x);
   }
   wave_sync();
+  PINKHIP_TICK(2);  // J = L^-T, x0
   if (li < NV) {  // L is dead: what the P product may read before it is written has to be finite
     zs[li] = 0.0;
     Ts[S::TRI - NV + li] = 0.0;
@@ -338,6 +361,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     }
     if (!wave_any(running)) break;
     const bool act = running;
+    PINKHIP_TICK(3);  // selection
 
     // (b) d = J^T n+
     double dl = 0.0;
@@ -359,6 +383,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         if (dn && li == j) dl = s;
       }
     }
+    PINKHIP_TICK(4);  // d = J^T n
     double dd = group_bcast<W>(rown2, src & (W - 1));
     if (md > 0 && wave_any(act && kind >= 2)) {
       const double dds = group_sum<W>(dl * dl);
@@ -377,6 +402,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       vs[li] = (li > q) ? dl : (li == q ? dq_ + sgq * nrm2 : 0.0);
     }
     wave_sync();
+    PINKHIP_TICK(5);  // norms, Householder vector
     // columns below every group's q carry zeros in d2 and v: skip them eight at a time
     const int qlow = groups_min<W>(act ? q : NV);
     double z = 0.0, w = 0.0;
@@ -394,6 +420,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
     }
+    PINKHIP_TICK(6);  // z, w
     // r = P d1, P = R^-1 upper triangular: r_li = sum_m P[li][li + m] d1[li + m], no dependency chain
     double rv = 0.0;
     {
@@ -401,14 +428,20 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 #pragma unroll
       for (int m0 = 0; m0 < NV; m0 += 8) {
         if (m0 < qmax) {
+          double pv[8], dv[8];
 #pragma unroll
-          for (int m = m0; m < m0 + 8; ++m) {
-            rv += Pl[S::doff(m)] * d1l[m];
-            if ((m & (kG - 1)) == kG - 1) pin(rv);
+          for (int m = 0; m < 8; ++m) {
+            pv[m] = Pl[S::doff(m0 + m)];
+            dv[m] = d1l[m0 + m];
           }
+          pin16(pv, dv);  // all 16 operands in flight before the first FMA
+#pragma unroll
+          for (int m = 0; m < 8; ++m) rv += pv[m] * dv[m];
+          pin(rv);
         }
       }
     }
+    PINKHIP_TICK(7);  // r = P d1
     // (c) step lengths
     const bool eq_pos = (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
     const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
@@ -438,6 +471,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       if (li < q) u -= t * rv;
       uplus += t;
     }
+    PINKHIP_TICK(8);  // step lengths, x / u update
     // (d) add: J2 <- J2 (I - beta v v^T), R gains column [d1; -sgq |d2|]
     if (wave_any(do_add)) {
       const double wb = do_add ? beta * w : 0.0;
@@ -469,6 +503,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
     }
     wave_sync();
+    PINKHIP_TICK(9);  // add
     // (e) drop the blocking constraint at active position kd
     if (wave_any(do_drop)) {
       const int idk = group_bcast_i<W>(A, kd);
@@ -480,59 +515,69 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
       wave_sync();
-      // Rotations l = kd .. q-2 restore the triangular form after removing column kd of R.  Their
-      // coefficients (R~[l][l], R~[l+1][l]) are entries l, l+1 of the column of the constraint at
-      // old position l+1, i.e. of +- row i of J (already carrying the earlier rotations), or
-      // J1^T n for a dense row.  P~ = P without row kd gets the same rotations on its columns; lane
-      // li produces NEW row li from old row li (li < kd) or li + 1.
-      // rotation indices any group needs: two wave-uniform bounds, tested per l on the scalar unit
+      // Removing column kd of R leaves a Hessenberg block that rotations G_l (columns l, l+1 of J and of
+      // P, l = kd .. q-2) make triangular again; the new factor is P~ = S^T P G with S^T deleting row kd.
+      // The last column of G = G_kd ... G_{q-2} is orthogonal to range(R S), i.e. proportional to row
+      // kd of P, and a chain of adjacent rotations is determined by its last column: G_l annihilates
+      // the running value a_l (a_kd = p_kd, a_{l+1} = |p_{kd..l+1}|) against p_{l+1}.  All rotations
+      // therefore follow from one prefix sum of squares over row kd of P, in parallel, instead of a
+      // chain of broadcasts through the rotated rows of J.
+      {
+        const bool inrow = do_drop && li >= kd && li < q;
+        const int mk = inrow ? li - kd : 0;
+        const double pc = inrow ? Ts[((mk * (2 * NV + 1 - mk)) >> 1) + kd] : 0.0;  // P[kd][li]
+        const double S = group_scan_sum<W>(pc * pc);
+        const double pn = from_next_lane(pc);
+        const bool rl = do_drop && li >= kd && li < q - 1;
+        const double rs = fast_rsqrt(rl ? S : 1.0), rn = fast_rsqrt(rl ? S + pn * pn : 1.0);
+        const double al = (li == kd) ? pc : S * rs;
+        if (li < NV) {
+          d2s[2 * li] = rl ? pn * rn : 1.0;    // cos
+          d2s[2 * li + 1] = rl ? -al * rn : 0.0;  // sin   (d2s and vs are contiguous and dead here)
+        }
+      }
+      wave_sync();
+      // rotation indices any group needs: two wave-uniform bounds, tested per l on the scalar unit;
+      // inside them a group that does not rotate at l reads the identity
+      constexpr int kRB = 4;  // rotations per batch (reads of a batch in flight together)
       const int l0 = groups_min<W>(do_drop ? kd : NV);
       const int l1 = groups_max<W>(do_drop ? q - 1 : 0);
-      const int ro = (li < kd) ? lv : (lv + 1 < NV ? lv + 1 : 0);
+      const int ro = (li < kd) ? lv : (lv + 1 < NV ? lv + 1 : 0);  // lane li builds NEW row li from old row ro
+      const bool prow = do_drop && li < q - 1;
       double *Po = sm + S::oT + S::prow(ro);  // P[ro][c] = Po[doff(c) + c * ro]
-      static_for<0, NV - 1>([&](auto L) {
-        constexpr int l = decltype(L)::value;
-        const bool rot = do_drop && l >= kd && l < q - 1;
-        if (l >= l0 && l < l1) {
-          const int idn = group_bcast_static_i<W, (l + 1 < W ? l + 1 : 0)>(A);
-          const int kn = idn >> 6;
-          const double xa = group_bcast<W>(Jr[l], idn & (W - 1));
-          const double xb = group_bcast<W>(Jr[l + 1], idn & (W - 1));
-          double ga = (kn == 0) ? xa : -xa, gb = (kn == 0) ? xb : -xb;
-          if (md > 0 && wave_any(rot && kn >= 2)) {
-            const bool dn = rot && kn >= 2;
-            const double gi = (in && dn) ? ((kn == 3) ? Gs[(idn & 31) * GP + li] : -Gs[(idn & 31) * GP + li]) : 0.0;
-            const double sa = group_sum<W>(Jr[l] * gi), sb = group_sum<W>(Jr[l + 1] * gi);
-            if (kn >= 2) {
-              ga = sa;
-              gb = sb;
-            }
-          }
-          const bool nz = rot && gb != 0.0;
-          const double rh = fast_rsqrt(nz ? ga * ga + gb * gb : 1.0);
-          const double cc = nz ? ga * rh : 1.0, ss = nz ? gb * rh : 0.0;
-          const bool prow = rot && li < q - 1;
-          double pa = 0.0, pb = 0.0;
-          int lik = lv, rok = ro;  // pinned: keeps the 2 (NV - 1) lane addresses from being hoisted out of the
-          pin(lik);                // active-set loop, where they would live in (spilled) registers
+      double carry = 0.0;
+      if (prow && ro <= kd) carry = Po[((kd * (2 * NV + 1 - kd)) >> 1) + kd * ro];
+      static_for<0, (NV - 2 + kRB) / kRB>([&](auto LB) {
+        constexpr int lb = decltype(LB)::value * kRB;
+        if (lb + kRB > l0 && lb < l1) {
+          // old entries P[ro][l + 1] are read one column ahead of the writes of new P[li][l]
+          double pb[kRB];
+          int lik = lv, rok = ro;  // pinned: keeps the per-column lane addresses from being hoisted out of
+          pin(lik);                // the active-set loop, where they would live in (spilled) registers
           pin(rok);
-          if (prow) {
-            if (l == kd) {
-              if (ro <= l) pa = Po[S::doff(l) + l * rok];  // column kd still sits at the old row positions
-            } else if (li <= l) {
-              pa = Pk[S::doff(l) + l * lik];  // written at the new positions by the previous rotation
-            }
-            if (ro <= l + 1) pb = Po[S::doff(l + 1) + (l + 1) * rok];
+#pragma unroll
+          for (int k = 0; k < kRB; ++k) {
+            const int l = lb + k;
+            pb[k] = 0.0;
+            if (l < NV - 1 && prow && ro <= l + 1) pb[k] = Po[S::doff(l + 1) + (l + 1) * rok];
           }
           wave_sync();  // every lane has read: old rows are other lanes' new rows
-          if (prow) {
-            if (li <= l) Pk[S::doff(l) + l * lik] = cc * pa + ss * pb;
-            if (li <= l + 1) Pk[S::doff(l + 1) + (l + 1) * lik] = -ss * pa + cc * pb;
+#pragma unroll
+          for (int k = 0; k < kRB; ++k) {
+            const int l = lb + k;
+            if (l < NV - 1) {
+              const double cc = d2s[2 * l], ss = d2s[2 * l + 1];
+              const bool rot = prow && l >= kd && l < q - 1;
+              const double pn_ = cc * carry + ss * pb[k];
+              if (rot) {
+                carry = cc * pb[k] - ss * carry;
+                if (li <= l) Pk[S::doff(l) + l * lik] = pn_;
+              }
+              const double ja = Jr[l], jb = Jr[l + 1];
+              Jr[l] = cc * ja + ss * jb;
+              Jr[l + 1] = cc * jb - ss * ja;
+            }
           }
-          wave_sync();
-          const double ja = Jr[l], jb = Jr[l + 1];
-          Jr[l] = cc * ja + ss * jb;
-          Jr[l + 1] = -ss * ja + cc * jb;
         }
       });
       {
@@ -550,7 +595,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       const double spn = group_bcast<W>(cand, src & (W - 1));
       if (do_drop && !dual_only) sp = (kind < 2) ? spn : sp + t * d2n;
     }
+    PINKHIP_TICK(10);  // drop
   }
+  PINKHIP_TICK(11);  // exit
 
   // ------------------------------------------------------------------ write-out
   if (valid) {

@@ -64,6 +64,17 @@ __device__ __forceinline__ void pin(T &x) {
   asm volatile("" : "+v"(x) : : "memory");
 }
 
+// Pin two groups of eight values at once: the sixteen loads that produce them are all issued
+// before this point and waited for once (hipcc otherwise issues the LDS reads of an accumulation
+// chain pairwise, right before their use, and every pair pays the full LDS latency).
+__device__ __forceinline__ void pin16(const double (&a)[8], const double (&b)[8]) {
+  asm volatile(""
+               :
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]),
+                 "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+               : "memory");
+}
+
 // Broadcast `v` of lane `src` (wave-uniform) to every lane: 2 x v_readlane_b32.
 __device__ __forceinline__ double bcast(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -77,9 +88,18 @@ __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // every lane has a source under these controls: with bound_ctrl set the old value is dead and the
+  // compiler emits the bare v_mov_b32_dpp instead of copy + dpp
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
+}
+// v_min_f64 without the canonicalising v_max_f64 x, x that fmin() gets in IEEE mode (operands here
+// are never signalling NaNs)
+__device__ __forceinline__ double min_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
@@ -210,12 +230,38 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 template <int W>
 __device__ __forceinline__ double group_min(double v) {
-  v = fmin(v, dpp_mov<kDppXor1>(v));
-  v = fmin(v, dpp_mov<kDppXor2>(v));
-  v = fmin(v, dpp_mov<kDppHalfMirror>(v));
-  if (W >= 16) v = fmin(v, dpp_mov<kDppMirror>(v));
-  if (W >= 32) v = fmin(v, swizzle_xor16(v));
-  if (W == 64) v = fmin(bcast(v, 0), bcast(v, 32));
+  v = min_raw(v, dpp_mov<kDppXor1>(v));
+  v = min_raw(v, dpp_mov<kDppXor2>(v));
+  v = min_raw(v, dpp_mov<kDppHalfMirror>(v));
+  if (W >= 16) v = min_raw(v, dpp_mov<kDppMirror>(v));
+  if (W >= 32) v = min_raw(v, swizzle_xor16(v));
+  if (W == 64) v = min_raw(bcast(v, 0), bcast(v, 32));
+  return v;
+}
+// Inclusive prefix sum inside each group of W lanes (lane li gets v_0 + ... + v_li): Hillis-Steele with
+// DPP row shifts inside the rows of 16, then the row totals through row_bcast15 / row_bcast31.
+template <int N>
+__device__ __forceinline__ double dpp_row_shr(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xF, 0xF, true);  // lanes without a source get 0
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int W>
+__device__ __forceinline__ double group_scan_sum(double v) {
+  const int li = lane_id() & (W - 1);
+  double t = dpp_row_shr<1>(v);
+  v += (li >= 1) ? t : 0.0;
+  t = dpp_row_shr<2>(v);
+  v += (li >= 2) ? t : 0.0;
+  t = dpp_row_shr<4>(v);
+  v += (li >= 4) ? t : 0.0;
+  if (W >= 16) {
+    t = dpp_row_shr<8>(v);
+    v += (li >= 8) ? t : 0.0;
+  }
+  if (W >= 32) v += dpp_row_bcast15(v, 0.0);
+  if (W == 64) v += dpp_row_bcast31(v, 0.0);
   return v;
 }
 // max / min over the groups of a group-uniform int (one v_readlane per group).

@@ -1,0 +1,61 @@
+"""Per-section cycle breakdown of the packed solve kernel (profiling build, not shipped).
+
+    python scripts/section_clock.py build      # here: cross-compile libpinkhip_clock.so
+    python scripts/section_clock.py [config]   # on the GPU box: run and print the breakdown
+
+The profiling library is the product source compiled with -DPINKHIP_SECTION_CLOCK: every 64th wave
+adds the s_memtime cycles spent in each section to a device array (ik_kernels_packed.h, PINKHIP_TICK).
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+LIB = os.path.join(ge.CSRC, "libpinkhip_clock.so")
+SECTIONS = ["stacking", "Cholesky", "J = L^-T, x0", "selection", "d = J^T n (row)", "norms, v, sync", "z, w",
+            "r = P d1", "steps, x/u update", "add (J2, P column)", "drop", "exit"]
+
+
+def build():
+    cmd = ["hipcc"] + ge.HIPCC_FLAGS + ["-DPINKHIP_SECTION_CLOCK"] + \
+        [os.path.join(ge.CSRC, s) for s in ge.HIP_SOURCES] + ["-o", LIB]
+    subprocess.run(cmd, check=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+        return
+    os.environ["PINKHIP_LIBRARY"] = LIB
+    import numpy as np
+    from pink_amd import synthetic, _lib
+    from pink_amd.batch_solver import BatchSolver
+    name = sys.argv[1] if len(sys.argv) > 1 else "draco3"
+    bounds = sys.argv[2] if len(sys.argv) > 2 else "tight"
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    s = BatchSolver(0)
+    lib = _lib.load_library()
+    lib.pinkhip_debug_section_clock.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    t = synthetic.make_terms(name, B, bounds=bounds, jacobians="dense" if bounds == "tight" else "kinematic")
+    dev = s.upload(synthetic.pack(t))
+    out = (ctypes.c_uint64 * 16)()
+    s.solve_device(dev)
+    s.sync()
+    lib.pinkhip_debug_section_clock(s._h, out)  # clear the warm-up launch
+    s.timer_start()
+    s.solve_device(dev)
+    ms = s.timer_stop()
+    assert lib.pinkhip_debug_section_clock(s._h, out) == 0
+    r = s.download(dev)
+    c = np.array(list(out), dtype=np.float64)[:len(SECTIONS)]
+    print(f"{name} {bounds} B={B}: {ms:.3f} ms (instrumented), mean iterations {r.iters.mean():.1f}")
+    for n, v in zip(SECTIONS, c):
+        print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / (B / 128):10.0f} cycles per sampled wave")
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,7 @@ inline void emu_rendezvous(int tag) {
 
 inline void wave_sync() { emu_rendezvous(1); }
 inline void sched_fence() {}
+inline void pin16(const double (&)[8], const double (&)[8]) {}
 template <typename T>
 inline void pin(T &) {}
 
@@ -236,6 +237,27 @@ inline double group_sum(double v) {
 template <int W>
 inline double group_min(double v) {
   return emu_group_reduce<W>(v, [](double a, double b) { return std::fmin(a, b); }, 22);
+}
+// same association order as wave.h: shifts by 1, 2, 4, 8 inside the rows of 16, then the row totals
+template <int W>
+inline double group_scan_sum(double v) {
+  const int l = emu().cur, li = l & (W - 1);
+  for (int n = 1; n <= 8; n *= 2) {
+    if (n == 8 && W < 16) break;
+    double t = emu_exchange(v, (l & 15) >= n ? l - n : l, 26);
+    if ((l & 15) < n) t = 0.0;  // row_shr with bound_ctrl: no source inside the row of 16
+    v += (li >= n) ? t : 0.0;
+  }
+  if (W >= 32) {
+    const int row = l >> 4;
+    const double t = emu_exchange(v, (row & 1) ? (row - 1) * 16 + 15 : l, 28);
+    v += (row & 1) ? t : 0.0;
+  }
+  if (W == 64) {
+    const double t = emu_exchange(v, 31, 30);
+    v += (l >= 32) ? t : 0.0;
+  }
+  return v;
 }
 template <int W>
 inline int groups_max(int v) {
