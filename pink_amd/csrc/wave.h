@@ -217,6 +217,16 @@ __device__ __forceinline__ double swizzle_xor16(double v) {
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
   return __hiloint2double(hi, lo);
 }
+// The two rows of 16 lanes of every 32-lane half exchange their values on the VALU (gfx950
+// v_permlane16_swap_b32, no LDS-crossbar round trip): a and b hold, in both rows, the value of the
+// even and of the odd row.
+__device__ __forceinline__ void row_pair(double v, double &a, double &b) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  a = __hiloint2double(rh[0], rl[0]);
+  b = __hiloint2double(rh[1], rl[1]);
+}
 // All-reduce inside each group of W lanes (every lane gets its group's result).
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {
@@ -224,7 +234,11 @@ __device__ __forceinline__ double group_sum(double v) {
   v += dpp_mov<kDppXor2>(v);
   v += dpp_mov<kDppHalfMirror>(v);
   if (W >= 16) v += dpp_mov<kDppMirror>(v);
-  if (W >= 32) v += swizzle_xor16(v);
+  if (W >= 32) {
+    double a, b;
+    row_pair(v, a, b);
+    v = a + b;
+  }
   if (W == 64) v = bcast(v, 0) + bcast(v, 32);
   return v;
 }
@@ -234,7 +248,11 @@ __device__ __forceinline__ double group_min(double v) {
   v = min_raw(v, dpp_mov<kDppXor2>(v));
   v = min_raw(v, dpp_mov<kDppHalfMirror>(v));
   if (W >= 16) v = min_raw(v, dpp_mov<kDppMirror>(v));
-  if (W >= 32) v = min_raw(v, swizzle_xor16(v));
+  if (W >= 32) {
+    double a, b;
+    row_pair(v, a, b);
+    v = min_raw(a, b);
+  }
   if (W == 64) v = min_raw(bcast(v, 0), bcast(v, 32));
   return v;
 }
