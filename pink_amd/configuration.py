@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .exceptions import FrameNotFound, NotWithinConfigurationLimits
-from .lie import SE3, exp3, exp6, log6
+from .lie import SE3, Jlog6, exp3, exp6, log6
 from .utils import VectorSpace
 
 
@@ -150,6 +150,12 @@ class Model:
                 return i
         raise FrameNotFound(name, self.frames)
 
+    def getJointId(self, name: str) -> int:
+        for i, j in enumerate(self.joints):
+            if j.name == name:
+                return i
+        raise FrameNotFound(name, self.joints)
+
     def neutral(self) -> np.ndarray:
         q = np.zeros(self.nq)
         for j in self.joints:
@@ -178,6 +184,17 @@ class Model:
             else:
                 out[j.idx_v] = q1[j.idx_q] - q0[j.idx_q]
         return out
+
+    def d_difference(self, q0: np.ndarray, q1: np.ndarray) -> np.ndarray:
+        """Jacobian of ``q1 (-) q0`` with respect to ``q1`` (``pin.dDifference(..., ARG1)``): identity
+        on vector-space joints, ``Jlog6(T_0^-1 T_1)`` on a free flyer."""
+        q0, q1 = np.asarray(q0, float), np.asarray(q1, float)
+        D = np.eye(self.nv)
+        for j in self.joints:
+            if j.kind == "free_flyer":
+                M = self.joint_transform(j, q0).actInv(self.joint_transform(j, q1))
+                D[j.idx_v:j.idx_v + 6, j.idx_v:j.idx_v + 6] = Jlog6(M)
+        return D
 
     def integrate(self, q: np.ndarray, v: np.ndarray) -> np.ndarray:
         """``q (+) v`` (``pin.integrate``)."""

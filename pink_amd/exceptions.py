@@ -65,3 +65,7 @@ class TaskDefinitionError(PinkError):
 
 class TaskJacobianNotSet(PinkError):
     """A task Jacobian is read before being set."""
+
+
+class NegativeMinimumDistance(PinkError):
+    """A barrier is given a negative minimum distance (``pink/exceptions.py``)."""

@@ -74,6 +74,20 @@ class SE3:
         return self.inverse() * other
 
     @property
+    def action(self) -> np.ndarray:
+        """6 x 6 adjoint acting on twists ``[linear; angular]`` (``pin.SE3.action``)."""
+        R, p = self.rotation, self.translation
+        A = np.zeros((6, 6))
+        A[:3, :3] = R
+        A[:3, 3:] = hat(p) @ R
+        A[3:, 3:] = R
+        return A
+
+    @property
+    def actionInverse(self) -> np.ndarray:
+        return self.inverse().action
+
+    @property
     def np(self) -> np.ndarray:
         T = np.eye(4)
         T[:3, :3] = self.rotation
