@@ -68,7 +68,10 @@ struct LdsP {
   static __host__ __device__ constexpr int prow(int r) { return -((r * (2 * NV - 1 + r)) / 2); }
 };
 
-template <int NV, int W>
+// DENSE = false is the instantiation for problems without dense inequality / equality rows (box limits
+// only, md = 0): every dense-row branch and its state (row slacks, row norms, equality bookkeeping)
+// folds away at compile time.
+template <int NV, int W, bool DENSE = true>
 __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) {
   static_assert(W >= NV && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
@@ -78,7 +81,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 
   const int lane = lane_id();
   const int g = lane / W, li = lane & (W - 1);
-  const int nv = a.nv, Kd = a.Kd, K = a.K, md = a.md, n_eq = a.n_eq;
+  const int nv = a.nv, Kd = a.Kd, K = a.K, md = DENSE ? a.md : 0, n_eq = DENSE ? a.n_eq : 0;
 #ifdef PINKHIP_SECTION_CLOCK
   const bool clock_on = (block & 63) == 0;
   unsigned long long clock_prev = __builtin_readcyclecounter();
@@ -344,7 +347,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       if (sel && !eqsel && none) running = false;  // optimal
       if (sel && !eqsel && !none) {
         bid = key_payload(best);
-        kind = bid >> 6;
+        kind = DENSE ? bid >> 6 : (bid >> 6) & 1;
         src = bid & 63;
         uplus = 0.0;
         need_sel = false;
@@ -365,17 +368,17 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 
     // (b) d = J^T n+
     double dl = 0.0;
-    if (wave_any(act && kind < 2)) {
-      if (act && kind < 2 && li == src) {
+    if (wave_any(act && (!DENSE || kind < 2))) {
+      if (act && (!DENSE || kind < 2) && li == src) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) ds[j] = Jr[j];
       }
       wave_sync();
       const double rowv = (li < NV) ? ds[lv] : 0.0;
-      if (act && kind < 2) dl = (kind == 0) ? rowv : -rowv;
+      if (act && (!DENSE || kind < 2)) dl = (kind == 0) ? rowv : -rowv;
     }
-    if (md > 0 && wave_any(act && kind >= 2)) {
-      const bool dn = act && kind >= 2;
+    if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
+      const bool dn = act && (DENSE && kind >= 2);
       const double gi = (in && dn) ? ((kind == 3) ? Gs[(src & 31) * GP + li] : -Gs[(src & 31) * GP + li]) : 0.0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
@@ -385,9 +388,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     }
     PINKHIP_TICK(4);  // d = J^T n
     double dd = group_bcast<W>(rown2, src & (W - 1));
-    if (md > 0 && wave_any(act && kind >= 2)) {
+    if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
       const double dds = group_sum<W>(dl * dl);
-      if (kind >= 2) dd = dds;
+      if ((DENSE && kind >= 2)) dd = dds;
     }
     const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
     const bool lin_dep = !(d2n > 1e-24 * dd);
@@ -443,7 +446,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     }
     PINKHIP_TICK(7);  // r = P d1
     // (c) step lengths
-    const bool eq_pos = (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
+    const bool eq_pos = DENSE && (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
     const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
     const double ratio = blocking ? u * fast_rcp(rv) : BIG;
     const double k1 = group_min<W>(blocking ? key_pack(ratio, li) : BIG);
@@ -453,7 +456,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
     const double t = (t1 < t2) ? t1 : t2;
     if (act && !(t < INF)) {
-      if (kind >= 2 && src < n_eq && fabs(sp) <= 1e-9 * (1.0 + fabs(hpend))) {
+      if ((DENSE && kind >= 2) && src < n_eq && fabs(sp) <= 1e-9 * (1.0 + fabs(hpend))) {
         // equality implied by the active ones and already satisfied: nothing to add
         ++eq_next;
         need_sel = true;
@@ -496,8 +499,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           if (kind == 0) bstate = 1;
           else if (kind == 1) bstate = 2;
         }
-        if (kind >= 2 && li == (src & 31)) dactive = 1;
-        if (kind >= 2 && src < n_eq) ++eq_next;
+        if ((DENSE && kind >= 2) && li == (src & 31)) dactive = 1;
+        if ((DENSE && kind >= 2) && src < n_eq) ++eq_next;
         ++q;
         need_sel = true;
       }
@@ -508,7 +511,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (wave_any(do_drop)) {
       const int idk = group_bcast_i<W>(A, kd);
       if (do_drop) {
-        if ((idk >> 6) < 2) {
+        if (!DENSE || (idk >> 6) < 2) {
           if (li == (idk & 63)) bstate = 0;
         } else if (li == (idk & 31)) {
           dactive = 0;
@@ -593,7 +596,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       // slack of the pending constraint at the new x (same n+ next trip)
       const double cand = (kind == 0) ? x - lbv : ubv - x;
       const double spn = group_bcast<W>(cand, src & (W - 1));
-      if (do_drop && !dual_only) sp = (kind < 2) ? spn : sp + t * d2n;
+      if (do_drop && !dual_only) sp = ((!DENSE || kind < 2)) ? spn : sp + t * d2n;
     }
     PINKHIP_TICK(10);  // drop
   }
@@ -609,9 +612,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   }
 }
 
-template <int NV, int W>
+template <int NV, int W, bool DENSE>
 __global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV) ik_solve_packed_kernel(KernelArgs a) {
-  ik_packed_instance<NV, W>(a, block_id());
+  ik_packed_instance<NV, W, DENSE>(a, block_id());
 }
 
 }  // namespace pinkhip

@@ -101,7 +101,10 @@ int launch_packed(pinkhip_handle *h, const KernelArgs &a) {
   constexpr int G = pinkhip::kWave / W;
   const size_t lds = static_cast<size_t>(pinkhip::LdsP<NV>::bytes(a.md, G));
   const dim3 grid(static_cast<unsigned>((a.B + G - 1) / G)), block(pinkhip::kWave);
-  hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W>), grid, block, lds, h->stream, a);
+  if (a.md == 0)  // box limits only: the instantiation without the dense-row machinery
+    hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W, false>), grid, block, lds, h->stream, a);
+  else
+    hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W, true>), grid, block, lds, h->stream, a);
   PH_HIP(h, hipGetLastError());
   return PINKHIP_OK;
 }

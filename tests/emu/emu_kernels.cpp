@@ -27,7 +27,10 @@ void lane_main(void *p) {
 template <int NV, int W>
 void lane_main_packed(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
-  pinkhip::ik_packed_instance<NV, W>(*a, pinkhip::block_id());
+  if (a->md == 0)
+    pinkhip::ik_packed_instance<NV, W, false>(*a, pinkhip::block_id());
+  else
+    pinkhip::ik_packed_instance<NV, W, true>(*a, pinkhip::block_id());
 }
 
 template <int NT>
