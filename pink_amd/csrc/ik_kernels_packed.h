@@ -306,6 +306,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 
   for (;;) {
     // (a) selection, for the groups that have no pending constraint
+    double sp_in = 0.0;    // slack of the newly selected constraint: a broadcast whose result is only
+    bool sp_take = false;  // merged into sp where it is first needed (step lengths), not waited for here
     if (wave_any(running && need_sel)) {
       double best = BIG, sd = 0.0;
       const double slo = x - lbv, sup = ubv - x;
@@ -353,8 +355,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         need_sel = false;
       }
       const double cand = (kind == 0) ? slo : (kind == 1) ? sup : sd;
-      const double spn = group_bcast<W>(cand, src & (W - 1));
-      if (sel && !eqsel && !none) sp = spn;
+      sp_in = group_bcast<W>(cand, src & (W - 1));
+      sp_take = sel && !eqsel && !none;
     }
     if (running) {
       if (++it > max_iter) {
@@ -393,7 +395,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       if ((DENSE && kind >= 2)) dd = dds;
     }
     const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
-    const bool lin_dep = !(d2n > 1e-24 * dd);
+    const bool lin_dep = !(d2n * 1e24 > dd);  // (the product sits on d2n: dd's broadcast is waited for after the reduction)
     const double dq_ = group_bcast<W>(dl, q < W ? q : W - 1);
     const double rn2 = lin_dep ? 0.0 : fast_rsqrt(lin_dep ? 1.0 : d2n);
     const double nrm2 = d2n * rn2;
@@ -402,7 +404,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (li < NV) {
       ds[li] = (li < q) ? dl : 0.0;  // d1, followed by the zeros of zs
       d2s[li] = (li >= q) ? dl : 0.0;
-      vs[li] = (li > q) ? dl : (li == q ? dq_ + sgq * nrm2 : 0.0);
+      vs[li] = (li > q) ? dl : (li == q ? dl + ((dl >= 0.0) ? nrm2 : -nrm2) : 0.0);  // lane q holds d_q itself
     }
     wave_sync();
     PINKHIP_TICK(5);  // norms, Householder vector
@@ -453,6 +455,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const int kd = key_payload(k1) & (W - 1);
     const double t1b = group_bcast<W>(ratio, kd);  // unconditional: cross-lane ops must not diverge
     const double t1 = (k1 < BIG) ? t1b : INF;
+    if (sp_take) sp = sp_in;
     const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
     const double t = (t1 < t2) ? t1 : t2;
     if (act && !(t < INF)) {
