@@ -40,9 +40,25 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
   for (int t = 0; t < NT; ++t) cpart[t] = 0.0;
   double mu_l = 0.0;
 
-  // dense rows, 128 at a time through the LDS coefficient table
+  // dense rows, 128 at a time through the LDS coefficient table; inside a pass, 32 rows (eight MFMA
+  // k-steps) of J are requested from HBM at once and the first request goes out before the table is
+  // built, so a wave pays one memory round trip per 32 rows instead of one per k-step
+  constexpr int kSteps = 8;
   for (int r0 = 0; r0 < Kd; r0 += 128) {
     const int rc = (Kd - r0 < 128) ? Kd - r0 : 128;
+    double Jp[kSteps][NT];
+    auto request = [&](int c0) {
+#pragma unroll
+      for (int st = 0; st < kSteps; ++st) {
+        const int kk = c0 + 4 * st + rq;  // this lane's task row inside the pass
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc) {
+          const int j = 16 * tc + col;
+          Jp[st][tc] = (kk < rc && j < nv) ? Jb[(long long)(r0 + kk) * nv + j] : 0.0;
+        }
+      }
+    };
+    request(0);
     wave_sync();
     for (int rr = lane; rr < rc; rr += kWave) {
       const int k = r0 + rr;
@@ -53,23 +69,27 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
       mu_l += l * (g * g) * wa * ev * ev;
     }
     wave_sync();
-    for (int k0 = 0; k0 < rc; k0 += 4) {
-      const int kk = k0 + rq;  // this lane's task row inside the slice
-      const bool krow = kk < rc;
-      const double wa = krow ? was[kk] : 0.0;
-      const double gw = krow ? gws[kk] : 0.0;
-      double Jv[NT], Av[NT];
+    for (int c0 = 0; c0 < rc; c0 += 4 * kSteps) {
+      if (c0 > 0) request(c0);
 #pragma unroll
-      for (int tc = 0; tc < NT; ++tc) {
-        const int j = 16 * tc + col;
-        Jv[tc] = (krow && j < nv) ? Jb[(long long)(r0 + kk) * nv + j] : 0.0;
-        Av[tc] = wa * Jv[tc];
-        cpart[tc] += gw * Jv[tc];
+      for (int st = 0; st < kSteps; ++st) {
+        if (c0 + 4 * st < rc) {  // wave-uniform
+          const int kk = c0 + 4 * st + rq;
+          const bool krow = kk < rc;
+          const double wa = krow ? was[kk] : 0.0;
+          const double gw = krow ? gws[kk] : 0.0;
+          double Av[NT];
+#pragma unroll
+          for (int tc = 0; tc < NT; ++tc) {
+            Av[tc] = wa * Jp[st][tc];
+            cpart[tc] += gw * Jp[st][tc];
+          }
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = mfma_f64_16x16x4(Av[ti], Jp[st][tj], acc[ti][tj]);
+        }
       }
-#pragma unroll
-      for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = mfma_f64_16x16x4(Av[ti], Jv[tj], acc[ti][tj]);
     }
   }
 
