@@ -219,14 +219,31 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   }
   if (!in) ci = 0.0;
 
-  // ------------------------------------------------------------------ Cholesky + forward solve
+  // ------------------------------------------------------------------ Cholesky + forward solve + J = L^-T
   // Column j (unscaled) and the running right-hand side go through LDS; the pivot is read
-  // back from there, so the step needs no cross-lane register traffic.
+  // back from there, so the step needs no cross-lane register traffic.  Row j-1 of L is complete when
+  // step j starts: lane li's forward substitution L y = e_li (J = L^-T, one row per lane) advances by
+  // that row inside step j, its independent FMAs filling the latency of the pivot / rsqrt chain.
   int status = STATUS_OPTIMAL;
   double cp = -ci;
-  wave_sync();
+  double Jr[NV];
+  double rinv_prev = 0.0;
+  auto inverse_row = [&](auto JJ, double rdiag) {
+    constexpr int jj = decltype(JJ)::value;
+    double acc = (li == jj) ? 1.0 : 0.0;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
+    for (int m0 = 0; m0 < jj; m0 += kG) {
+#pragma unroll
+      for (int m = m0; m < m0 + kG; ++m)
+        if (m < jj) acc -= Ts[S::lrow(jj) + m] * Jr[m];
+      pin(acc);
+    }
+    Jr[jj] = acc * rdiag;
+    pin(Jr[jj]);
+  };
+  wave_sync();
+  static_for<0, NV>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
     if (li < NV) {
       xs[li] = M[j];
       ys[li] = cp;
@@ -237,11 +254,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       status = STATUS_NOT_PD;
       p = 1.0;
     }
+    if constexpr (j > 0) inverse_row(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, rinv_prev);
     const double rinv = fast_rsqrt(p);
     const double lij = M[j] * rinv;
     const double tj = lij * rinv;  // M[j] / p
     if (li >= j && li < NV) Ts[S::lrow(li) + j] = lij;
-    if (li == 0) ds[j] = rinv;
     const double yj = ys[j] * rinv;
     cp = (li > j) ? cp - lij * yj : (li == j ? yj : cp);
 #pragma unroll
@@ -253,26 +270,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       for (int m = m0; m < m0 + kG; ++m)
         if (m > j) pin(M[m]);
     }
+    rinv_prev = rinv;
     wave_sync();
-  }
+  });
   if (li < NV) xs[li] = cp;  // y
   wave_sync();
-  PINKHIP_TICK(1);  // Cholesky
-  // J = L^-T
-  double Jr[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    double acc = (li == j) ? 1.0 : 0.0;
-#pragma unroll
-    for (int m0 = 0; m0 < j; m0 += kG) {
-#pragma unroll
-      for (int m = m0; m < m0 + kG; ++m)
-        if (m < j) acc -= Ts[S::lrow(j) + m] * Jr[m];
-      pin(acc);
-    }
-    Jr[j] = acc * ds[j];
-    pin(Jr[j]);
-  }
+  inverse_row(std::integral_constant<int, NV - 1>{}, rinv_prev);
+  PINKHIP_TICK(1);  // Cholesky, J = L^-T
   double rown2 = 0.0;
 #pragma unroll
   for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
