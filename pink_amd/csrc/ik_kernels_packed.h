@@ -48,7 +48,8 @@ template <int NV>
 struct LdsP {
   static constexpr int GP = NV + 1;               // row pitch of the dense inequality rows
   static constexpr int TRI = NV * (NV + 3) / 2;   // packed triangle with one sub-diagonal slot per column
-  static constexpr int RC = (TRI / NV < 32) ? TRI / NV : 32;  // staged J rows per chunk (pitch NV)
+  static constexpr int RC = (TRI / NV < 12) ? TRI / NV : 12;  // staged J rows per chunk (pitch NV); the next
+                                                              // chunk waits in RC * NV / W registers per lane
   static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then P = R^-1
   static constexpr int oD = oT + TRI;             // NV   row of J, then d1   (init: 1/diag(L))
   static constexpr int oZ = oD + NV;              // NV   zeros: d1 read at [li + m] runs into them
@@ -118,31 +119,69 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const double *eb = a.e + b * (long long)K;
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
 
+  // Rows are staged chunk by chunk (RC rows) through LDS.  The HBM requests of chunk c+1 (rows and their
+  // weights) are issued into registers before chunk c is accumulated, so that only the first chunk pays
+  // the memory latency; kernels whose chunk does not fit the register budget stage directly.
+  constexpr int RL = (S::RC * NV + W - 1) / W;  // row entries per lane and chunk
+  constexpr bool kPrefetch = RL <= 20;
+  static_assert(S::RC <= W, "one weight row per lane");
+  double stage[kPrefetch ? RL : 1];
+  double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
+  auto fetch = [&](int r0, int rc) {
+    if constexpr (kPrefetch) {
+      const double *src = Jb + (long long)r0 * nv;
+#pragma unroll
+      for (int t = 0; t < RL; ++t) {
+        const int idx = li + t * W;
+        stage[t] = (idx < rc * nv) ? src[idx] : 0.0;
+      }
+    }
+    if (li < rc) {
+      const int k = r0 + li;
+      pw = costb[k];
+      pe = eb[k];
+      pg = a.row_gain[k];
+      pl = a.row_lm[k];
+    }
+  };
+  if (Kd > 0) fetch(0, Kd < S::RC ? Kd : S::RC);
   for (int r0 = 0; r0 < Kd; r0 += S::RC) {
     const int rc = (Kd - r0 < S::RC) ? Kd - r0 : S::RC;
     wave_sync();
     {  // this group's rows, W lanes wide, LDS pitch NV
-      const double *src = Jb + (long long)r0 * nv;
       int r = li / nv, j = li - r * nv;
       const int dr = W / nv, dj = W - dr * nv;
-      for (int idx = li; idx < rc * nv; idx += W) {
-        Ts[r * NV + j] = src[idx];
-        r += dr;
-        j += dj;
-        if (j >= nv) {
-          j -= nv;
-          ++r;
+      if constexpr (kPrefetch) {
+#pragma unroll
+        for (int t = 0; t < RL; ++t) {
+          if (li + t * W < rc * nv) Ts[r * NV + j] = stage[t];
+          r += dr;
+          j += dj;
+          if (j >= nv) {
+            j -= nv;
+            ++r;
+          }
+        }
+      } else {
+        const double *src = Jb + (long long)r0 * nv;
+        for (int idx = li; idx < rc * nv; idx += W) {
+          Ts[r * NV + j] = src[idx];
+          r += dr;
+          j += dj;
+          if (j >= nv) {
+            j -= nv;
+            ++r;
+          }
         }
       }
     }
-    for (int rr = li; rr < rc; rr += W) {
-      const int k = r0 + rr;
-      const double w = costb[k], ev = eb[k], gn = a.row_gain[k], l = a.row_lm[k];
-      const double wa = w * w;
-      was[rr] = wa;
-      gs[rr] = gn * wa * ev;
-      mu_l += l * (gn * gn) * wa * ev * ev;
+    if (li < rc) {  // RC <= W: one weight row per lane
+      const double wa = pw * pw;
+      was[li] = wa;
+      gs[li] = pg * wa * pe;
+      mu_l += pl * (pg * pg) * wa * pe * pe;
     }
+    if (r0 + S::RC < Kd) fetch(r0 + S::RC, (Kd - r0 - S::RC < S::RC) ? Kd - r0 - S::RC : S::RC);
     wave_sync();
     for (int k = 0; k < rc; ++k) {
       const double *row = Ts + k * NV;
