@@ -347,10 +347,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   int kind = 0, src = 0, bid = 0;
   double sp = 0.0, uplus = 0.0, hpend = 0.0;
 
+  double sp_in = 0.0;    // slack of the pending constraint as broadcast by the selection or the drop: only
+  bool sp_take = false;  // merged into sp where it is first needed (step lengths), not waited for earlier
   for (;;) {
     // (a) selection, for the groups that have no pending constraint
-    double sp_in = 0.0;    // slack of the newly selected constraint: a broadcast whose result is only
-    bool sp_take = false;  // merged into sp where it is first needed (step lengths), not waited for here
     if (wave_any(running && need_sel)) {
       double best = BIG, sd = 0.0;
       const double slo = x - lbv, sup = ubv - x;
@@ -398,8 +398,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         need_sel = false;
       }
       const double cand = (kind == 0) ? slo : (kind == 1) ? sup : sd;
-      sp_in = group_bcast<W>(cand, src & (W - 1));
-      sp_take = sel && !eqsel && !none;
+      const double spn = group_bcast<W>(cand, src & (W - 1));
+      if (sel && !eqsel && !none) {
+        sp_in = spn;
+        sp_take = true;
+      }
     }
     if (running) {
       if (++it > max_iter) {
@@ -499,6 +502,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double t1b = group_bcast<W>(ratio, kd);  // unconditional: cross-lane ops must not diverge
     const double t1 = (k1 < BIG) ? t1b : INF;
     if (sp_take) sp = sp_in;
+    sp_take = false;
     const double t2 = lin_dep ? INF : -sp * rn2 * rn2;
     const double t = (t1 < t2) ? t1 : t2;
     if (act && !(t < INF)) {
@@ -563,7 +567,6 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           dactive = 0;
         }
       }
-      wave_sync();
       // Removing column kd of R leaves a Hessenberg block that rotations G_l (columns l, l+1 of J and of
       // P, l = kd .. q-2) make triangular again; the new factor is P~ = S^T P G with S^T deleting row kd.
       // The last column of G = G_kd ... G_{q-2} is orthogonal to range(R S), i.e. proportional to row
@@ -574,10 +577,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       {
         const bool inrow = do_drop && li >= kd && li < q;
         const int mk = inrow ? li - kd : 0;
-        const double pc = inrow ? Ts[((mk * (2 * NV + 1 - mk)) >> 1) + kd] : 0.0;  // P[kd][li]
-        const double S = group_scan_sum<W>(pc * pc);
-        const double pn = from_next_lane(pc);
         const bool rl = do_drop && li >= kd && li < q - 1;
+        const double pc = inrow ? Ts[((mk * (2 * NV + 1 - mk)) >> 1) + kd] : 0.0;            // P[kd][li]
+        const double pn = rl ? Ts[(((mk + 1) * (2 * NV - mk)) >> 1) + kd] : 0.0;              // P[kd][li + 1]
+        const double S = group_scan_sum<W>(pc * pc);
         const double rs = fast_rsqrt(rl ? S : 1.0), rn = fast_rsqrt(rl ? S + pn * pn : 1.0);
         const double al = (li == kd) ? pc : S * rs;
         if (li < NV) {
@@ -600,7 +603,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         constexpr int lb = decltype(LB)::value * kRB;
         if (lb + kRB > l0 && lb < l1) {
           // old entries P[ro][l + 1] are read one column ahead of the writes of new P[li][l]
-          double pb[kRB];
+          double pb[kRB], cc[kRB], ss[kRB];
           int lik = lv, rok = ro;  // pinned: keeps the per-column lane addresses from being hoisted out of
           pin(lik);                // the active-set loop, where they would live in (spilled) registers
           pin(rok);
@@ -608,23 +611,28 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           for (int k = 0; k < kRB; ++k) {
             const int l = lb + k;
             pb[k] = 0.0;
-            if (l < NV - 1 && prow && ro <= l + 1) pb[k] = Po[S::doff(l + 1) + (l + 1) * rok];
+            cc[k] = 1.0;
+            ss[k] = 0.0;
+            if (l < NV - 1) {
+              if (prow && ro <= l + 1) pb[k] = Po[S::doff(l + 1) + (l + 1) * rok];
+              cc[k] = d2s[2 * l];
+              ss[k] = d2s[2 * l + 1];
+            }
           }
           wave_sync();  // every lane has read: old rows are other lanes' new rows
 #pragma unroll
           for (int k = 0; k < kRB; ++k) {
             const int l = lb + k;
             if (l < NV - 1) {
-              const double cc = d2s[2 * l], ss = d2s[2 * l + 1];
               const bool rot = prow && l >= kd && l < q - 1;
-              const double pn_ = cc * carry + ss * pb[k];
+              const double pn_ = cc[k] * carry + ss[k] * pb[k];
               if (rot) {
-                carry = cc * pb[k] - ss * carry;
+                carry = cc[k] * pb[k] - ss[k] * carry;
                 if (li <= l) Pk[S::doff(l) + l * lik] = pn_;
               }
               const double ja = Jr[l], jb = Jr[l + 1];
-              Jr[l] = cc * ja + ss * jb;
-              Jr[l + 1] = cc * jb - ss * ja;
+              Jr[l] = cc[k] * ja + ss[k] * jb;
+              Jr[l + 1] = cc[k] * jb - ss[k] * ja;
             }
           }
         }
@@ -638,11 +646,12 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
       if (do_drop) --q;
-      wave_sync();
-      // slack of the pending constraint at the new x (same n+ next trip)
+      // slack of the pending constraint at the new x (same n+ next trip); the broadcast is merged into sp
+      // where the next trip needs it
       const double cand = (kind == 0) ? x - lbv : ubv - x;
-      const double spn = group_bcast<W>(cand, src & (W - 1));
-      if (do_drop && !dual_only) sp = ((!DENSE || kind < 2)) ? spn : sp + t * d2n;
+      sp_in = group_bcast<W>(cand, src & (W - 1));
+      sp_take = do_drop && !dual_only && (!DENSE || kind < 2);
+      if (do_drop && !dual_only && DENSE && kind >= 2) sp += t * d2n;
     }
     PINKHIP_TICK(10);  // drop
   }
