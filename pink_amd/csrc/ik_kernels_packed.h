@@ -47,7 +47,8 @@ namespace pinkhip {
 template <int NV>
 struct LdsP {
   static constexpr int GP = NV + 1;               // row pitch of the dense inequality rows
-  static constexpr int TRI = NV * (NV + 3) / 2;   // packed triangle with one sub-diagonal slot per column
+  static constexpr int LEND = NV * (NV + 1) / 2;  // exact packed triangle (L, then P by diagonals)
+  static constexpr int TRI = (NV * (NV + 3) / 2 + 1) & ~1;  // + NV slots a lane may read past its row, even
   static constexpr int RC = (TRI / NV < 12) ? TRI / NV : 12;  // staged J rows per chunk (pitch NV); the next
                                                               // chunk waits in RC * NV / W registers per lane
   static constexpr int oT = 0;                    // TRI  staging of J rows, then L, then P = R^-1
@@ -74,7 +75,7 @@ struct LdsP {
 // folds away at compile time.
 template <int NV, int W, bool DENSE = true>
 __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) {
-  static_assert(W >= NV && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
+  static_assert(W >= NV && NV % 2 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
   constexpr double INF = INFINITY;
@@ -191,9 +192,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 #pragma unroll
       for (int j0 = 0; j0 < NV; j0 += kG) {
 #pragma unroll
-        for (int j = j0; j < j0 + kG; ++j) M[j] += aa * row[j];
+        for (int j = j0; j < j0 + kG; ++j)
+          if (j < NV) M[j] += aa * row[j];
 #pragma unroll
-        for (int j = j0; j < j0 + kG; ++j) pin(M[j]);
+        for (int j = j0; j < j0 + kG; ++j)
+          if (j < NV) pin(M[j]);
       }
     }
   }
@@ -304,10 +307,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
 #pragma unroll
       for (int m = m0; m < m0 + kG; ++m)
-        if (m > j) M[m] -= tj * xs[m];
+        if (m > j && m < NV) M[m] -= tj * xs[m];
 #pragma unroll
       for (int m = m0; m < m0 + kG; ++m)
-        if (m > j) pin(M[m]);
+        if (m > j && m < NV) pin(M[m]);
     }
     rinv_prev = rinv;
     wave_sync();
@@ -329,7 +332,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   PINKHIP_TICK(2);  // J = L^-T, x0
   if (li < NV) {  // L is dead: what the P product may read before it is written has to be finite
     zs[li] = 0.0;
-    Ts[S::TRI - NV + li] = 0.0;
+    Ts[S::LEND + li] = 0.0;
+    if (li == 0 && S::TRI - S::LEND > NV) Ts[S::TRI - 1] = 0.0;
   }
 
   // ------------------------------------------------------------------ Goldfarb-Idnani, flat
@@ -462,11 +466,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       if (j0 + 8 > qlow) {
 #pragma unroll
         for (int j = j0; j < j0 + 8; ++j) {
-          z += Jr[j] * d2s[j];
-          w += Jr[j] * vs[j];
-          if ((j & (kG - 1)) == kG - 1) {
-            pin(z);
-            pin(w);
+          if (j < NV) {
+            z += Jr[j] * d2s[j];
+            w += Jr[j] * vs[j];
+            if ((j & (kG - 1)) == kG - 1 || j == NV - 1) {
+              pin(z);
+              pin(w);
+            }
           }
         }
       }
@@ -482,8 +488,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           double pv[8], dv[8];
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
-            pv[m] = Pl[S::doff(m0 + m)];
-            dv[m] = d1l[m0 + m];
+            pv[m] = (m0 + m < NV) ? Pl[S::doff(m0 + m)] : 0.0;
+            dv[m] = (m0 + m < NV) ? d1l[m0 + m] : 0.0;
           }
           pin16(pv, dv);  // all 16 operands in flight before the first FMA
 #pragma unroll
@@ -532,9 +538,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       for (int j0 = 0; j0 < NV; j0 += 8) {
         if (j0 + 8 > qlow) {
 #pragma unroll
-          for (int j = j0; j < j0 + 8; ++j) Jr[j] -= wb * vs[j];
+          for (int j = j0; j < j0 + 8; ++j)
+            if (j < NV) Jr[j] -= wb * vs[j];
 #pragma unroll
-          for (int j = j0; j < j0 + 8; ++j) pin(Jr[j]);
+          for (int j = j0; j < j0 + 8; ++j)
+            if (j < NV) pin(Jr[j]);
         }
       }
       if (do_add) {

@@ -122,9 +122,13 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   }
   if (solve && h->packed) {
     // several QPs per wavefront when a row group (8 / 16 / 32 lanes) holds the problem
+    // (NV is the smallest instantiated even size >= nv: padded coordinates cost FMAs and LDS traffic)
+    if (a.nv <= 6 && a.md <= 8) return launch_packed<6, 8>(h, a);
     if (a.nv <= 8 && a.md <= 8) return launch_packed<8, 8>(h, a);
+    if (a.nv <= 12 && a.md <= 16) return launch_packed<12, 16>(h, a);
     if (a.nv <= 16 && a.md <= 16) return launch_packed<16, 16>(h, a);
     if (a.nv <= 24) return launch_packed<24, 32>(h, a);
+    if (a.nv <= 30) return launch_packed<30, 32>(h, a);
     if (a.nv <= 32) return launch_packed<32, 32>(h, a);
     // nv > 32: one QP per wavefront, same kernel (packed triangular L / R keeps LDS small)
     if (a.nv <= 40) return launch_packed<40, 64>(h, a);

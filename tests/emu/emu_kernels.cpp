@@ -119,9 +119,12 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   }
   if (solve && packed) {  // same dispatch rule as pinkhip.hip
     int G = 0;
-    if (a.nv <= 8 && a.md <= 8) { fn = lane_main_packed<8, 8>; G = 8; }
+    if (a.nv <= 6 && a.md <= 8) { fn = lane_main_packed<6, 8>; G = 8; }
+    else if (a.nv <= 8 && a.md <= 8) { fn = lane_main_packed<8, 8>; G = 8; }
+    else if (a.nv <= 12 && a.md <= 16) { fn = lane_main_packed<12, 16>; G = 4; }
     else if (a.nv <= 16 && a.md <= 16) { fn = lane_main_packed<16, 16>; G = 4; }
     else if (a.nv <= 24) { fn = lane_main_packed<24, 32>; G = 2; }
+    else if (a.nv <= 30) { fn = lane_main_packed<30, 32>; G = 2; }
     else if (a.nv <= 32) { fn = lane_main_packed<32, 32>; G = 2; }
     else if (a.nv <= 40) { fn = lane_main_packed<40, 64>; G = 1; }
     else if (a.nv <= 48) { fn = lane_main_packed<48, 64>; G = 1; }

@@ -19,7 +19,7 @@ def test_baseline_configs(emu, name, bounds, jac):
     ps.config(emu, name, bounds, jac, B=3 if name == "jvrc" else 5)
 
 
-@pytest.mark.parametrize("nv", [1, 2, 5, 8, 9, 16, 17, 24, 25, 33, 40, 41, 48, 56, 57, 64])
+@pytest.mark.parametrize("nv", [1, 2, 5, 6, 7, 8, 9, 12, 13, 16, 17, 24, 25, 30, 31, 32, 33, 40, 41, 48, 56, 57, 64])
 def test_every_padding_class(emu, nv):
     ps.random_dims(emu, nv, B=2, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
 

@@ -25,7 +25,7 @@ def test_baseline_configs(gpu_solver, name, bounds, jac):
     ps.config(gpu_solver, name, bounds, jac, B=4096 if name == "ur5" else 2048)
 
 
-@pytest.mark.parametrize("nv", [1, 2, 5, 8, 9, 16, 17, 24, 25, 33, 40, 41, 48, 56, 57, 64])
+@pytest.mark.parametrize("nv", [1, 2, 5, 6, 7, 8, 9, 12, 13, 16, 17, 24, 25, 30, 31, 32, 33, 40, 41, 48, 56, 57, 64])
 def test_every_padding_class(gpu_solver, nv):
     ps.random_dims(gpu_solver, nv, B=256, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
 
