@@ -211,6 +211,15 @@ int pinkhip_model_destroy(pinkhip_handle *h, pinkhip_model *model);
 /* q [B,nq] -> T_frames [B,nf,12], J_body [B,nf,6,nv] (device pointers) */
 int pinkhip_fk_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const double *q,
                       double *T_frames, double *J_body);
+/* Forward kinematics and the FrameTask rows of every model frame in one pass (fusion of pinkhip_fk_device
+ * with one pinkhip_frame_task_strided_device per frame; the body Jacobians stay in registers):
+ *   e[b * sE + 6 f + i]              = log6(T_f(q_b)^-1 T_target[b, f])_i               (frame_task.py:181-193)
+ *   J[b * sJ + (6 f + i) * nv + j]   = (-Jlog6(T_target[b, f]^-1 T_f(q_b)) fJ_f(q_b))_ij  (frame_task.py:222-227)
+ * i.e. with sE = K and sJ = Kd * nv the rows land in the packed streams of pinkhip_problem.
+ * T_frames [B,nf,12] is optional (NULL: not written).  All pointers are device pointers. */
+int pinkhip_fk_frame_tasks_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const double *q,
+                                  const double *T_target, double *T_frames, double *e, int64_t sE, double *J,
+                                  int64_t sJ);
 /* q [B,nq], q_target [nq] or [B,nq] -> lb, ub [B,nv]; posture error written into e [B,K] at columns
  * e_off .. e_off + nv - root_nv (e may be NULL) */
 int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double dt,

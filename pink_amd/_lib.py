@@ -89,6 +89,7 @@ ABI_SYMBOLS = (
     "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
+    "pinkhip_fk_frame_tasks_device",
     "pinkhip_limits_posture_device", "pinkhip_integrate_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_destroy",
     "pinkhip_malloc", "pinkhip_free",
@@ -129,6 +130,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_model_create.argtypes = [vp, vp, ctypes.POINTER(vp)]
     lib.pinkhip_model_destroy.argtypes = [vp, vp]
     lib.pinkhip_fk_device.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.pinkhip_fk_frame_tasks_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64]
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]

@@ -233,6 +233,11 @@ class BatchSolver:
     def fk(self, model: int, B: int, q: int, T_frames: int, J_body: int) -> None:
         self._check(self._lib.pinkhip_fk_device(self._h, ctypes.c_void_p(model), B, q, T_frames, J_body))
 
+    def fk_frame_tasks(self, model: int, B: int, q: int, T_target: int, T_frames, e: int, sE: int, J: int, sJ: int) -> None:
+        """Forward kinematics + the FrameTask rows of every model frame in one launch."""
+        self._check(self._lib.pinkhip_fk_frame_tasks_device(self._h, ctypes.c_void_p(model), B, q, T_target, T_frames,
+                                                            e, sE, J, sJ))
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ) -> None:
         self._check(self._lib.pinkhip_frame_task_strided_device(self._h, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ))
 

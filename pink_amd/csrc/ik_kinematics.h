@@ -103,14 +103,30 @@ struct FkArgs {
   ModelDev m;
   long long B;
   const double *q;   // [B, nq]
-  double *T_frames;  // [B, nf, 12]
-  double *J_body;    // [B, nf, 6, nv]
+  double *T_frames;  // [B, nf, 12]      (optional in the fused kernel)
+  double *J_body;    // [B, nf, 6, nv]   (unfused kernel only)
+  // fused kernel: every model frame f carries a FrameTask with target T_target[b, f]; its error goes to
+  // e_out[b * sE + 6 f ..], its Jacobian to rows 6 f .. 6 f + 5 of J_out[b * sJo + ...] (pitch nv), i.e.
+  // straight into the packed e [B, K] / J [B, Kd, nv] streams of the solve kernel
+  const double *T_target = nullptr;  // [B, nf, 12]
+  double *e_out = nullptr;
+  double *J_out = nullptr;
+  long long sE = 0, sJo = 0;
 };
 
-// LDS per instance: oM [nj, 12] + inverse frame poses [nf, 12]
-__device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj + nf); }
+// LDS per instance: oM [nj, 12] + inverse frame poses [nf, 12] + ancestor pointers [nj] + Jlog6 [nf, 36]
+__device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj + nf) + ((nj + 1) & ~1) + 36 * nf; }
 
-template <int W>
+// Forward kinematics and body (LOCAL) frame Jacobians of one instance by a group of W lanes (W >= nj).
+//   1. lane = joint: local transform (sin / cos), pose in the parent frame;
+//   2. composition along the tree by pointer jumping: every joint multiplies its pose by its current
+//      ancestor's and adopts that ancestor's ancestor, ceil(log2(depth)) rounds instead of a serial walk;
+//   3. lane = frame: pose, inverse pose and -- FUSED -- the FrameTask error and Jlog6 of that frame;
+//   4. lane = tangent column: the column of every frame Jacobian, stored (J_body) or -- FUSED -- multiplied
+//      by -Jlog6 and written straight into the rows of the packed task Jacobian.
+// FUSED = true moves 8 (nq + 12 nf + nf (6 + 6 nv)) bytes per instance instead of 8 (nq + 12 nf + 6 nf nv)
+// written by the FK launch and 8 nf (24 + 12 nv + 6) re-read and written by nf frame-task launches.
+template <int W, bool FUSED = false>
 __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.m;
@@ -121,29 +137,50 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   if (!valid) b = a.B - 1;
   double *oM = shared_base() + (long long)g * fk_lds_doubles(m.nj, m.nf);
   double *fMo = oM + 12 * m.nj;  // frame-from-world transforms
+  int *anc = reinterpret_cast<int *>(fMo + 12 * m.nf);
+  double *Jls = fMo + 12 * m.nf + ((m.nj + 1) & ~1);
   const double *q = a.q + b * (long long)m.nq;
 
-  // forward kinematics: the local transforms (sin / cos) in parallel, one joint per lane, then
-  // the composition along the tree by one lane (39 FMAs per joint, parents precede children)
-  for (int j = li; j < m.nj; j += W) {
-    double X[12], Tj[12];
-    joint_transform(m, j, q, Tj);
-    se3_mul(m.placement + 12 * j, Tj, X);
+  // 1. pose of joint li in its parent's frame
+  const bool isj = li < m.nj;
+  const int jl = isj ? li : 0;
+  double T[12];
+  {
+    double Tj[12];
+    joint_transform(m, jl, q, Tj);
+    se3_mul(m.placement + 12 * jl, Tj, T);
+  }
+  int up = isj ? m.parent[jl] : -1;
+  if (isj) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) oM[12 * j + i] = X[i];
+    for (int i = 0; i < 12; ++i) oM[12 * li + i] = T[i];
+    anc[li] = up;
   }
   wave_sync();
-  if (li == 0) {
-    for (int j = 0; j < m.nj; ++j) {
-      if (m.parent[j] >= 0) {
-        double P[12];
-        se3_mul(oM + 12 * m.parent[j], oM + 12 * j, P);
+  // 2. pointer jumping: T_j <- T_up(j) T_j, up(j) <- up(up(j)) until every joint is expressed in the world
+  while (wave_any(up >= 0)) {
+    double P[12];
+    int upup = -1;
+    if (up >= 0) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) oM[12 * j + i] = P[i];
-      }
+      for (int i = 0; i < 12; ++i) P[i] = oM[12 * up + i];
+      upup = anc[up];
     }
+    wave_sync();  // every lane has read the old poses and pointers
+    if (up >= 0) {
+      double N[12];
+      se3_mul(P, T, N);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        T[i] = N[i];
+        oM[12 * li + i] = N[i];
+      }
+      anc[li] = upup;
+      up = upup;
+    }
+    wave_sync();
   }
-  wave_sync();
+  // 3. frames
   for (int f = li; f < m.nf; f += W) {
     double F[12];
     const int fj = m.frame_joint[f];
@@ -153,7 +190,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) F[i] = m.frame_placement[12 * f + i];
     }
-    if (valid) {
+    if (valid && a.T_frames) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) a.T_frames[(b * m.nf + f) * 12 + i] = F[i];
     }
@@ -164,9 +201,24 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
       for (int j = 0; j < 3; ++j) fMo[12 * f + 3 * i + j] = F[3 * j + i];
       fMo[12 * f + 9 + i] = -(F[i] * F[9] + F[3 + i] * F[10] + F[6 + i] * F[11]);
     }
+    if constexpr (FUSED) {
+      double Tt[12], R[9], pr[3], xi[6], Jl[36];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Tt[i] = a.T_target[(b * m.nf + f) * 12 + i];
+      se3_act_inv(F, Tt, R, pr);  // e = log6(T_frame^-1 T_target), frame_task.py:181-193
+      log6(R, pr, xi);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.e_out[b * a.sE + 6 * f + i] = xi[i];
+      }
+      se3_act_inv(Tt, F, R, pr);  // J = -Jlog6(T_target^-1 T_frame) J_body, frame_task.py:222-227
+      jlog6(R, pr, Jl);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) Jls[36 * f + i] = Jl[i];
+    }
   }
   wave_sync();
-  // body Jacobians: lane = tangent column
+  // 4. body Jacobians: lane = tangent column
   for (int j = li; j < m.nv; j += W) {
     const int jt = m.dof_joint[j], sub = m.dof_sub[j], ty = m.jtype[jt];
     for (int f = 0; f < m.nf; ++f) {
@@ -200,8 +252,20 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
         }
       }
       if (valid) {
+        if constexpr (FUSED) {
+          double *Jo = a.J_out + b * a.sJo + (long long)(6 * f) * m.nv;
+          const double *Jl = Jls + 36 * f;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) a.J_body[((b * m.nf + f) * 6 + r) * m.nv + j] = col[r];
+          for (int i = 0; i < 6; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) sacc -= Jl[6 * i + r] * col[r];
+            Jo[i * m.nv + j] = sacc;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) a.J_body[((b * m.nf + f) * 6 + r) * m.nv + j] = col[r];
+        }
       }
     }
   }
@@ -209,7 +273,11 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
 
 template <int W>
 __global__ void __launch_bounds__(kWave) ik_fk_kernel(FkArgs a) {
-  ik_fk_instance<W>(a, block_id());
+  ik_fk_instance<W, false>(a, block_id());
+}
+template <int W>
+__global__ void __launch_bounds__(kWave) ik_fk_frame_tasks_kernel(FkArgs a) {
+  ik_fk_instance<W, true>(a, block_id());
 }
 
 struct LimitsPostureArgs {

@@ -559,10 +559,42 @@ int pinkhip_fk_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, cons
   pinkhip::FkArgs a{m->dev, B, q, T_frames, J_body};
   const int per = pinkhip::fk_lds_doubles(m->dev.nj, m->dev.nf);
   const dim3 block(pinkhip::kWave);
-  if (m->dev.nv <= 32) {
+  const int width = m->dev.nv > m->dev.nj ? m->dev.nv : m->dev.nj;  // lanes per instance: one per joint / column
+  if (width <= 8) {
+    hipLaunchKernelGGL(pinkhip::ik_fk_kernel<8>, dim3((unsigned)((B + 7) / 8)), block, 8 * 8 * per + 16, h->stream, a);
+  } else if (width <= 32) {
     hipLaunchKernelGGL(pinkhip::ik_fk_kernel<32>, dim3((unsigned)((B + 1) / 2)), block, 8 * 2 * per + 16, h->stream, a);
   } else {
     hipLaunchKernelGGL(pinkhip::ik_fk_kernel<64>, dim3((unsigned)B), block, 8 * per + 16, h->stream, a);
+  }
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_fk_frame_tasks_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, const double *q,
+                                  const double *T_target, double *T_frames, double *e, int64_t sE, double *J,
+                                  int64_t sJ) {
+  if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
+  if (B < 0 || B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "bad B");
+  if (B == 0 || m->dev.nf == 0) return PINKHIP_OK;
+  if (!q || !T_target || !e || !J) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  if (sE < 6 * m->dev.nf || sJ < 6LL * m->dev.nf * m->dev.nv) return fail(h, PINKHIP_E_INVALID, "strides smaller than the frame rows");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::FkArgs a{m->dev, B, q, T_frames, nullptr};
+  a.T_target = T_target;
+  a.e_out = e;
+  a.J_out = J;
+  a.sE = sE;
+  a.sJo = sJ;
+  const int per = pinkhip::fk_lds_doubles(m->dev.nj, m->dev.nf);
+  const dim3 block(pinkhip::kWave);
+  const int width = m->dev.nv > m->dev.nj ? m->dev.nv : m->dev.nj;
+  if (width <= 8) {
+    hipLaunchKernelGGL(pinkhip::ik_fk_frame_tasks_kernel<8>, dim3((unsigned)((B + 7) / 8)), block, 8 * 8 * per + 16, h->stream, a);
+  } else if (width <= 32) {
+    hipLaunchKernelGGL(pinkhip::ik_fk_frame_tasks_kernel<32>, dim3((unsigned)((B + 1) / 2)), block, 8 * 2 * per + 16, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(pinkhip::ik_fk_frame_tasks_kernel<64>, dim3((unsigned)B), block, 8 * per + 16, h->stream, a);
   }
   PH_HIP(h, hipGetLastError());
   return PINKHIP_OK;

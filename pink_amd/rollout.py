@@ -5,8 +5,8 @@ robot at a time (``examples/inverse_kinematics_ur10.py:75-91``, ``tests/test_sol
 :160-210``).  ``DeviceRollout`` keeps ``B`` robots resident in HBM and runs every stage of a
 step as a HIP kernel, with no host round trip between steps:
 
-    forward kinematics + body Jacobians      pinkhip_fk_device
-    FrameTask e, J (log6 / Jlog6)            pinkhip_frame_task_strided_device (one launch per task)
+    forward kinematics + FrameTask e, J      pinkhip_fk_frame_tasks_device (one fused launch; ``fused=False``:
+                                             pinkhip_fk_device + one pinkhip_frame_task_strided_device per task)
     box limits + PostureTask error           pinkhip_limits_posture_device
     stack + QP solve                         pinkhip_solve_device
     q <- q (+) dq                            pinkhip_integrate_device
@@ -98,8 +98,10 @@ class DeviceRollout:
 
     def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
-                 config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0):
+                 config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
+                 fused: bool = True):
         self.api, self.model, self.dt = api, model, float(dt)
+        self.fused = bool(fused)  # FK + FrameTask rows in one launch (False: FK, then one launch per task)
         self.B = B = int(q0.shape[0])
         self.nv, self.nq = model.nv, model.nq
         self.frames = [ft[0] for ft in frame_tasks]
@@ -171,11 +173,15 @@ class DeviceRollout:
     def step(self) -> None:
         """Enqueue one IK step for every robot (asynchronous)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
-        a.fk(self.dmodel, B, self.d_q, self.d_T, self.d_Jb)
-        for t in range(nf):
-            a.frame_task_strided(B, nv, self.d_T + 8 * 12 * t, 12 * nf, self.d_Tt + 8 * 12 * t, 12 * nf,
-                                 self.d_Jb + 8 * 6 * nv * t, 6 * nv * nf, self.d_e + 8 * 6 * t, self.K,
-                                 self.d_J + 8 * 6 * nv * t, self.Kd * nv)
+        if self.fused:
+            if nf:
+                a.fk_frame_tasks(self.dmodel, B, self.d_q, self.d_Tt, self.d_T, self.d_e, self.K, self.d_J, self.Kd * nv)
+        else:  # one launch for FK, one per FrameTask (kept for A/B runs and as a cross-check of the fusion)
+            a.fk(self.dmodel, B, self.d_q, self.d_T, self.d_Jb)
+            for t in range(nf):
+                a.frame_task_strided(B, nv, self.d_T + 8 * 12 * t, 12 * nf, self.d_Tt + 8 * 12 * t, 12 * nf,
+                                     self.d_Jb + 8 * 6 * nv * t, 6 * nv * nf, self.d_e + 8 * 6 * t, self.K,
+                                     self.d_J + 8 * 6 * nv * t, self.Kd * nv)
         a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
                          self.d_e if self.n_post else None, self.K, self.Kd)
         a.solve_raw(self.desc, self.problem, self.result)

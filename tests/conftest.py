@@ -112,6 +112,11 @@ class EmuSolver:
         self.lib.pinkhip_emu_fk.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
         self.lib.pinkhip_emu_fk(model, B, q, T_frames, J_body)
 
+    def fk_frame_tasks(self, model, B, q, T_target, T_frames, e, sE, J, sJ):
+        vp, ll = ctypes.c_void_p, ctypes.c_longlong
+        self.lib.pinkhip_emu_fk_frame_tasks.argtypes = [vp, ll, vp, vp, vp, vp, ll, vp, ll]
+        self.lib.pinkhip_emu_fk_frame_tasks(model, B, q, T_target, T_frames, e, sE, J, sJ)
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ):
         vp, ll = ctypes.c_void_p, ctypes.c_longlong
         self.lib.pinkhip_emu_frame_task_strided.argtypes = [ll, ctypes.c_int, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll]

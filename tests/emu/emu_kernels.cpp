@@ -148,6 +148,11 @@ void lane_main_fk(void *p) {
   pinkhip::ik_fk_instance<W>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
 }
 
+template <int W>
+void lane_main_fk_fused(void *p) {
+  pinkhip::ik_fk_instance<W, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
+}
+
 struct EmuModel {
   pinkhip::ModelImage image;
   pinkhip::ModelDev dev;
@@ -173,10 +178,32 @@ int pinkhip_emu_model_destroy(void *m) {
 int pinkhip_emu_fk(void *mp, long long B, const double *q, double *T_frames, double *J_body) {
   EmuModel *m = static_cast<EmuModel *>(mp);
   pinkhip::FkArgs a{m->dev, B, q, T_frames, J_body};
-  if (m->dev.nv <= 32) {
+  const int width = m->dev.nv > m->dev.nj ? m->dev.nv : m->dev.nj;
+  if (width <= 8) {
+    for (long long b = 0; b < (B + 7) / 8; ++b) pinkhip::emu_run_block(b, lane_main_fk<8>, &a);
+  } else if (width <= 32) {
     for (long long b = 0; b < (B + 1) / 2; ++b) pinkhip::emu_run_block(b, lane_main_fk<32>, &a);
   } else {
     for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_fk<64>, &a);
+  }
+  return PINKHIP_OK;
+}
+int pinkhip_emu_fk_frame_tasks(void *mp, long long B, const double *q, const double *T_target, double *T_frames,
+                               double *e, long long sE, double *J, long long sJ) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::FkArgs a{m->dev, B, q, T_frames, nullptr};
+  a.T_target = T_target;
+  a.e_out = e;
+  a.J_out = J;
+  a.sE = sE;
+  a.sJo = sJ;
+  const int width = m->dev.nv > m->dev.nj ? m->dev.nv : m->dev.nj;
+  if (width <= 8) {
+    for (long long b = 0; b < (B + 7) / 8; ++b) pinkhip::emu_run_block(b, lane_main_fk_fused<8>, &a);
+  } else if (width <= 32) {
+    for (long long b = 0; b < (B + 1) / 2; ++b) pinkhip::emu_run_block(b, lane_main_fk_fused<32>, &a);
+  } else {
+    for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_fk_fused<64>, &a);
   }
   return PINKHIP_OK;
 }

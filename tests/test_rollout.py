@@ -5,7 +5,7 @@ import pytest
 
 import pink_amd
 from pink_amd import Configuration, FrameTask, PostureTask, build_chain, solve_ik
-from pink_amd.lie import SE3, exp6
+from pink_amd.lie import SE3, exp3, exp6
 from pink_amd.rollout import DeviceRollout, ModelArrays, pose12
 from pink_amd.runtime import set_default_solver
 
@@ -175,3 +175,45 @@ def test_closed_loop_matches_host_loop_and_converges(api, which):
             assert np.abs(Ta.translation - Tb.translation).max() < 1e-8 and np.abs(Ta.rotation - Tb.rotation).max() < 1e-8
         assert np.linalg.norm(host_tasks[b][0].compute_error(cd)) < e0  # the loop makes progress on every robot
     ro.free()
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_fused_fk_frame_tasks_equal_separate_launches(api, which):
+    """pinkhip_fk_frame_tasks_device writes the same e / J rows into the packed streams as
+    pinkhip_fk_device followed by one pinkhip_frame_task_strided_device per task."""
+    model, frames = _models()[which]
+    rng = np.random.default_rng(30 + which)
+    B = 5
+    q0 = _random_q(model, B, rng)
+    if which == 1:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    specs = [(f, 1.0, 0.5, 1.0, 1e-3) for f in frames]
+    targets = np.zeros((B, len(frames), 12))
+    for b in range(B):
+        cfg = Configuration(model, q0[b])
+        for i, f in enumerate(frames):
+            tgt = cfg.get_transform_frame_to_world(f) * SE3(exp3(0.4 * rng.normal(size=3)), 0.1 * rng.normal(size=3))
+            targets[b, i] = pose12(tgt)
+    rows = []
+    for fused in (True, False):
+        ro = DeviceRollout(api, model, q0, specs, 5e-3, posture_cost=1e-2, fused=fused)
+        ro.set_targets(targets)
+        ro.step()
+        api.sync()
+        e = np.zeros((B, ro.K))
+        J = np.zeros((B, ro.Kd, ro.nv))
+        api.get(e, ro.d_e)
+        api.get(J, ro.d_J)
+        rows.append((e, J, ro.frame_poses()))
+        ro.free()
+    assert np.abs(rows[0][0] - rows[1][0]).max() < 1e-13
+    assert np.abs(rows[0][1] - rows[1][1]).max() < 1e-13
+    assert np.abs(rows[0][2] - rows[1][2]).max() < 1e-14
+    # and the rows are the host FrameTask's (frame_task.py:176-227)
+    for b in range(B):
+        cfg = Configuration(model, q0[b])
+        for i, f in enumerate(frames):
+            t = FrameTask(f, 1.0, 0.5)
+            t.set_target(SE3(targets[b, i, :9].reshape(3, 3), targets[b, i, 9:]))
+            assert np.abs(t.compute_error(cfg) - rows[0][0][b, 6 * i:6 * i + 6]).max() < 1e-10
+            assert np.abs(t.compute_jacobian(cfg) - rows[0][1][b, 6 * i:6 * i + 6]).max() < 1e-9
