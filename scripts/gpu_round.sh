@@ -13,3 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only > /dev/null 2> gpurun_out/pmc_$c.err
 done
 ls -R gpurun_out/pmc_FETCH_SIZE | head
+# closed loop on the device: bench line + kernel stats
+python scripts/rollout_bench.py > gpurun_out/rollout_bench.txt 2>&1; tail -2 gpurun_out/rollout_bench.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rollout -o r01 -- python scripts/rollout_bench.py > /dev/null 2> gpurun_out/prof_rollout.err
