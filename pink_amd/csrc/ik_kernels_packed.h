@@ -7,7 +7,7 @@
 // advances 64/W QPs.  What changes with respect to the one-QP-per-wave kernel:
 //   * values that were wave-uniform (q, the selected constraint, step lengths, ...) become
 //     group-uniform and live in VGPRs; broadcasts from a data-dependent lane use ds_bpermute,
-//     from a compile-time lane ds_swizzle, reductions are DPP butterflies inside the group;
+//     reductions are DPP butterflies inside the group (row pairs through v_permlane16_swap);
 //   * the active-set iteration is a flat state machine: each trip of the loop is one
 //     Goldfarb-Idnani step for every group that is still running; add / drop / select
 //     sections are executed when any group needs them and are predicated per group;

@@ -194,29 +194,6 @@ template <int W>
 __device__ __forceinline__ int group_bcast_i(int v, int src) {
   return lane_shfl_i(v, (lane_id() & ~(W - 1)) | src);
 }
-// Same with a compile-time source lane: ds_swizzle bit mode (no address register).
-template <int W, int K>
-__device__ __forceinline__ double group_bcast_static(double v) {
-  static_assert(K < W, "source lane outside the group");
-  if constexpr (W == 64) return bcast(v, K);  // one group: plain v_readlane
-  constexpr int pattern = ((~(W - 1)) & 0x1F) | (K << 5);
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
-  return __hiloint2double(hi, lo);
-}
-template <int W, int K>
-__device__ __forceinline__ int group_bcast_static_i(int v) {
-  static_assert(K < W, "source lane outside the group");
-  if constexpr (W == 64) return bcast_i(v, K);
-  constexpr int pattern = ((~(W - 1)) & 0x1F) | (K << 5);
-  return __builtin_amdgcn_ds_swizzle(v, pattern);
-}
-__device__ __forceinline__ double swizzle_xor16(double v) {
-  constexpr int pattern = (0x10 << 10) | 0x1F;
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
-  return __hiloint2double(hi, lo);
-}
 // The two rows of 16 lanes of every 32-lane half exchange their values on the VALU (gfx950
 // v_permlane16_swap_b32, no LDS-crossbar round trip): a and b hold, in both rows, the value of the
 // even and of the odd row.

@@ -207,18 +207,6 @@ inline int group_bcast_i(int v, int src) {
   if (src < 0 || src >= W) std::abort();
   return lane_shfl_i(v, (emu().cur & ~(W - 1)) | src);
 }
-template <int W, int K>
-inline double group_bcast_static(double v) {
-  static_assert(K < W, "");
-  if (W == 64) return bcast(v, K);
-  return lane_shfl(v, (emu().cur & ~(W - 1)) | K);
-}
-template <int W, int K>
-inline int group_bcast_static_i(int v) {
-  static_assert(K < W, "");
-  if (W == 64) return bcast_i(v, K);
-  return lane_shfl_i(v, (emu().cur & ~(W - 1)) | K);
-}
 template <int W, class Op>
 inline double emu_group_reduce(double v, Op op, int tag) {
   const int l = emu().cur;
