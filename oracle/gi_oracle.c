@@ -12,10 +12,11 @@
  * (not vendored, not pinned in pixi.lock/uv.lock, not installable offline).  It
  * implements the dual active-set method of Goldfarb & Idnani (Math. Prog. 27,
  * 1983); this file restates that published algorithm in its updating form
- * (J = L^-T Q, R triangular, Givens add/drop).  PARITY UNPINNED for the solve
- * half: the reference ships no golden dq; see oracle/pink_oracle.py header for
- * how it is anchored (KKT certificate, BVLS cross-check, second independent
- * implementation in NumPy).
+ * (J = L^-T Q, R triangular, Givens add/drop).  PARITY UNPINNED by a run of the
+ * reference for the solve half: it ships no golden dq; see oracle/pink_oracle.py
+ * header for how it is anchored (the known answers quadprog / qpsolvers publish,
+ * tests/test_published_qp.py; KKT certificate; BVLS and SLSQP cross-checks; a
+ * second independent implementation in NumPy).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (pink_amd / libpinkhip.so) never does.

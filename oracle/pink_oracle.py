@@ -15,17 +15,21 @@ Parity status
   against the known-answer tests the reference holds for this boundary
   (``tests/test_frame_task.py:123-141``, ``tests/test_low_acceleration_task.py
   :34-42``, ``tests/test_damping_task.py:34-39``).
-* QP-solve half (``goldfarb_idnani``): PARITY UNPINNED by the reference.  The
-  arithmetic lives in the third-party package ``quadprog`` (reached through
+* QP-solve half (``goldfarb_idnani``): PARITY UNPINNED by a run of the reference.
+  The arithmetic lives in the third-party package ``quadprog`` (reached through
   ``qpsolvers.solve_problem`` at ``pink/solve_ik.py:270``); neither package is
   vendored, pinned (quadprog appears in no lock file) or installable here, and
   the reference's tests contain no golden dq.  The restatement follows the
   published algorithm (D. Goldfarb, A. Idnani, "A numerically stable dual
   method for solving strictly convex quadratic programs", Math. Prog. 27,
-  1983), which is what quadprog implements.  It is anchored by (i) uniqueness
-  of the minimiser of a strictly convex QP plus the KKT certificate computed by
-  ``kkt_residuals``, (ii) ``scipy.optimize.lsq_linear(method="bvls")`` on
-  box-only problems, (iii) the properties the reference's solve tests assert
+  1983), which is what quadprog implements.  It is anchored by (i) the known
+  answers those packages publish: the Goldfarb-Idnani worked example documented
+  for quadprog's ``solve.QP`` (solution, multipliers, active set) and the example
+  of the qpsolvers README (inequalities + an equality), both in
+  ``tests/test_published_qp.py``; (ii) uniqueness of the minimiser of a strictly
+  convex QP plus the KKT certificate computed by ``kkt_residuals``; (iii)
+  ``scipy.optimize.lsq_linear(method="bvls")`` on box-only problems and SLSQP on
+  the published examples; (iv) the properties the reference's solve tests assert
   (``tests/test_solve_ik.py:79-102``).
 
 All ``file:line`` citations are relative to the reference checkout.
