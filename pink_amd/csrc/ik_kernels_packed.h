@@ -80,6 +80,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;
+  // groups made of whole rows of 16 lanes multiply lane-held vectors into lane-local accumulators with the
+  // broadcast-FMA of wave.h (no LDS); 8-lane groups keep the LDS broadcast
+  constexpr bool kBc = W >= 16;
+  using BcT = Bcast<(W >= 16 ? W : 16)>;
 
   const int lane = lane_id();
   const int g = lane / W, li = lane & (W - 1);
@@ -451,27 +455,44 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double nrm2 = d2n * rn2;
     const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
     const double beta = lin_dep ? 0.0 : rn2 * fast_rcp(lin_dep ? 1.0 : nrm2 + fabs(dq_));
+    const double vv = (li > q) ? dl : (li == q ? dl + ((dl >= 0.0) ? nrm2 : -nrm2) : 0.0);  // lane q holds d_q itself
     if (li < NV) {
       ds[li] = (li < q) ? dl : 0.0;  // d1, followed by the zeros of zs
-      d2s[li] = (li >= q) ? dl : 0.0;
-      vs[li] = (li > q) ? dl : (li == q ? dl + ((dl >= 0.0) ? nrm2 : -nrm2) : 0.0);  // lane q holds d_q itself
+      if constexpr (!kBc) d2s[li] = (li >= q) ? dl : 0.0;
+      vs[li] = vv;  // read back by the Householder update of (d)
     }
     wave_sync();
     PINKHIP_TICK(5);  // norms, Householder vector
     // columns below every group's q carry zeros in d2 and v: skip them eight at a time
     const int qlow = groups_min<W>(act ? q : NV);
     double z = 0.0, w = 0.0;
+    if constexpr (kBc) {
+      // d2 and v live in the lanes: entry j is lane j's, fed to every lane's FMA by the DPP broadcast
+      const BcT d2b = bcast_prepare<W>((li >= q && li < NV) ? dl : 0.0);
+      const BcT vb = bcast_prepare<W>(li < NV ? vv : 0.0);
+      static_for<0, (NV + 7) / 8>([&](auto J8) {
+        constexpr int j0 = decltype(J8)::value * 8;
+        if (j0 + 8 > qlow) {
+          static_for<j0, (j0 + 8 < NV ? j0 + 8 : NV)>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            z = fma_bcast<W, j>(z, d2b, Jr[j]);
+            w = fma_bcast<W, j>(w, vb, Jr[j]);
+          });
+        }
+      });
+    } else {
 #pragma unroll
-    for (int j0 = 0; j0 < NV; j0 += 8) {
-      if (j0 + 8 > qlow) {
+      for (int j0 = 0; j0 < NV; j0 += 8) {
+        if (j0 + 8 > qlow) {
 #pragma unroll
-        for (int j = j0; j < j0 + 8; ++j) {
-          if (j < NV) {
-            z += Jr[j] * d2s[j];
-            w += Jr[j] * vs[j];
-            if ((j & (kG - 1)) == kG - 1 || j == NV - 1) {
-              pin(z);
-              pin(w);
+          for (int j = j0; j < j0 + 8; ++j) {
+            if (j < NV) {
+              z += Jr[j] * d2s[j];
+              w += Jr[j] * vs[j];
+              if ((j & (kG - 1)) == kG - 1 || j == NV - 1) {
+                pin(z);
+                pin(w);
+              }
             }
           }
         }
@@ -534,15 +555,18 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     // (d) add: J2 <- J2 (I - beta v v^T), R gains column [d1; -sgq |d2|]
     if (wave_any(do_add)) {
       const double wb = do_add ? beta * w : 0.0;
+      // (the update reads v back from LDS: a broadcast-FMA writing J in place costs registers, measured)
+      {
 #pragma unroll
-      for (int j0 = 0; j0 < NV; j0 += 8) {
-        if (j0 + 8 > qlow) {
+        for (int j0 = 0; j0 < NV; j0 += 8) {
+          if (j0 + 8 > qlow) {
 #pragma unroll
-          for (int j = j0; j < j0 + 8; ++j)
-            if (j < NV) Jr[j] -= wb * vs[j];
+            for (int j = j0; j < j0 + 8; ++j)
+              if (j < NV) Jr[j] -= wb * vs[j];
 #pragma unroll
-          for (int j = j0; j < j0 + 8; ++j)
-            if (j < NV) pin(Jr[j]);
+            for (int j = j0; j < j0 + 8; ++j)
+              if (j < NV) pin(Jr[j]);
+          }
         }
       }
       if (do_add) {

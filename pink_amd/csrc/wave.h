@@ -204,6 +204,61 @@ __device__ __forceinline__ void row_pair(double v, double &a, double &b) {
   a = __hiloint2double(rh[0], rl[0]);
   b = __hiloint2double(rh[1], rl[1]);
 }
+// Same between the two halves of the wave (v_permlane32_swap_b32): a = value of the lower 32 lanes, b = value
+// of the upper 32 lanes, in both halves.
+__device__ __forceinline__ void half_pair(double v, double &a, double &b) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  a = __hiloint2double(rh[0], rl[0]);
+  b = __hiloint2double(rh[1], rl[1]);
+}
+
+// ---- broadcast-FMA: acc + (value held by lane J of the group) * x in ONE VALU instruction ----
+// gfx90a+ allow a DPP operand on the double-precision VOP2 v_fmac_f64 with the row_newbcast controls
+// (lane K of every row of 16 lanes feeds the whole row; measured on MI355X at the rate of a plain
+// v_fmac_f64, scripts/probes/dpp64_probe.hip).  A group-uniform vector whose entry j lives in lane j --
+// the Householder vector, a Cholesky column, a staged task row -- therefore multiplies into lane-local
+// accumulators without going through LDS at all: no ds_write, no barrier, no broadcast ds_read.
+// Bcast<W> holds one copy of the lane-held value per row of the group (W = 32: the value of the even and of
+// the odd row, W = 64: of the four rows), made by bcast_prepare() with permlane swaps.
+template <int W>
+struct Bcast {
+  static_assert(W == 16 || W == 32 || W == 64, "broadcast-FMA groups are whole rows of 16 lanes");
+  double r[W / 16];
+};
+template <int W>
+__device__ __forceinline__ Bcast<W> bcast_prepare(double v) {
+  Bcast<W> b;
+  if constexpr (W == 16) {
+    b.r[0] = v;
+    asm volatile("s_nop 1" : "+v"(b.r[0]));  // VALU write -> DPP read: two wait states, unknown to the compiler
+  } else if constexpr (W == 32) {
+    row_pair(v, b.r[0], b.r[1]);
+    asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]));
+  } else {
+    double e, o;
+    row_pair(v, e, o);
+    half_pair(e, b.r[0], b.r[2]);
+    half_pair(o, b.r[1], b.r[3]);
+    asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]));
+  }
+  return b;
+}
+template <int W, int J>
+__device__ __forceinline__ double fma_bcast(double acc, const Bcast<W> &b, double x) {
+  static_assert(J >= 0 && J < W, "source lane outside the group");
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(b.r[J / 16]), "v"(x), "n"(J % 16));
+  return acc;
+}
+// the value itself, group-uniform
+template <int W, int J>
+__device__ __forceinline__ double value_bcast(const Bcast<W> &b) {
+  return fma_bcast<W, J>(0.0, b, 1.0);
+}
+
 // All-reduce inside each group of W lanes (every lane gets its group's result).
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {

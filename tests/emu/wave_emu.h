@@ -207,6 +207,25 @@ inline int group_bcast_i(int v, int src) {
   if (src < 0 || src >= W) std::abort();
   return lane_shfl_i(v, (emu().cur & ~(W - 1)) | src);
 }
+// broadcast-FMA (wave.h: v_fmac_f64 with a DPP row_newbcast operand): here one rendezvous per use
+template <int W>
+struct Bcast {
+  double v;
+};
+template <int W>
+inline Bcast<W> bcast_prepare(double v) {
+  return Bcast<W>{v};
+}
+template <int W, int J>
+inline double fma_bcast(double acc, const Bcast<W> &b, double x) {
+  static_assert(J >= 0 && J < W, "");
+  const double s = emu_exchange(b.v, (emu().cur & ~(W - 1)) | J, 32);
+  return std::fma(s, x, acc);
+}
+template <int W, int J>
+inline double value_bcast(const Bcast<W> &b) {
+  return fma_bcast<W, J>(0.0, b, 1.0);
+}
 template <int W, class Op>
 inline double emu_group_reduce(double v, Op op, int tag) {
   const int l = emu().cur;
