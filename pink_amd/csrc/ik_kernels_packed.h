@@ -290,12 +290,24 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   wave_sync();
   static_for<0, NV>([&](auto Jc) {
     constexpr int j = decltype(Jc)::value;
-    if (li < NV) {
-      xs[li] = M[j];
-      ys[li] = cp;
+    double p, yraw;
+    BcT xb;
+    if constexpr (kBc) {
+      // column j (lane m holds H~[m][j]) and the right-hand side stay in the lanes: pivot, y_j and the
+      // trailing update read them through the DPP broadcast -- no LDS write, no barrier, no read-back
+      xb = bcast_prepare<W>(li < NV ? M[j] : 0.0);
+      const BcT yb = bcast_prepare<W>(cp);
+      p = value_bcast<W, j>(xb);
+      yraw = value_bcast<W, j>(yb);
+    } else {
+      if (li < NV) {
+        xs[li] = M[j];
+        ys[li] = cp;
+      }
+      wave_sync();
+      p = xs[j];
+      yraw = ys[j];
     }
-    wave_sync();
-    double p = xs[j];
     if (!(p > 0.0)) {
       status = STATUS_NOT_PD;
       p = 1.0;
@@ -305,21 +317,31 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double lij = M[j] * rinv;
     const double tj = lij * rinv;  // M[j] / p
     if (li >= j && li < NV) Ts[S::lrow(li) + j] = lij;
-    const double yj = ys[j] * rinv;
+    const double yj = yraw * rinv;
     cp = (li > j) ? cp - lij * yj : (li == j ? yj : cp);
+    if constexpr (kBc) {
+      const double ntj = -tj;
+      static_for<j + 1, NV>([&](auto Mc) {
+        constexpr int m = decltype(Mc)::value;
+        M[m] = fma_bcast<W, m>(M[m], xb, ntj);
+      });
+    } else {
 #pragma unroll
-    for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
+      for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
 #pragma unroll
-      for (int m = m0; m < m0 + kG; ++m)
-        if (m > j && m < NV) M[m] -= tj * xs[m];
+        for (int m = m0; m < m0 + kG; ++m)
+          if (m > j && m < NV) M[m] -= tj * xs[m];
 #pragma unroll
-      for (int m = m0; m < m0 + kG; ++m)
-        if (m > j && m < NV) pin(M[m]);
+        for (int m = m0; m < m0 + kG; ++m)
+          if (m > j && m < NV) pin(M[m]);
+      }
     }
     rinv_prev = rinv;
-    wave_sync();
+    wave_sync();  // L[.][j] is in LDS for the forward substitution of the next step
   });
-  if (li < NV) xs[li] = cp;  // y
+  if constexpr (!kBc) {
+    if (li < NV) xs[li] = cp;  // y
+  }
   wave_sync();
   inverse_row(std::integral_constant<int, NV - 1>{}, rinv_prev);
   PINKHIP_TICK(1);  // Cholesky, J = L^-T
@@ -327,10 +349,18 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
 #pragma unroll
   for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
   double x = 0.0;
+  if constexpr (kBc) {
+    const BcT yb = bcast_prepare<W>(li < NV ? cp : 0.0);  // y_j lives in lane j
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      x = fma_bcast<W, j>(x, yb, Jr[j]);
+    });
+  } else {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    x += Jr[j] * xs[j];
-    if ((j & (kG - 1)) == kG - 1) pin(x);
+    for (int j = 0; j < NV; ++j) {
+      x += Jr[j] * xs[j];
+      if ((j & (kG - 1)) == kG - 1) pin(x);
+    }
   }
   wave_sync();
   PINKHIP_TICK(2);  // J = L^-T, x0
