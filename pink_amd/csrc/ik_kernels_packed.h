@@ -124,83 +124,128 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   const double *eb = a.e + b * (long long)K;
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
 
-  // Rows are staged chunk by chunk (RC rows) through LDS.  The HBM requests of chunk c+1 (rows and their
-  // weights) are issued into registers before chunk c is accumulated, so that only the first chunk pays
-  // the memory latency; kernels whose chunk does not fit the register budget stage directly.
-  constexpr int RL = (S::RC * NV + W - 1) / W;  // row entries per lane and chunk
-  constexpr bool kPrefetch = RL <= 20;
-  static_assert(S::RC <= W, "one weight row per lane");
-  double stage[kPrefetch ? RL : 1];
-  double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
-  auto fetch = [&](int r0, int rc) {
-    if constexpr (kPrefetch) {
-      const double *src = Jb + (long long)r0 * nv;
+  if constexpr (kBc) {
+    // No LDS at all: lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row; the
+    // next chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters
+    // every lane's H row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j]
+    // taken from lane j and w_k^2 from lane k.
+    constexpr int RC = S::RC;
+    static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
+    double cur[RC], nxt[RC];
+    double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
+    auto request = [&](double (&dst)[RC], int r0, int rc) {
 #pragma unroll
-      for (int t = 0; t < RL; ++t) {
-        const int idx = li + t * W;
-        stage[t] = (idx < rc * nv) ? src[idx] : 0.0;
+      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
+      if (li < rc) {
+        const int k = r0 + li;
+        pw = costb[k];
+        pe = eb[k];
+        pg = a.row_gain[k];
+        pl = a.row_lm[k];
       }
+    };
+    if (Kd > 0) request(cur, 0, Kd < RC ? Kd : RC);
+    for (int r0 = 0; r0 < Kd; r0 += RC) {
+      const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;
+      const double wa = (li < rc) ? pw * pw : 0.0;
+      const double gw = (li < rc) ? pg * wa * pe : 0.0;
+      if (li < rc) mu_l += pl * (pg * pg) * wa * pe * pe;
+      const BcT wab = bcast_prepare<W>(wa), gwb = bcast_prepare<W>(gw);
+      if (r0 + RC < Kd) request(nxt, r0 + RC, (Kd - r0 - RC < RC) ? Kd - r0 - RC : RC);
+      static_for<0, RC>([&](auto Kc) {
+        constexpr int kk = decltype(Kc)::value;
+        if (kk < rc) {  // wave-uniform
+          const BcT rowb = bcast_prepare<W>(cur[kk]);
+          const double aa = fma_bcast<W, kk>(0.0, wab, cur[kk]);
+          ci = fma_bcast<W, kk>(ci, gwb, cur[kk]);
+          static_for<0, NV>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            M[j] = fma_bcast<W, j>(M[j], rowb, aa);
+          });
+        }
+      });
+#pragma unroll
+      for (int kk = 0; kk < RC; ++kk) cur[kk] = nxt[kk];
     }
-    if (li < rc) {
-      const int k = r0 + li;
-      pw = costb[k];
-      pe = eb[k];
-      pg = a.row_gain[k];
-      pl = a.row_lm[k];
-    }
-  };
-  if (Kd > 0) fetch(0, Kd < S::RC ? Kd : S::RC);
-  for (int r0 = 0; r0 < Kd; r0 += S::RC) {
-    const int rc = (Kd - r0 < S::RC) ? Kd - r0 : S::RC;
-    wave_sync();
-    {  // this group's rows, W lanes wide, LDS pitch NV
-      int r = li / nv, j = li - r * nv;
-      const int dr = W / nv, dj = W - dr * nv;
+  } else {
+    // Rows are staged chunk by chunk (RC rows) through LDS.  The HBM requests of chunk c+1 (rows and their
+    // weights) are issued into registers before chunk c is accumulated, so that only the first chunk pays
+    // the memory latency; kernels whose chunk does not fit the register budget stage directly.
+    constexpr int RL = (S::RC * NV + W - 1) / W;  // row entries per lane and chunk
+    constexpr bool kPrefetch = RL <= 20;
+    static_assert(S::RC <= W, "one weight row per lane");
+    double stage[kPrefetch ? RL : 1];
+    double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
+    auto fetch = [&](int r0, int rc) {
       if constexpr (kPrefetch) {
-#pragma unroll
-        for (int t = 0; t < RL; ++t) {
-          if (li + t * W < rc * nv) Ts[r * NV + j] = stage[t];
-          r += dr;
-          j += dj;
-          if (j >= nv) {
-            j -= nv;
-            ++r;
-          }
-        }
-      } else {
         const double *src = Jb + (long long)r0 * nv;
-        for (int idx = li; idx < rc * nv; idx += W) {
-          Ts[r * NV + j] = src[idx];
-          r += dr;
-          j += dj;
-          if (j >= nv) {
-            j -= nv;
-            ++r;
+  #pragma unroll
+        for (int t = 0; t < RL; ++t) {
+          const int idx = li + t * W;
+          stage[t] = (idx < rc * nv) ? src[idx] : 0.0;
+        }
+      }
+      if (li < rc) {
+        const int k = r0 + li;
+        pw = costb[k];
+        pe = eb[k];
+        pg = a.row_gain[k];
+        pl = a.row_lm[k];
+      }
+    };
+    if (Kd > 0) fetch(0, Kd < S::RC ? Kd : S::RC);
+    for (int r0 = 0; r0 < Kd; r0 += S::RC) {
+      const int rc = (Kd - r0 < S::RC) ? Kd - r0 : S::RC;
+      wave_sync();
+      {  // this group's rows, W lanes wide, LDS pitch NV
+        int r = li / nv, j = li - r * nv;
+        const int dr = W / nv, dj = W - dr * nv;
+        if constexpr (kPrefetch) {
+  #pragma unroll
+          for (int t = 0; t < RL; ++t) {
+            if (li + t * W < rc * nv) Ts[r * NV + j] = stage[t];
+            r += dr;
+            j += dj;
+            if (j >= nv) {
+              j -= nv;
+              ++r;
+            }
+          }
+        } else {
+          const double *src = Jb + (long long)r0 * nv;
+          for (int idx = li; idx < rc * nv; idx += W) {
+            Ts[r * NV + j] = src[idx];
+            r += dr;
+            j += dj;
+            if (j >= nv) {
+              j -= nv;
+              ++r;
+            }
           }
         }
       }
-    }
-    if (li < rc) {  // RC <= W: one weight row per lane
-      const double wa = pw * pw;
-      was[li] = wa;
-      gs[li] = pg * wa * pe;
-      mu_l += pl * (pg * pg) * wa * pe * pe;
-    }
-    if (r0 + S::RC < Kd) fetch(r0 + S::RC, (Kd - r0 - S::RC < S::RC) ? Kd - r0 - S::RC : S::RC);
-    wave_sync();
-    for (int k = 0; k < rc; ++k) {
-      const double *row = Ts + k * NV;
-      const double jki = row[lc];
-      const double aa = was[k] * jki;
-      ci += gs[k] * jki;
-#pragma unroll
-      for (int j0 = 0; j0 < NV; j0 += kG) {
-#pragma unroll
-        for (int j = j0; j < j0 + kG; ++j)
-          if (j < NV) M[j] += aa * row[j];
-#pragma unroll
-        for (int j = j0; j < j0 + kG; ++j)
-          if (j < NV) pin(M[j]);
+      if (li < rc) {  // RC <= W: one weight row per lane
+        const double wa = pw * pw;
+        was[li] = wa;
+        gs[li] = pg * wa * pe;
+        mu_l += pl * (pg * pg) * wa * pe * pe;
+      }
+      if (r0 + S::RC < Kd) fetch(r0 + S::RC, (Kd - r0 - S::RC < S::RC) ? Kd - r0 - S::RC : S::RC);
+      wave_sync();
+      for (int k = 0; k < rc; ++k) {
+        const double *row = Ts + k * NV;
+        const double jki = row[lc];
+        const double aa = was[k] * jki;
+        ci += gs[k] * jki;
+  #pragma unroll
+        for (int j0 = 0; j0 < NV; j0 += kG) {
+  #pragma unroll
+          for (int j = j0; j < j0 + kG; ++j)
+            if (j < NV) M[j] += aa * row[j];
+  #pragma unroll
+          for (int j = j0; j < j0 + kG; ++j)
+            if (j < NV) pin(M[j]);
+        }
       }
     }
   }
