@@ -311,13 +311,18 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   if (!in) ci = 0.0;
 
   // ------------------------------------------------------------------ Cholesky + forward solve + J = L^-T
-  // Column j (unscaled) and the running right-hand side go through LDS; the pivot is read
-  // back from there, so the step needs no cross-lane register traffic.  Row j-1 of L is complete when
-  // step j starts: lane li's forward substitution L y = e_li (J = L^-T, one row per lane) advances by
-  // that row inside step j, its independent FMAs filling the latency of the pivot / rsqrt chain.
+  // Right-looking Cholesky with the forward substitutions L y = e_li (J = L^-T, one row per lane) and
+  // L y = -c riding along.  Row-group kernels (kBc) keep everything in registers: column j of the trailing
+  // matrix, of L and the right-hand side are lane-held vectors that reach the other lanes' FMAs through the
+  // DPP broadcast -- the whole factorisation has no LDS access and no barrier.  8-lane groups publish the
+  // column through LDS, keep L there (row-major packed) and substitute row by row.
   int status = STATUS_OPTIMAL;
   double cp = -ci;
   double Jr[NV];
+  if constexpr (kBc) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) Jr[j] = (li == j) ? 1.0 : 0.0;
+  }
   double rinv_prev = 0.0;
   auto inverse_row = [&](auto JJ, double rdiag) {
     constexpr int jj = decltype(JJ)::value;
@@ -357,11 +362,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       status = STATUS_NOT_PD;
       p = 1.0;
     }
-    if constexpr (j > 0) inverse_row(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, rinv_prev);
+    if constexpr (!kBc && j > 0) inverse_row(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, rinv_prev);
     const double rinv = fast_rsqrt(p);
     const double lij = M[j] * rinv;
     const double tj = lij * rinv;  // M[j] / p
-    if (li >= j && li < NV) Ts[S::lrow(li) + j] = lij;
+    if constexpr (!kBc) {
+      if (li >= j && li < NV) Ts[S::lrow(li) + j] = lij;
+    }
     const double yj = yraw * rinv;
     cp = (li > j) ? cp - lij * yj : (li == j ? yj : cp);
     if constexpr (kBc) {
@@ -370,6 +377,17 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         constexpr int m = decltype(Mc)::value;
         M[m] = fma_bcast<W, m>(M[m], xb, ntj);
       });
+      // y_j of every substitution is final: scale it, then eliminate it from the rows below with column j
+      // of L (lane jj holds L[jj][j])
+      Jr[j] *= rinv;
+      if constexpr (j + 1 < NV) {
+        const BcT lb = bcast_prepare<W>((li > j && li < NV) ? lij : 0.0);
+        const double nyj = -Jr[j];
+        static_for<j + 1, NV>([&](auto Jn) {
+          constexpr int jj = decltype(Jn)::value;
+          Jr[jj] = fma_bcast<W, jj>(Jr[jj], lb, nyj);
+        });
+      }
     } else {
 #pragma unroll
       for (int m0 = (j + 1) & ~(kG - 1); m0 < NV; m0 += kG) {
@@ -382,13 +400,13 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
     }
     rinv_prev = rinv;
-    wave_sync();  // L[.][j] is in LDS for the forward substitution of the next step
+    if constexpr (!kBc) wave_sync();  // L[.][j] is in LDS for the forward substitution of the next step
   });
   if constexpr (!kBc) {
     if (li < NV) xs[li] = cp;  // y
+    wave_sync();
+    inverse_row(std::integral_constant<int, NV - 1>{}, rinv_prev);
   }
-  wave_sync();
-  inverse_row(std::integral_constant<int, NV - 1>{}, rinv_prev);
   PINKHIP_TICK(1);  // Cholesky, J = L^-T
   double rown2 = 0.0;
 #pragma unroll
@@ -409,7 +427,14 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   }
   wave_sync();
   PINKHIP_TICK(2);  // J = L^-T, x0
-  if (li < NV) {  // L is dead: what the P product may read before it is written has to be finite
+  // what the P product may read before it is written has to be finite: L has left finite values in the
+  // triangle (8-lane groups); the row-group kernels never stored L and clear the whole region
+  if constexpr (kBc) {
+#pragma unroll
+    for (int t = 0; t < (S::TRI + W - 1) / W; ++t)
+      if (li + t * W < S::TRI) Ts[li + t * W] = 0.0;
+    if (li < NV) zs[li] = 0.0;
+  } else if (li < NV) {
     zs[li] = 0.0;
     Ts[S::LEND + li] = 0.0;
     if (li == 0 && S::TRI - S::LEND > NV) Ts[S::TRI - 1] = 0.0;
