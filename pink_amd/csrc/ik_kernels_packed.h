@@ -559,7 +559,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (li < NV) {
       ds[li] = (li < q) ? dl : 0.0;  // d1, followed by the zeros of zs
       if constexpr (!kBc) d2s[li] = (li >= q) ? dl : 0.0;
-      vs[li] = vv;  // read back by the Householder update of (d)
+      if constexpr (!kBc) vs[li] = vv;
     }
     wave_sync();
     PINKHIP_TICK(5);  // norms, Householder vector
@@ -655,8 +655,19 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     // (d) add: J2 <- J2 (I - beta v v^T), R gains column [d1; -sgq |d2|]
     if (wave_any(do_add)) {
       const double wb = do_add ? beta * w : 0.0;
-      // (the update reads v back from LDS: a broadcast-FMA writing J in place costs registers, measured)
-      {
+      if constexpr (kBc) {
+        const double nwb = -wb;
+        const BcT vb2 = bcast_prepare<W>(li < NV ? vv : 0.0);  // rebuilt: two registers live across (c), not four
+        static_for<0, (NV + 7) / 8>([&](auto J8) {
+          constexpr int j0 = decltype(J8)::value * 8;
+          if (j0 + 8 > qlow) {
+            static_for<j0, (j0 + 8 < NV ? j0 + 8 : NV)>([&](auto Jc) {
+              constexpr int j = decltype(Jc)::value;
+              Jr[j] = fma_bcast<W, j>(Jr[j], vb2, nwb);
+            });
+          }
+        });
+      } else {
 #pragma unroll
         for (int j0 = 0; j0 < NV; j0 += 8) {
           if (j0 + 8 > qlow) {
