@@ -129,7 +129,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     // next chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters
     // every lane's H row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j]
     // taken from lane j and w_k^2 from lane k.
-    constexpr int RC = S::RC;
+    constexpr int RC = S::RC < 8 ? S::RC : 8;  // (two chunks of eight rows in registers: twelve spill at NV = 30)
     static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
     double cur[RC], nxt[RC];
     double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
