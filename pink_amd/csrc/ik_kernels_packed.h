@@ -82,7 +82,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   constexpr double BIG = 1e300;
   // groups made of whole rows of 16 lanes multiply lane-held vectors into lane-local accumulators with the
   // broadcast-FMA of wave.h (no LDS); 8-lane groups keep the LDS broadcast
-  constexpr bool kBc = W >= 16;
+  constexpr bool kBc = W == 16 || W == 32;  // (64-lane groups: the unrolled assembly of NV >= 40 costs tens of minutes of compile time)
   using BcT = Bcast<(W >= 16 ? W : 16)>;
 
   const int lane = lane_id();
