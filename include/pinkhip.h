@@ -229,6 +229,13 @@ int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model,
 /* q [B,nq] <- q (+) dq [B,nv], in place */
 int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double *q,
                              const double *dq);
+/* Same, but an instance whose solve failed is NOT integrated: the reference raises NoSolutionFound and never
+ * applies a failed solve (pink/solve_ik.py:271-275).  status [B] is the solver's output of this step;
+ * first_failure [B] (optional, zero-initialised by the caller) keeps, per instance, `status | (step << 8)` of
+ * the FIRST failing step, so a failure in the middle of a rollout stays visible after later steps. */
+int pinkhip_integrate_checked_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double *q,
+                                     const double *dq, const int32_t *status, int32_t *first_failure,
+                                     int32_t step);
 
 /* ---- multi-GPU: gather of dq over RCCL / xGMI --------------------------- */
 /* Instances are independent, so a batch is sharded over one handle per GPU (one process per

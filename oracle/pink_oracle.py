@@ -354,14 +354,14 @@ def goldfarb_idnani(
 # ---------------------------------------------------------------------------
 
 
-def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9):
-    """KKT certificate of ``x`` for  min 1/2 x^T P x + q^T x, G x <= h.
+def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
+    """KKT certificate of ``x`` for ``min 1/2 x'Px + q'x  s.t. Gx <= h, Ax = b``.
 
-    Returns ``(stationarity, primal_violation, multipliers)`` where the
-    multipliers are the non-negative least-squares fit of the gradient on the
-    rows whose slack is below ``active_tol``.  A strictly convex QP has a unique
-    minimiser, so small residuals certify ``x`` independently of how it was
-    computed.
+    Returns ``(stationarity, primal violation, lam)``: multipliers ``lam >= 0`` of the inequality
+    rows that are active within ``active_tol`` (and free multipliers of the equalities) are fitted by
+    non-negative least squares, the stationarity residual is ``|Px + q + G'lam + A'nu|_inf`` and the
+    violation ``max(0, max(Gx - h), |Ax - b|_inf)``.  A strictly convex QP has a unique minimiser, so a
+    small certificate proves ``x`` is the solution whatever solver produced it.
     """
     from scipy.optimize import nnls
 
@@ -369,28 +369,55 @@ def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9):
     q = np.asarray(q, float)
     x = np.asarray(x, float)
     g = P @ x + q
-    if G is None or len(G) == 0:
+    n_in = 0 if G is None else len(G)
+    n_eq = 0 if A is None else len(A)
+    if n_in == 0 and n_eq == 0:
         return float(np.abs(g).max(initial=0.0)), 0.0, np.zeros(0)
-    G = np.asarray(G, float)
-    h = np.asarray(h, float)
-    slack = h - G @ x
-    viol = float(max(0.0, -(slack.min())))
-    norms = np.linalg.norm(G, axis=1)
-    norms[norms == 0] = 1.0
-    act = np.nonzero(slack / norms <= active_tol)[0]
-    lam = np.zeros(h.size)
-    if act.size:
-        # g + G_A^T lam = 0, lam >= 0; scale rows for conditioning
-        A = (G[act] / norms[act, None]).T
-        sol, _ = nnls(A, -g, maxiter=50 * max(A.shape))
-        lam[act] = sol / norms[act]
-    stat = float(np.abs(g + G.T @ lam).max(initial=0.0))
+    viol = 0.0
+    cols = []
+    lam = np.zeros(n_in)
+    act = np.zeros(0, dtype=int)
+    if n_in:
+        G = np.asarray(G, float)
+        h = np.asarray(h, float)
+        slack = h - G @ x
+        viol = float(max(0.0, -(slack.min())))
+        norms = np.linalg.norm(G, axis=1)
+        norms[norms == 0] = 1.0
+        act = np.nonzero(slack / norms <= active_tol)[0]
+        if act.size:
+            cols.append((G[act] / norms[act, None]).T)  # scale rows for conditioning
+    if n_eq:
+        A = np.asarray(A, float)
+        viol = max(viol, float(np.abs(A @ x - np.asarray(b, float)).max()))
+        an = np.linalg.norm(A, axis=1)
+        an[an == 0] = 1.0
+        cols += [(A / an[:, None]).T, -(A / an[:, None]).T]  # free multiplier = difference of two non-negative ones
+    r = g.copy()
+    if cols:
+        M = np.hstack(cols)
+        sol, _ = nnls(M, -g, maxiter=50 * max(M.shape))
+        r = g + M @ sol
+        if act.size:
+            lam[act] = sol[:act.size] / norms[act]
+    stat = float(np.abs(r).max(initial=0.0))
     return stat, viol, lam
 
 
 # ---------------------------------------------------------------------------
 # Whole path for one instance
 # ---------------------------------------------------------------------------
+
+
+def qp_equalities(constraints):
+    """``(A, b)`` of the tasks enforced strictly: ``A = J``, ``b = -gain e`` stacked task after task
+    (``pink/solve_ik.py:140-149``); ``(None, None)`` without constraints (``:138-139``).
+    ``constraints`` holds ``(J, e, gain)`` tuples."""
+    if not constraints:
+        return None, None
+    A = np.vstack([np.asarray(J, dtype=float) for J, _e, _g in constraints])
+    b = np.hstack([-float(g) * np.asarray(e, dtype=float) for _J, e, g in constraints])
+    return A, b
 
 
 def build_qp(nv, tasks, damping, limit_blocks=(), barrier_terms=(), dt=None):

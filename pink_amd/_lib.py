@@ -90,7 +90,7 @@ ABI_SYMBOLS = (
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
     "pinkhip_fk_frame_tasks_device",
-    "pinkhip_limits_posture_device", "pinkhip_integrate_device",
+    "pinkhip_limits_posture_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_destroy",
     "pinkhip_malloc", "pinkhip_free",
     "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_sync", "pinkhip_timer_start",
@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_fk_frame_tasks_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64]
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.pinkhip_integrate_checked_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32]
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.pinkhip_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.pinkhip_comm_gather.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int]

@@ -248,6 +248,11 @@ class BatchSolver:
     def integrate(self, model, B, q, dq) -> None:
         self._check(self._lib.pinkhip_integrate_device(self._h, ctypes.c_void_p(model), B, q, dq))
 
+    def integrate_checked(self, model, B, q, dq, status, first_failure, step) -> None:
+        """``integrate`` that leaves instances with ``status != 0`` untouched and records the first failure."""
+        self._check(self._lib.pinkhip_integrate_checked_device(self._h, ctypes.c_void_p(model), B, q, dq, status,
+                                                               first_failure, int(step)))
+
     def solve_raw(self, desc, problem, result) -> None:
         self._check(self._lib.pinkhip_solve_device(self._h, ctypes.byref(desc), ctypes.byref(problem), ctypes.byref(result)))
 

@@ -1,0 +1,28 @@
+// Which instantiation of ik_solve_packed_kernel<NV, W, DENSE> serves a problem of tangent dimension nv with md
+// dense rows.  Plain C++: shared by the host side of the library (pinkhip.hip), by the per-instantiation
+// translation units (tu_packed.hip) and by the CPU wave emulator of the test suite, so that the three can never
+// disagree about the rule.
+#pragma once
+
+// X(NV, W): NV = nv padded to the next instantiated even size (padded coordinates cost FMAs and LDS traffic),
+// W = lanes per QP (64 / W QPs per wavefront).  Every pair is built with and without the dense-row machinery.
+#define PINKHIP_PACKED_TABLE(X)                                                                          \
+  X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(56, 64) X(64, 64)
+
+namespace pinkhip {
+
+struct PackedChoice {
+  int NV, W;
+};
+
+// Smallest instantiation that holds the problem.  Lane li < md of a group owns dense row li, so a group of W
+// lanes takes at most W dense rows (PINKHIP_MAX_MD = 32 <= W for W >= 32).
+inline PackedChoice select_packed(int nv, int md) {
+#define PINKHIP_PICK(NV_, W_) \
+  if (nv <= NV_ && md <= W_) return PackedChoice{NV_, W_};
+  PINKHIP_PACKED_TABLE(PINKHIP_PICK)
+#undef PINKHIP_PICK
+  return PackedChoice{0, 0};
+}
+
+}  // namespace pinkhip

@@ -1,0 +1,69 @@
+// Definitions shared by every kernel of the library: the kernarg struct, status codes, compile-time loop.
+// Uses only the primitives of wave.h; the CPU wave emulator under tests/emu provides the same names to run the
+// kernel sources unmodified in tests.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+// Tuning knobs (compile-time): how many independent LDS loads are batched before
+// their FMAs are pinned, and the occupancy the register allocator is told to aim for.
+// Tuning (measured on MI355X, profiles/): the number of LDS loads batched before their FMAs
+// are pinned is 8 for NV >= 24 and 4 below; occupancy targets (waves per SIMD, i.e. the VGPR
+// budget handed to the register allocator) are set per kernel in wave.h.
+#ifndef PINKHIP_GROUP_LARGE
+#define PINKHIP_GROUP_LARGE 8  // NV >= 24
+#endif
+#ifndef PINKHIP_GROUP_SMALL
+#define PINKHIP_GROUP_SMALL 4  // NV <= 16
+#endif
+
+namespace pinkhip {
+
+template <int NV>
+constexpr int group_size() {
+  return NV >= 24 ? PINKHIP_GROUP_LARGE : PINKHIP_GROUP_SMALL;
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+constexpr int STATUS_OPTIMAL = 0;
+constexpr int STATUS_MAX_ITER = 1;
+constexpr int STATUS_INFEASIBLE = 2;
+constexpr int STATUS_NOT_PD = 3;
+
+// Everything a launch needs; passed by value in the kernarg segment.
+struct KernelArgs {
+  long long B;
+  int nv, Kd, K, md;
+  int n_eq;          // the first n_eq dense rows are equalities Gd dq = hd (packed kernel only)
+  int n_dtasks;      // diagonal tasks
+  int n_barriers;
+  int cost_batched;
+  int max_iter;
+  double damping, dt;
+  // per-instance streams
+  const double *J, *e, *cost, *lb, *ub, *Gd, *hd, *c_extra;
+  // broadcast tables (device memory, built once per descriptor by the host)
+  const double *row_gain;  // [K]
+  const double *row_lm;    // [K]
+  const int *dtask_col0;   // [n_dtasks] first tangent column
+  const int *dtask_row0;   // [n_dtasks] first row in e / cost
+  const int *dtask_k;      // [n_dtasks] number of rows
+  const int *barrier_rows;        // [n_barriers + 1]
+  const double *barrier_safe_gain;  // [n_barriers]
+  // outputs
+  double *dq;
+  int *status;
+  int *iters;
+  double *H_out, *c_out;  // stack-only kernel
+};
+
+}  // namespace pinkhip

@@ -13,7 +13,7 @@
 // appendix B.3 (closed forms of log3 / log6 / Jlog3 / Jlog6 with their small-angle series).
 #pragma once
 
-#include "ik_kernels.h"
+#include "ik_common.h"
 
 namespace pinkhip {
 

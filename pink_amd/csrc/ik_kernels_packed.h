@@ -15,7 +15,7 @@
 // The arithmetic per instance is the same as in ik_kernels.h (same citations apply).
 #pragma once
 
-#include "ik_kernels.h"
+#include "ik_common.h"
 
 // The triangular factor of the active set is kept as P = R^-1 (R itself is never stored): the dual
 // direction r = P d1 is a chain-free matrix-vector product, a new column of P costs one LDS write per
@@ -82,7 +82,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   constexpr double BIG = 1e300;
   // groups made of whole rows of 16 lanes multiply lane-held vectors into lane-local accumulators with the
   // broadcast-FMA of wave.h (no LDS); 8-lane groups keep the LDS broadcast
-  constexpr bool kBc = W == 16 || W == 32;  // (64-lane groups: the unrolled assembly of NV >= 40 costs tens of minutes of compile time)
+  constexpr bool kBc = W >= 16;
   using BcT = Bcast<(W >= 16 ? W : 16)>;
 
   const int lane = lane_id();

@@ -330,6 +330,9 @@ struct IntegrateArgs {
   long long B;
   double *q;         // [B, nq] in place
   const double *dq;  // [B, nv]
+  const int *status = nullptr;   // [B] solver status of this step: instances with status != 0 keep their q
+  int *first_failure = nullptr;  // [B] sticky: status | (step << 8) of the first failing step
+  int step = 0;
 };
 
 // one thread per (instance, joint): q <- q (+) dq
@@ -338,6 +341,13 @@ __device__ inline void ik_integrate_thread(const IntegrateArgs &a, long long t) 
   if (t >= a.B * m.nj) return;
   const long long b = t / m.nj;
   const int j = (int)(t - b * m.nj);
+  if (a.status) {  // a failed solve is never applied (pink/solve_ik.py:271-275 raises before integrating)
+    const int st = a.status[b];
+    if (st != 0) {
+      if (j == 0 && a.first_failure && a.first_failure[b] == 0) a.first_failure[b] = st | (a.step << 8);
+      return;
+    }
+  }
   double *q = a.q + b * m.nq + m.idx_q[j];
   const double *v = a.dq + b * m.nv + m.idx_v[j];
   if (m.jtype[j] != JOINT_FREE_FLYER) {

@@ -11,7 +11,7 @@
 // The kernel is bound by the HBM stream: 8 (Kd nv + K + nv^2 + nv) bytes per QP.
 #pragma once
 
-#include "ik_kernels.h"
+#include "ik_common.h"
 
 namespace pinkhip {
 

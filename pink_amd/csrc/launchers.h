@@ -1,0 +1,22 @@
+// Launch functions the kernel translation units export to the host side of the library (pinkhip.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dispatch.h"
+#include "ik_common.h"
+
+#define PINKHIP_PASTE5(a, b, c, d, e) a##b##_##c##_##d##e
+#define PINKHIP_LAUNCH_PACKED_NAME(NV, W, D) PINKHIP_PASTE5(launch_packed_, NV, W, D, )
+
+namespace pinkhip {
+
+#define PINKHIP_DECLARE(NV, W)                                                                  \
+  hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(hipStream_t stream, const KernelArgs &a);     \
+  hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 1)(hipStream_t stream, const KernelArgs &a);
+PINKHIP_PACKED_TABLE(PINKHIP_DECLARE)
+#undef PINKHIP_DECLARE
+
+
+
+
+}  // namespace pinkhip

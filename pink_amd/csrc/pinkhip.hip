@@ -15,8 +15,8 @@
 
 // clang-format off
 #include "wave.h"
-#include "ik_kernels.h"
-#include "ik_kernels_packed.h"
+#include "ik_common.h"
+#include "launchers.h"
 #include "ik_stack_mfma.h"
 #include "ik_frame_task.h"
 #include "ik_kinematics.h"
@@ -48,7 +48,6 @@ struct pinkhip_handle {
   char *arena = nullptr;             // grow-only scratch of the *_host entry points
   size_t arena_bytes = 0;
   hipDeviceProp_t prop;
-  bool packed = true;                // PINKHIP_KERNEL=wave forces one QP per wavefront
   void *comm = nullptr;              // ncclComm_t once pinkhip_comm_init succeeded
   int comm_rank = 0, comm_size = 0;
 };
@@ -76,18 +75,6 @@ struct pinkhip_unique_id_t {
   char internal[PINKHIP_COMM_ID_BYTES];
 };
 
-template <int NV>
-int launch_nv(pinkhip_handle *h, const KernelArgs &a, bool solve) {
-  const size_t lds = static_cast<size_t>(pinkhip::Lds<NV>::bytes(a.md));
-  const dim3 grid(static_cast<unsigned>(a.B)), block(pinkhip::kWave);
-  if (solve)
-    hipLaunchKernelGGL(pinkhip::ik_solve_kernel<NV>, grid, block, lds, h->stream, a);
-  else
-    hipLaunchKernelGGL(pinkhip::ik_stack_kernel<NV>, grid, block, lds, h->stream, a);
-  PH_HIP(h, hipGetLastError());
-  return PINKHIP_OK;
-}
-
 template <int NT>
 int launch_stack_mfma(pinkhip_handle *h, const KernelArgs &a) {
   const dim3 grid(static_cast<unsigned>(a.B)), block(pinkhip::kWave);
@@ -96,57 +83,33 @@ int launch_stack_mfma(pinkhip_handle *h, const KernelArgs &a) {
   return PINKHIP_OK;
 }
 
-template <int NV, int W>
-int launch_packed(pinkhip_handle *h, const KernelArgs &a) {
-  constexpr int G = pinkhip::kWave / W;
-  const size_t lds = static_cast<size_t>(pinkhip::LdsP<NV>::bytes(a.md, G));
-  const dim3 grid(static_cast<unsigned>((a.B + G - 1) / G)), block(pinkhip::kWave);
-  if (a.md == 0)  // box limits only: the instantiation without the dense-row machinery
-    hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W, false>), grid, block, lds, h->stream, a);
-  else
-    hipLaunchKernelGGL((pinkhip::ik_solve_packed_kernel<NV, W, true>), grid, block, lds, h->stream, a);
-  PH_HIP(h, hipGetLastError());
-  return PINKHIP_OK;
-}
-
 int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   if (a.B == 0) return PINKHIP_OK;
   if (a.B > 0x7fffffffLL) return fail(h, PINKHIP_E_INVALID, "B exceeds the grid limit 2^31-1");
-  if (!solve && h->packed) {  // stack only: fp64 MFMA tiles, NT = ceil(nv / 16)
+  if (!solve) {  // stack only: fp64 MFMA tiles, NT = ceil(nv / 16)
     switch ((a.nv + 15) / 16) {
       case 1: return launch_stack_mfma<1>(h, a);
       case 2: return launch_stack_mfma<2>(h, a);
       case 3: return launch_stack_mfma<3>(h, a);
       case 4: return launch_stack_mfma<4>(h, a);
     }
+    return fail(h, PINKHIP_E_INVALID, "unsupported nv");
   }
-  if (solve && h->packed) {
-    // several QPs per wavefront when a row group (8 / 16 / 32 lanes) holds the problem
-    // (NV is the smallest instantiated even size >= nv: padded coordinates cost FMAs and LDS traffic)
-    if (a.nv <= 6 && a.md <= 8) return launch_packed<6, 8>(h, a);
-    if (a.nv <= 8 && a.md <= 8) return launch_packed<8, 8>(h, a);
-    if (a.nv <= 12 && a.md <= 16) return launch_packed<12, 16>(h, a);
-    if (a.nv <= 16 && a.md <= 16) return launch_packed<16, 16>(h, a);
-    if (a.nv <= 24) return launch_packed<24, 32>(h, a);
-    if (a.nv <= 30) return launch_packed<30, 32>(h, a);
-    if (a.nv <= 32) return launch_packed<32, 32>(h, a);
-    // nv > 32: one QP per wavefront, same kernel (packed triangular L / R keeps LDS small)
-    if (a.nv <= 40) return launch_packed<40, 64>(h, a);
-    if (a.nv <= 48) return launch_packed<48, 64>(h, a);
-    if (a.nv <= 56) return launch_packed<56, 64>(h, a);
-    return launch_packed<64, 64>(h, a);
+  // stack + solve: the instantiation chosen by dispatch.h, each one its own translation unit (tu_packed.hip)
+  const pinkhip::PackedChoice pc = pinkhip::select_packed(a.nv, a.md);
+  hipError_t e = hipErrorInvalidValue;
+  switch (pc.NV) {
+#define PINKHIP_CASE(NV, W)                                                                   \
+  case NV:                                                                                    \
+    e = a.md == 0 ? pinkhip::PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(h->stream, a)               \
+                  : pinkhip::PINKHIP_LAUNCH_PACKED_NAME(NV, W, 1)(h->stream, a);              \
+    break;
+    PINKHIP_PACKED_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    default: return fail(h, PINKHIP_E_INVALID, "unsupported nv / md");
   }
-  switch (pinkhip::padded_nv(a.nv)) {
-    case 8: return launch_nv<8>(h, a, solve);
-    case 16: return launch_nv<16>(h, a, solve);
-    case 24: return launch_nv<24>(h, a, solve);
-    case 32: return launch_nv<32>(h, a, solve);
-    case 40: return launch_nv<40>(h, a, solve);
-    case 48: return launch_nv<48>(h, a, solve);
-    case 56: return launch_nv<56>(h, a, solve);
-    case 64: return launch_nv<64>(h, a, solve);
-  }
-  return fail(h, PINKHIP_E_INVALID, "unsupported nv");
+  PH_HIP(h, e);
+  return PINKHIP_OK;
 }
 
 // Validate `d`, refresh the device tables if they changed, fill the table part of `a`.
@@ -156,8 +119,6 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   pinkhip::HostTables t;
   const std::string why = pinkhip::build_tables(*d, t);
   if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
-  if (d->n_eq > 0 && !h->packed)
-    return fail(h, PINKHIP_E_UNSUPPORTED, "equality constraints need the packed kernel (unset PINKHIP_KERNEL=wave)");
   PH_HIP(h, hipSetDevice(h->device));
 
   // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
@@ -310,7 +271,6 @@ int pinkhip_create(pinkhip_handle **out, int device_id) {
   pinkhip_handle *h = new (std::nothrow) pinkhip_handle();
   if (!h) return fail(nullptr, PINKHIP_E_NOMEM, "out of host memory");
   h->device = device_id;
-  if (const char *k = std::getenv("PINKHIP_KERNEL")) h->packed = std::strcmp(k, "wave") != 0;
   hipError_t e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipGetDeviceProperties(&h->prop, device_id);
   if (e == hipSuccess && std::strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
@@ -625,6 +585,20 @@ int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *m, int64_t 
   if (!q || !dq) return fail(h, PINKHIP_E_INVALID, "null pointer");
   PH_HIP(h, hipSetDevice(h->device));
   pinkhip::IntegrateArgs a{m->dev, B, q, dq};
+  const long long n = B * m->dev.nj;
+  hipLaunchKernelGGL(pinkhip::ik_integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_integrate_checked_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, double *q, const double *dq,
+                                     const int32_t *status, int32_t *first_failure, int32_t step) {
+  if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
+  if (B < 0 || step < 0 || step >= (1 << 23)) return fail(h, PINKHIP_E_INVALID, "bad B / step");
+  if (B == 0) return PINKHIP_OK;
+  if (!q || !dq || !status) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::IntegrateArgs a{m->dev, B, q, dq, status, first_failure, step};
   const long long n = B * m->dev.nj;
   hipLaunchKernelGGL(pinkhip::ik_integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
   PH_HIP(h, hipGetLastError());

@@ -24,6 +24,7 @@ import numpy as np
 
 from ._lib import Desc, Problem, Result, c_double_p, c_int32_p
 from .configuration import Model
+from .exceptions import NoSolutionFound, NotWithinConfigurationLimits
 from .utils import get_root_joint_dim
 
 _JT = {"revolute": 0, "prismatic": 1, "free_flyer": 2}
@@ -92,15 +93,24 @@ class DeviceRollout:
     methods: the test suite passes the CPU wave emulator).  ``frame_tasks`` is a list of
     ``(frame_name, position_cost, orientation_cost, gain, lm_damping)``; ``posture_cost`` enables a
     PostureTask toward ``q_posture`` (default: the initial configuration of each robot).
+
+    A robot whose QP fails at some step (``status != 0``) is frozen: the failed ``dq`` is never integrated
+    (the reference raises ``NoSolutionFound`` before integrating, ``pink/solve_ik.py:271-275``) and the first
+    failure is remembered per robot on the device; :meth:`run` raises once the steps are done
+    (``raise_on_failure=False``: inspect :meth:`failures`).  ``safety_break`` checks the initial
+    configurations against the joint limits like ``solve_ik`` does (``pink/solve_ik.py:260``); later
+    configurations stay inside them by construction (the QP's box is ``gain * (q_limit - q)``).
     """
 
-    _BUFFERS = ("d_q", "d_T", "d_Jb", "d_Tt", "d_J", "d_e", "d_cost", "d_lb", "d_ub", "d_dq", "d_status", "d_iters", "d_qt")
+    _BUFFERS = ("d_q", "d_T", "d_Jb", "d_Tt", "d_J", "d_e", "d_cost", "d_lb", "d_ub", "d_dq", "d_status", "d_iters", "d_qt",
+                "d_fail")
 
     def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
-                 fused: bool = True):
+                 fused: bool = True, safety_break: bool = True):
         self.api, self.model, self.dt = api, model, float(dt)
+        self._check_limits(model, np.asarray(q0, dtype=np.float64), safety_break)
         self.fused = bool(fused)  # FK + FrameTask rows in one launch (False: FK, then one launch per task)
         self.B = B = int(q0.shape[0])
         self.nv, self.nq = model.nv, model.nq
@@ -122,7 +132,8 @@ class DeviceRollout:
         cost = []
         for ft in frame_tasks:
             cost += list(np.broadcast_to(np.asarray(ft[1], float), (3,))) + list(np.broadcast_to(np.asarray(ft[2], float), (3,)))
-        cost += [float(posture_cost)] * n_post
+        if n_post:
+            cost += [float(posture_cost)] * n_post
         self.cost = np.ascontiguousarray(cost if cost else [0.0], dtype=np.float64)
         self.brow = np.zeros(1, dtype=np.int32)
         self.bsafe = np.zeros(1, dtype=np.float64)
@@ -151,6 +162,8 @@ class DeviceRollout:
         self.d_cost = f8(max(self.K, 1))
         self.d_lb, self.d_ub, self.d_dq = f8(B, nv), f8(B, nv), f8(B, nv)
         self.d_status, self.d_iters = a.alloc(4 * B), a.alloc(4 * B)
+        self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
+        a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self.d_qt = f8(B, nq)
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
         a.put(self.d_q, q0)
@@ -185,13 +198,44 @@ class DeviceRollout:
         a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
                          self.d_e if self.n_post else None, self.K, self.Kd)
         a.solve_raw(self.desc, self.problem, self.result)
-        a.integrate(self.dmodel, B, self.d_q, self.d_dq)
+        a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
         self.steps_done += 1
 
-    def run(self, steps: int) -> None:
+    def run(self, steps: int, raise_on_failure: bool = True) -> None:
+        """``steps`` IK steps for every robot, then one synchronisation.  Raises :class:`NoSolutionFound`
+        listing the robots whose QP failed at some step (they stopped moving at that step)."""
         for _ in range(steps):
             self.step()
         self.api.sync()
+        if raise_on_failure:
+            idx, status, step = self.failures()
+            if idx.size:
+                exc = NoSolutionFound(None, None, idx, status)
+                exc.steps = step
+                raise exc
+
+    def failures(self):
+        """``(indices, status, step)`` of the robots whose solve has failed so far (first failure of each)."""
+        f = np.zeros(self.B, np.int32)
+        self.api.get(f, self.d_fail)
+        idx = np.nonzero(f)[0]
+        return idx, f[idx] & 0xFF, f[idx] >> 8
+
+    @staticmethod
+    def _check_limits(model: Model, q0: np.ndarray, safety_break: bool, tol: float = 1e-6) -> None:
+        """``Configuration.check_limits`` (``pink/configuration.py:166-201``) over the batch of initial
+        configurations: first violated joint limit raises (or warns)."""
+        lo, up = model.lowerPositionLimit, model.upperPositionLimit
+        start = model.root_joint.nq if model.root_joint is not None else 0
+        bad = (up > lo + tol) & ((q0 < lo - tol) | (q0 > up + tol))
+        bad[:, :start] = False
+        if bad.any():
+            b, i = (int(v[0]) for v in np.nonzero(bad))
+            if safety_break:
+                raise NotWithinConfigurationLimits(i, q0[b, i], lo[i], up[i], instance=b)
+            import logging
+
+            logging.warning("Value %f at index %d of instance %d is out of limits: [%f, %f]", q0[b, i], i, b, lo[i], up[i])
 
     def configurations(self) -> np.ndarray:
         q = np.zeros((self.B, self.nq))

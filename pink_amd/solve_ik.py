@@ -140,8 +140,11 @@ def _pose12(T) -> np.ndarray:
     return np.hstack([np.asarray(T.rotation, dtype=float).ravel(), np.asarray(T.translation, dtype=float)])
 
 
+_PAD_ROW_H = 1e30  # right-hand side of the padding rows  0 dq <= PAD
+
+
 def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, damping: float = 1e-12, limits=None,
-                        barriers=None, solver_handle=None, gpu_frame_tasks: bool = True) -> IKBatch:
+                        barriers=None, solver_handle=None, gpu_frame_tasks: bool = True, constraints=None) -> IKBatch:
     """Evaluate the same task / limit / barrier objects at every configuration and
     pack the batch.  The task list may also be a list of per-instance lists (one
     target per instance): ``tasks[b]`` is then used for ``configurations[b]``.
@@ -149,6 +152,9 @@ def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, da
     FrameTasks are evaluated for the whole batch by the HIP frame-task kernel
     (``log6`` / ``Jlog6`` / ``-Jlog6 J_body``, ``pink/tasks/frame_task.py:176-227``) when
     ``gpu_frame_tasks`` is set: the host only gathers poses and body Jacobians.
+
+    ``constraints`` (tasks enforced as equalities, ``pink/solve_ik.py:125-149``) follows the same convention
+    as ``tasks``: one list for all instances or one list per instance.
     """
     from .tasks.frame_task import FrameTask
 
@@ -191,23 +197,52 @@ def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, da
     for cfg in configurations:
         _, _, lb, ub, dr, bt, _ = _collect_terms(cfg, [], dt, limits, barriers)
         lbs.append(lb), ubs.append(ub), dense.append(dr), bterms.append(bt)
+    # Dense limit rows: the number a limit returns may differ from instance to instance (a row that is
+    # axis-aligned at one configuration went into the box there; a limit may return None).  Every instance's
+    # rows are concatenated and padded to the batch maximum with rows  0 dq <= PAD  that can never be active.
     dense_rows = []
-    if B and dense[0]:
-        for k in range(len(dense[0])):
-            dense_rows.append((np.concatenate([d[k][0] for d in dense], axis=0), np.concatenate([d[k][1] for d in dense], axis=0)))
+    n_rows = [sum(h.shape[1] for _, h in dr) for dr in dense]
+    r_max = max(n_rows, default=0)
+    if r_max:
+        Gp = np.zeros((B, r_max, nv))
+        hp = np.full((B, r_max), _PAD_ROW_H)
+        for b, dr in enumerate(dense):
+            if dr:
+                Gp[b, :n_rows[b]] = np.concatenate([G[0] for G, _ in dr], axis=0)
+                hp[b, :n_rows[b]] = np.concatenate([h[0] for _, h in dr], axis=0)
+        dense_rows.append((Gp, hp))
     barrier_terms = []
-    if B and bterms[0]:
-        for k, b0 in enumerate(bterms[0]):
-            sd = None if b0.safe_displacement is None else np.concatenate([bt[k].safe_displacement for bt in bterms], axis=0)
-            barrier_terms.append(BarrierTerm(J_h=np.concatenate([bt[k].J_h for bt in bterms], axis=0),
-                                             h=np.concatenate([bt[k].h for bt in bterms], axis=0), gain=b0.gain,
-                                             safe_displacement_gain=b0.safe_displacement_gain, safe_displacement=sd))
+    n_bar = {len(bt) for bt in bterms}
+    if len(n_bar) > 1:
+        raise PinkError("every instance of a batch must evaluate the same list of barriers")
+    for k in range(n_bar.pop() if n_bar else 0):
+        col = [bt[k] for bt in bterms]
+        b0 = col[0]
+        if any(t.J_h.shape != b0.J_h.shape or t.safe_displacement_gain != b0.safe_displacement_gain
+               or not np.array_equal(np.asarray(t.gain), np.asarray(b0.gain)) for t in col):
+            raise PinkError(f"barrier slot {k}: dimension / gains must be the same for every instance of a batch")
+        # a barrier whose safe displacement is zero at some configurations (as_term reports None there)
+        # contributes zero to the linear term of those instances only
+        sd = None
+        if any(t.safe_displacement is not None for t in col):
+            sd = np.concatenate([np.zeros((1, nv)) if t.safe_displacement is None else t.safe_displacement for t in col], axis=0)
+        barrier_terms.append(BarrierTerm(J_h=np.concatenate([t.J_h for t in col], axis=0),
+                                         h=np.concatenate([t.h for t in col], axis=0), gain=b0.gain,
+                                         safe_displacement_gain=b0.safe_displacement_gain, safe_displacement=sd))
+    equality_rows = []
+    if constraints:  # pink/solve_ik.py:125-149, per instance
+        per_c = B > 0 and len(constraints) == B and isinstance(constraints[0], (list, tuple))
+        Ab = [_equalities(cfg, constraints[b] if per_c else constraints) for b, cfg in enumerate(configurations)]
+        if len({A.shape for A, _ in Ab}) > 1:
+            raise PinkError("constraints= must produce the same number of equality rows for every instance")
+        equality_rows.append((np.stack([A for A, _ in Ab]), np.stack([bb for _, bb in Ab])))
     return pack_terms(nv, merged, dt, damping, boxes=[(np.array(lbs), np.array(ubs))] if B else (),
-                      dense_rows=dense_rows, barriers=barrier_terms, batch_size=B)
+                      dense_rows=dense_rows, barriers=barrier_terms, batch_size=B, equality_rows=equality_rows)
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
-                   limits=None, barriers=None, safety_break: bool = True, solver_handle=None, **kwargs) -> np.ndarray:
+                   limits=None, barriers=None, constraints=None, safety_break: bool = True, solver_handle=None,
+                   **kwargs) -> np.ndarray:
     """Batched ``solve_ik``: velocities ``[B, nv]`` for ``B`` configurations.
 
     Raises :class:`NoSolutionFound` listing the failing instances (the batched
@@ -220,7 +255,7 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     for cfg in configurations:
         cfg.check_limits(safety_break=safety_break)
     batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, solver_handle,
-                                gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)))
+                                gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)), constraints=constraints)
     result = (solver_handle or default_solver()).solve(batch, max_iter=int(kwargs.get("max_iter", 0)))
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])

@@ -28,11 +28,29 @@ def golden_case(golden, name):
     barriers = []
     if f"{name}/barrier_J" in g:
         for i in range(g[f"{name}/barrier_J"].shape[0]):
+            sd = g[f"{name}/barrier_dq_safe"][i][None] if f"{name}/barrier_dq_safe" in g else None
             barriers.append(BarrierTerm(J_h=g[f"{name}/barrier_J"][i][None], h=g[f"{name}/barrier_h"][i][None],
                                         gain=float(g[f"{name}/barrier_gain"][i]),
-                                        safe_displacement_gain=float(g[f"{name}/barrier_safe_gain"][i])))
-    batch = pack_terms(nv, tasks, dt, 1e-12, boxes=[(lb[None], ub[None])], barriers=barriers, batch_size=1)
+                                        safe_displacement_gain=float(g[f"{name}/barrier_safe_gain"][i]),
+                                        safe_displacement=sd))
+    eq = []
+    for i in range(int(g[f"{name}/n_constraints"]) if f"{name}/n_constraints" in g else 0):
+        # what pink_amd.solve_ik._equalities hands over: A = J, b = -gain e per constraint task
+        eq.append((g[f"{name}/constraint{i}_J"][None],
+                   (-float(g[f"{name}/constraint{i}_gain"]) * g[f"{name}/constraint{i}_e"])[None]))
+    batch = pack_terms(nv, tasks, dt, 1e-12, boxes=[(lb[None], ub[None])], barriers=barriers, batch_size=1,
+                       equality_rows=eq)
     return batch, g[f"{name}/P"], g[f"{name}/qvec"], g[f"{name}/G"], g[f"{name}/h"]
+
+
+GOLDEN_NAMES = ["ur5", "draco3", "barrier", "equality", "safe"]
+
+
+def golden_equalities(golden, name):
+    """(A, b) the reference's build_ik produced for the fixture, or (None, None)."""
+    if f"{name}/A" in golden:
+        return golden[f"{name}/A"], golden[f"{name}/b"]
+    return None, None
 
 
 def random_case(nv, B, seed, Kd_tasks=2, md=0, diag=True, tight=0.05, root=0, lm=0.0, rank_deficient=False):

@@ -133,6 +133,11 @@ class EmuSolver:
         self.lib.pinkhip_emu_integrate.argtypes = [vp, ctypes.c_longlong, vp, vp]
         self.lib.pinkhip_emu_integrate(model, B, q, dq)
 
+    def integrate_checked(self, model, B, q, dq, status, first_failure, step):
+        vp = ctypes.c_void_p
+        self.lib.pinkhip_emu_integrate_checked.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, ctypes.c_int]
+        self.lib.pinkhip_emu_integrate_checked(model, B, q, dq, status, first_failure, step)
+
     def solve_raw(self, desc, problem, result):
         rc = self.lib.pinkhip_emu_solve_host(ctypes.byref(desc), ctypes.byref(problem), ctypes.byref(result))
         if rc != 0:

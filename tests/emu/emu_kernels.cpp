@@ -3,7 +3,8 @@
 // signature as the host entry points of include/pinkhip.h.
 #include "wave_emu.h"
 // clang-format off
-#include "../../pink_amd/csrc/ik_kernels.h"
+#include "../../pink_amd/csrc/ik_common.h"
+#include "../../pink_amd/csrc/dispatch.h"
 #include "../../pink_amd/csrc/ik_kernels_packed.h"
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/ik_frame_task.h"
@@ -18,12 +19,6 @@ namespace {
 
 using pinkhip::KernelArgs;
 
-template <int NV, bool SOLVE>
-void lane_main(void *p) {
-  const KernelArgs *a = static_cast<const KernelArgs *>(p);
-  pinkhip::ik_instance<NV, SOLVE>(*a, pinkhip::block_id());
-}
-
 template <int NV, int W>
 void lane_main_packed(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
@@ -37,21 +32,6 @@ template <int NT>
 void lane_main_stack_mfma(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
   pinkhip::ik_stack_mfma_instance<NT>(*a, pinkhip::block_id());
-}
-
-template <bool SOLVE>
-pinkhip::LaneFn pick(int nvp) {
-  switch (nvp) {
-    case 8: return lane_main<8, SOLVE>;
-    case 16: return lane_main<16, SOLVE>;
-    case 24: return lane_main<24, SOLVE>;
-    case 32: return lane_main<32, SOLVE>;
-    case 40: return lane_main<40, SOLVE>;
-    case 48: return lane_main<48, SOLVE>;
-    case 56: return lane_main<56, SOLVE>;
-    case 64: return lane_main<64, SOLVE>;
-  }
-  return nullptr;
 }
 
 std::string g_err;
@@ -96,41 +76,30 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   }
   a.H_out = H_out;
   a.c_out = c_out;
-  const int nvp = pinkhip::padded_nv(d->nv);
-  pinkhip::LaneFn fn = solve ? pick<true>(nvp) : pick<false>(nvp);
-  if (!fn) {
-    g_err = "unsupported nv";
-    return PINKHIP_E_INVALID;
-  }
+  pinkhip::LaneFn fn = nullptr;
   long long blocks = d->B;
-  const char *k = std::getenv("PINKHIP_KERNEL");
-  const bool packed = !(k && std::strcmp(k, "wave") == 0);
-  if (d->n_eq > 0 && !packed) {
-    g_err = "equality constraints need the packed kernel";
-    return PINKHIP_E_UNSUPPORTED;
-  }
-  if (!solve && packed) {
+  if (!solve) {
     switch ((a.nv + 15) / 16) {
       case 1: fn = lane_main_stack_mfma<1>; break;
       case 2: fn = lane_main_stack_mfma<2>; break;
       case 3: fn = lane_main_stack_mfma<3>; break;
       case 4: fn = lane_main_stack_mfma<4>; break;
     }
+  } else {  // the dispatch rule of the library (dispatch.h)
+    const pinkhip::PackedChoice pc = pinkhip::select_packed(a.nv, a.md);
+    switch (pc.NV) {
+#define PINKHIP_CASE(NV, W)          \
+  case NV:                           \
+    fn = lane_main_packed<NV, W>;    \
+    blocks = (d->B + 64 / W - 1) / (64 / W); \
+    break;
+      PINKHIP_PACKED_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    }
   }
-  if (solve && packed) {  // same dispatch rule as pinkhip.hip
-    int G = 0;
-    if (a.nv <= 6 && a.md <= 8) { fn = lane_main_packed<6, 8>; G = 8; }
-    else if (a.nv <= 8 && a.md <= 8) { fn = lane_main_packed<8, 8>; G = 8; }
-    else if (a.nv <= 12 && a.md <= 16) { fn = lane_main_packed<12, 16>; G = 4; }
-    else if (a.nv <= 16 && a.md <= 16) { fn = lane_main_packed<16, 16>; G = 4; }
-    else if (a.nv <= 24) { fn = lane_main_packed<24, 32>; G = 2; }
-    else if (a.nv <= 30) { fn = lane_main_packed<30, 32>; G = 2; }
-    else if (a.nv <= 32) { fn = lane_main_packed<32, 32>; G = 2; }
-    else if (a.nv <= 40) { fn = lane_main_packed<40, 64>; G = 1; }
-    else if (a.nv <= 48) { fn = lane_main_packed<48, 64>; G = 1; }
-    else if (a.nv <= 56) { fn = lane_main_packed<56, 64>; G = 1; }
-    else { fn = lane_main_packed<64, 64>; G = 1; }
-    if (G) blocks = (d->B + G - 1) / G;
+  if (!fn) {
+    g_err = "unsupported nv / md";
+    return PINKHIP_E_INVALID;
   }
   for (long long b = 0; b < blocks; ++b) pinkhip::emu_run_block(b, fn, &a);
   return PINKHIP_OK;
@@ -218,6 +187,13 @@ int pinkhip_emu_limits_posture(void *mp, long long B, double dt, double gain, co
 int pinkhip_emu_integrate(void *mp, long long B, double *q, const double *dq) {
   EmuModel *m = static_cast<EmuModel *>(mp);
   pinkhip::IntegrateArgs a{m->dev, B, q, dq};
+  for (long long t = 0; t < B * m->dev.nj; ++t) pinkhip::ik_integrate_thread(a, t);
+  return PINKHIP_OK;
+}
+int pinkhip_emu_integrate_checked(void *mp, long long B, double *q, const double *dq, const int *status,
+                                  int *first_failure, int step) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::IntegrateArgs a{m->dev, B, q, dq, status, first_failure, step};
   for (long long t = 0; t < B * m->dev.nj; ++t) pinkhip::ik_integrate_thread(a, t);
   return PINKHIP_OK;
 }

@@ -104,15 +104,21 @@ def main():
             return "SyntheticTask()"
 
     class SyntheticBarrier(Barrier):
-        def __init__(self, J_h, h_val, **kw):
+        def __init__(self, J_h, h_val, dq_safe=None, **kw):
             super().__init__(len(h_val), **kw)
-            self.J_h, self.h_val = J_h, h_val
+            self.J_h, self.h_val, self.dq_safe = J_h, h_val, dq_safe
 
         def compute_barrier(self, configuration):
             return self.h_val
 
         def compute_jacobian(self, configuration):
             return self.J_h
+
+        def compute_safe_displacement(self, configuration):
+            # the hook a subclass overrides (pink/barriers/barrier.py:134-149); default is zero
+            if self.dq_safe is None:
+                return super().compute_safe_displacement(configuration)
+            return self.dq_safe
 
     rng = np.random.default_rng(20260924)
     out = {}
@@ -121,6 +127,12 @@ def main():
         dict(name="draco3", nv=30, root=6, frames=[(1.0, 1.0), (1.0, 0.0), (1.0, 1.0), (4.0, 4.0)], lm=0.0,
              posture=1e-1, dt=0.005, nbar=0),
         dict(name="barrier", nv=12, root=0, frames=[(1.0, 3.0), (2.0, 0.5)], lm=1e-3, posture=1e-2, dt=0.01, nbar=2),
+        # constraints=[task]: A = J, b = -gain e (pink/solve_ik.py:125-149)
+        dict(name="equality", nv=9, root=0, frames=[(1.0, 1.0), (2.0, 1.0)], lm=0.0, posture=1e-1, dt=0.005, nbar=0,
+             n_constraints=2),
+        # barriers whose compute_safe_displacement is overridden: c gains -rho dq_safe (pink/barriers/barrier.py:193-201)
+        dict(name="safe", nv=14, root=6, frames=[(1.0, 1.0), (1.0, 0.5)], lm=1e-2, posture=1e-2, dt=0.01, nbar=2,
+             safe=True, safe_gains=(1.0, 3.0)),
     ]
     for cs in cases:
         nv, root, dt = cs["nv"], cs["root"], cs["dt"]
@@ -147,13 +159,27 @@ def main():
         ep = rng.uniform(-0.5, 0.5, size=n_act)
         tasks.append(SyntheticTask(Jp, ep, cost=float(cs["posture"]), gain=1.0, lm_damping=0.0))
         barriers, bJ, bh, bgain, bsafe = [], [], [], [], []
-        for _ in range(cs["nbar"]):
+        bdq = []
+        for ib in range(cs["nbar"]):
             Jh = rng.normal(0, 0.3, size=(3, nv))
             hv = rng.uniform(0.0, 0.05, size=3)
-            barriers.append(SyntheticBarrier(Jh, hv, gain=100.0, safe_displacement_gain=1.0))
-            bJ.append(Jh), bh.append(hv), bgain.append(100.0), bsafe.append(1.0)
+            sgain = cs.get("safe_gains", (1.0,) * cs["nbar"])[ib]
+            dq_safe = 0.02 * rng.normal(size=nv) if cs.get("safe") else None
+            barriers.append(SyntheticBarrier(Jh, hv, dq_safe, gain=100.0, safe_displacement_gain=sgain))
+            bJ.append(Jh), bh.append(hv), bgain.append(100.0), bsafe.append(sgain)
+            if dq_safe is not None:
+                bdq.append(dq_safe)
+        constraints, cJ, ce, cgain = [], [], [], []
+        for ic in range(cs.get("n_constraints", 0)):
+            k = 2 + ic
+            Jc = rng.normal(0, 0.5, size=(k, nv))
+            ec = 0.01 * rng.normal(size=k)
+            gc = [0.7, 1.0][ic]
+            constraints.append(SyntheticTask(Jc, ec, cost=1.0, gain=gc))
+            cJ.append(Jc), ce.append(ec), cgain.append(gc)
         limits = [ConfigurationLimit(model), VelocityLimit(model)]
-        problem = pink.build_ik(cfg, tasks, dt, damping=1e-12, limits=limits, barriers=barriers or None)
+        problem = pink.build_ik(cfg, tasks, dt, damping=1e-12, limits=limits, barriers=barriers or None,
+                                constraints=constraints or None)
         H_tasks = [t.compute_qp_objective(cfg) for t in tasks]
         n = cs["name"]
         out[f"{n}/nv"] = nv
@@ -173,6 +199,14 @@ def main():
             out[f"{n}/barrier_h"] = np.stack(bh)
             out[f"{n}/barrier_gain"] = np.array(bgain)
             out[f"{n}/barrier_safe_gain"] = np.array(bsafe)
+        if bdq:
+            out[f"{n}/barrier_dq_safe"] = np.stack(bdq)
+        for ic in range(len(cJ)):
+            out[f"{n}/constraint{ic}_J"], out[f"{n}/constraint{ic}_e"] = cJ[ic], ce[ic]
+            out[f"{n}/constraint{ic}_gain"] = cgain[ic]
+        if cJ:
+            out[f"{n}/n_constraints"] = len(cJ)
+            out[f"{n}/A"], out[f"{n}/b"] = problem.A, problem.b
         out[f"{n}/P"], out[f"{n}/qvec"] = problem.P, problem.q
         out[f"{n}/G"], out[f"{n}/h"] = problem.G, problem.h
         out[f"{n}/H_task0"], out[f"{n}/c_task0"] = H_tasks[0]

@@ -13,7 +13,7 @@ import numpy as np
 from oracle import c_oracle
 from oracle import pink_oracle as po
 from pink_amd.batch import DenseTaskTerm, DiagonalTaskTerm, pack_terms
-from tests.cases import config_case, golden_case, random_case
+from tests.cases import config_case, golden_case, golden_equalities, random_case
 
 TOL_DQ = 1e-10
 
@@ -45,14 +45,21 @@ def golden(solver, golden_npz, name):
     """Fixture produced by the reference's own build_ik: H, c vs its (P, q); dq vs
     the oracle solving the reference's own (P, q, G, h)."""
     batch, P, q, G, h = golden_case(golden_npz, name)
+    A, b = golden_equalities(golden_npz, name)
     H, c = solver.stack(batch)
     assert np.allclose(H[0], P, rtol=1e-13, atol=1e-15)
     assert np.allclose(c[0], q, rtol=1e-13, atol=1e-15)
     out = solver.solve(batch)
-    x, st, _, _ = c_oracle.gi_solve(P, q, G, h)
+    if A is None:
+        x, st, _, _ = c_oracle.gi_solve(P, q, G, h)
+    else:  # the reference's own (A, b) lead the rows as equalities (quadprog's meq)
+        assert batch.n_eq == len(b)
+        assert np.array_equal(batch.Gd[0, :batch.n_eq], A) and np.array_equal(batch.hd[0, :batch.n_eq], b)
+        x, st, _, _ = c_oracle.gi_solve(P, q, np.vstack([A, G]), np.hstack([b, h]), meq=len(b))
+        assert np.abs(A @ out.dq[0] - b).max() < 1e-12
     assert st == 0 and out.status[0] == 0
     assert np.abs(out.dq[0] - x).max() <= TOL_DQ
-    stat, viol, _ = po.kkt_residuals(P, q, G, h, out.dq[0])
+    stat, viol, _ = po.kkt_residuals(P, q, G, h, out.dq[0], A=A, b=b)
     assert stat < 1e-10 and viol < 1e-11
 
 

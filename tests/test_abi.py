@@ -69,3 +69,17 @@ def test_descriptor_validation(emu):
     ]:
         rc, msg = err(mut)
         assert rc == -1 and re.search(word, msg), (rc, msg)
+
+
+def test_makefile_builds_every_instantiation_of_the_dispatch_table():
+    """dispatch.h (PINKHIP_PACKED_TABLE) is the single source of the (NV, W) instantiations; the Makefile has to
+    compile one translation unit per entry (x DENSE in {0, 1}) or the link fails only on the GPU box."""
+    import re
+
+    csrc = os.path.join(ROOT, "pink_amd", "csrc")
+    table = re.search(r"#define PINKHIP_PACKED_TABLE\(X\)(.*?)\n\n", open(os.path.join(csrc, "dispatch.h")).read(), re.S).group(1)
+    pairs = re.findall(r"X\((\d+), (\d+)\)", table)
+    packed = re.search(r"^PACKED\s*:=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
+    assert packed == [f"{nv}_{w}" for nv, w in pairs] and len(pairs) >= 11
+    for nv, w in pairs:
+        assert int(w) >= int(nv) and int(nv) % 2 == 0 and 64 % int(w) == 0

@@ -328,3 +328,78 @@ def test_urdf_reader_on_reference_robots():
     cfg = Configuration(m, np.array([0.3, -0.4]))
     J = cfg.get_frame_jacobian(m.frames[-1].name)
     assert J.shape == (6, 2) and np.abs(J).max() > 0
+
+
+def test_solve_ik_batch_ragged_dense_rows_safe_displacement_and_constraints(backend):
+    """pack_configurations must not key the batch's dense rows / safe displacements on instance 0:
+    a limit that yields dense rows only at some configurations, a barrier whose safe displacement is zero at
+    others, and constraints= all have to match the per-instance solve_ik."""
+    m = build_chain(6)
+    rng = np.random.default_rng(8)
+    cfgs = [Configuration(m, Q0 + 0.2 * rng.normal(size=6)) for _ in range(5)]
+    task = FrameTask("tool0", 1.0, 1.0, lm_damping=0.1)
+    task.set_target(cfgs[0].get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.0, 0.004, 0.002]))
+    post = PostureTask(cost=1e-2)
+    post.set_target(Q0)
+    free0 = solve_ik_batch(cfgs, [task, post], 5e-3, gpu_frame_tasks=False) * 5e-3  # dq without the extra limit
+
+    class SometimesDense(pink_amd.limits.Limit):
+        """No row at instance 0, an axis-aligned row at instance 1 (goes into the box), k - 1 dense rows at
+        instance k >= 2; the first dense row cuts the unconstrained step in half along its own direction."""
+
+        def compute_qp_inequalities(self, configuration, dt):
+            k = int(np.argmin([np.abs(configuration.q - c.q).max() for c in cfgs]))
+            if k == 0:
+                return None
+            if k == 1:
+                G = np.zeros((1, 6))
+                G[0, 3] = 2.0
+                return G, np.array([1e-3])
+            G = np.ones((k - 1, 6)) + 0.1 * np.arange(6)[None] * np.arange(1, k)[:, None]
+            h = np.full(k - 1, 1.0)
+            G[0] = free0[k] / np.linalg.norm(free0[k])
+            h[0] = 0.5 * np.linalg.norm(free0[k])
+            return G, h
+
+    class SometimesSafe(PositionBarrier):
+        def compute_safe_displacement(self, configuration):
+            k = int(np.argmin([np.abs(configuration.q - c.q).max() for c in cfgs]))
+            return np.zeros(6) if k in (0, 3) else 1e-3 * (k + 1) * np.arange(1.0, 7.0)
+
+    bar = SometimesSafe("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]), safe_displacement_gain=2.0)
+    lims = [m.configuration_limit, m.velocity_limit, SometimesDense()]
+    V = solve_ik_batch(cfgs, [task, post], 5e-3, limits=lims, barriers=[bar], gpu_frame_tasks=False)
+    for b, cfg in enumerate(cfgs):
+        assert np.abs(V[b] - solve_ik(cfg, [task, post], 5e-3, limits=lims, barriers=[bar])).max() < 1e-11, b
+    # the limit really constrains the later instances (the test would be vacuous otherwise)
+    free = solve_ik_batch(cfgs, [task, post], 5e-3, barriers=[bar], gpu_frame_tasks=False)
+    assert np.abs(free[3] - V[3]).max() > 1e-6
+    # constraints= on the batched entry point (pink/solve_ik.py:125-149)
+    # (one constraint list per instance: each robot moves its own tool position by 1 mm, exactly, while the
+    # posture task pulls; position rows only -- six equalities on nv = 6 would leave no freedom for the box)
+    class PositionOf(pink_amd.tasks.Task):
+        def __init__(self, frame_task):
+            super().__init__(cost=1.0, gain=frame_task.gain)
+            self.t = frame_task
+
+        def compute_error(self, configuration):
+            return self.t.compute_error(configuration)[:3]
+
+        def compute_jacobian(self, configuration):
+            return self.t.compute_jacobian(configuration)[:3]
+
+        def __repr__(self):
+            return "PositionOf()"
+
+    holds = []
+    for cfg in cfgs:
+        ft = FrameTask("tool0", 1.0, 1.0)
+        ft.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), [0.0, 1e-3, 0.0]))
+        holds.append([PositionOf(ft)])
+    Vc = solve_ik_batch(cfgs, [post], 5e-3, constraints=holds, gpu_frame_tasks=False)
+    for b, cfg in enumerate(cfgs):
+        hold = holds[b][0]
+        assert np.abs(Vc[b] - solve_ik(cfg, [post], 5e-3, constraints=[hold])).max() < 1e-10
+        J, e = hold.compute_jacobian(cfg), hold.compute_error(cfg)
+        assert np.abs(J @ (Vc[b] * 5e-3) + hold.gain * e).max() < 1e-12
+    assert np.abs(Vc).max() > 1e-3

@@ -9,7 +9,7 @@ from tests import parity_suite as ps
 from tests.cases import CONFIG_CASES
 
 
-@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier"])
+@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier", "equality", "safe"])
 def test_golden_fixture(emu, golden, name):
     ps.golden(emu, golden, name)
 
@@ -89,29 +89,3 @@ def test_equality_edge_cases(emu):
 
 def test_fuzz(emu):
     assert ps.fuzz(emu, range(5000, 5060)) > 100
-
-
-def test_first_generation_kernels_still_agree(built):
-    """PINKHIP_KERNEL=wave selects the one-QP-per-wave kernels of ik_kernels.h (kept for A/B
-    timing); they must keep matching the oracle.  Run in a subprocess because the switch is read
-    when the emulator harness starts."""
-    import os
-    import subprocess
-    import sys
-
-    code = (
-        "import sys, ctypes, os; sys.path.insert(0, %r);"
-        "from tests.conftest import EmuSolver; from tests import parity_suite as ps;"
-        "from pink_amd._lib import Desc, Problem, Result;"
-        "lib = ctypes.CDLL(os.path.join(%r, 'tests', 'emu', 'libpinkemu.so'));"
-        "lib.pinkhip_emu_solve_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)];"
-        "lib.pinkhip_emu_stack_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.c_void_p, ctypes.c_void_p];"
-        "lib.pinkhip_emu_last_error.restype = ctypes.c_char_p; emu = EmuSolver(lib);"
-        "ps.config(emu, 'ur5', 'tight', 'dense', 3); ps.config(emu, 'draco3', 'tight', 'dense', 3);"
-        "ps.config(emu, 'jvrc', 'kinematic', 'kinematic', 2); ps.mixed_status_batch(emu); ps.infeasible(emu);"
-        "ps.not_positive_definite(emu); print('wave-ok')"
-    )
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code % (root, root)], env=dict(os.environ, PINKHIP_KERNEL="wave"),
-                         capture_output=True, text=True, cwd=root, timeout=600)
-    assert out.returncode == 0 and "wave-ok" in out.stdout, out.stderr[-2000:]

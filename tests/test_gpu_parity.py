@@ -15,7 +15,7 @@ from tests.cases import CONFIG_CASES, config_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier"])
+@pytest.mark.parametrize("name", ["ur5", "draco3", "barrier", "equality", "safe"])
 def test_golden_fixture(gpu_solver, golden, name):
     ps.golden(gpu_solver, golden, name)
 

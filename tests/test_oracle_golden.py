@@ -6,7 +6,7 @@ import pytest
 from oracle import c_oracle
 from oracle import pink_oracle as po
 
-NAMES = ["ur5", "draco3", "barrier"]
+NAMES = ["ur5", "draco3", "barrier", "equality", "safe"]
 
 
 def _terms(g, n):
@@ -21,9 +21,15 @@ def _terms(g, n):
     barriers = []
     if f"{n}/barrier_J" in g:
         for i in range(g[f"{n}/barrier_J"].shape[0]):
+            dq_safe = g[f"{n}/barrier_dq_safe"][i] if f"{n}/barrier_dq_safe" in g else None
             barriers.append((g[f"{n}/barrier_J"][i], g[f"{n}/barrier_h"][i], float(g[f"{n}/barrier_gain"][i]),
-                             float(g[f"{n}/barrier_safe_gain"][i]), None))
+                             float(g[f"{n}/barrier_safe_gain"][i]), dq_safe))
     return nv, dt, tasks, blocks, barriers, ci, vi
+
+
+def _constraints(g, n):
+    k = int(g[f"{n}/n_constraints"]) if f"{n}/n_constraints" in g else 0
+    return [(g[f"{n}/constraint{i}_J"], g[f"{n}/constraint{i}_e"], float(g[f"{n}/constraint{i}_gain"])) for i in range(k)]
 
 
 @pytest.mark.parametrize("n", NAMES)
@@ -40,6 +46,20 @@ def test_build_qp_matches_reference_build_ik(golden, n):
     H0, c0 = po.task_objective(*tasks[0])
     assert np.allclose(H0, golden[f"{n}/H_task0"], rtol=1e-13, atol=1e-15)
     assert np.allclose(c0, golden[f"{n}/c_task0"], rtol=1e-13, atol=1e-15)
+    # constraints= (pink/solve_ik.py:125-149): A, b as the reference's build_ik returned them
+    A, b = po.qp_equalities(_constraints(golden, n))
+    if f"{n}/A" in golden:
+        assert np.array_equal(A, golden[f"{n}/A"]) and np.allclose(b, golden[f"{n}/b"], rtol=1e-15, atol=0)
+    else:
+        assert A is None and b is None
+
+
+def test_safe_displacement_fixture_has_a_linear_term(golden):
+    """The fixture really exercises c += -rho dq_safe (barrier.py:201): q differs from the value without it."""
+    nv, dt, tasks, blocks, barriers, _, _ = _terms(golden, "safe")
+    no_safe = [(J, hv, g, r, None) for (J, hv, g, r, _dq) in barriers]
+    _, q0, _, _ = po.build_qp(nv, tasks, 1e-12, blocks, no_safe, dt)
+    assert np.abs(q0 - golden["safe/qvec"]).max() > 1e-3
 
 
 @pytest.mark.parametrize("n", NAMES)
@@ -51,14 +71,23 @@ def test_c_oracle_stacking_matches_reference(golden, n):
     rows = np.cumsum([0] + [t[0].shape[0] for t in tasks]).astype(np.int32)
     gain = np.array([t[3] for t in tasks])
     lm = np.array([t[4] for t in tasks])
-    diag_extra = None
+    diag_extra = c_extra = None
     if barriers:
-        diag_extra = np.array([sum(b[3] / np.linalg.norm(b[0]) ** 2 for b in barriers)])
-    out = c_oracle.solve_ik_batch(J, e, cost, gain, lm, rows, 1e-12, golden[f"{n}/G"][None], golden[f"{n}/h"][None],
-                                  diag_extra=diag_extra, want_Hc=True)
+        rho = [b[3] / np.linalg.norm(b[0]) ** 2 for b in barriers]
+        diag_extra = np.array([sum(rho)])
+        if any(b[4] is not None for b in barriers):
+            c_extra = -sum(r * b[4] for r, b in zip(rho, barriers))[None]
+    G, h, meq = golden[f"{n}/G"], golden[f"{n}/h"], 0
+    A = golden[f"{n}/A"] if f"{n}/A" in golden else None
+    b = golden[f"{n}/b"] if f"{n}/A" in golden else None
+    if A is not None:
+        G, h, meq = np.vstack([A, G]), np.hstack([b, h]), len(b)
+    out = c_oracle.solve_ik_batch(J, e, cost, gain, lm, rows, 1e-12, G[None], h[None],
+                                  diag_extra=diag_extra, c_extra=c_extra, want_Hc=True, meq=meq)
     assert np.allclose(out["H"][0], golden[f"{n}/P"], rtol=1e-13, atol=1e-15)
     assert np.allclose(out["c"][0], golden[f"{n}/qvec"], rtol=1e-13, atol=1e-15)
-    # and the solve on the reference's own (P, q, G, h) is KKT-certified
+    # and the solve on the reference's own (P, q, G, h, A, b) is KKT-certified
     assert out["status"][0] == 0
-    stat, viol, lam = po.kkt_residuals(golden[f"{n}/P"], golden[f"{n}/qvec"], golden[f"{n}/G"], golden[f"{n}/h"], out["dq"][0])
+    stat, viol, lam = po.kkt_residuals(golden[f"{n}/P"], golden[f"{n}/qvec"], golden[f"{n}/G"], golden[f"{n}/h"],
+                                       out["dq"][0], A=A, b=b)
     assert stat < 1e-10 and viol < 1e-12

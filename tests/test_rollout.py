@@ -217,3 +217,43 @@ def test_fused_fk_frame_tasks_equal_separate_launches(api, which):
             t.set_target(SE3(targets[b, i, :9].reshape(3, 3), targets[b, i, 9:]))
             assert np.abs(t.compute_error(cfg) - rows[0][0][b, 6 * i:6 * i + 6]).max() < 1e-10
             assert np.abs(t.compute_jacobian(cfg) - rows[0][1][b, 6 * i:6 * i + 6]).max() < 1e-9
+
+
+def test_failed_solves_are_not_integrated_and_stay_visible(api):
+    """A robot whose QP fails (here: iteration cap of one active-set step) must keep its configuration -- the
+    reference raises NoSolutionFound before integrating (pink/solve_ik.py:271-275) -- and the failure must
+    survive later steps (first failure is sticky); run() raises listing those robots."""
+    from pink_amd.exceptions import NoSolutionFound, NotWithinConfigurationLimits
+
+    model, frames = _models()[0]
+    rng = np.random.default_rng(77)
+    B, dt = 6, 5e-3
+    q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
+    specs = [(f, 1.0, 0.5, 1.0, 1e-3) for f in frames]
+    targets = np.zeros((B, len(frames), 12))
+    for b in range(B):
+        cfg = Configuration(model, q0[b])
+        for i, f in enumerate(frames):
+            # robots 0..2: far targets (velocity limits become active: more than one active-set step);
+            # robots 3..5: target = current pose (no active constraint, solved without any step)
+            far = SE3(np.eye(3), (2.0 if b < 3 else 0.0) * np.ones(3))
+            targets[b, i] = pose12(cfg.get_transform_frame_to_world(f) * far)
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=None, max_iter=1)
+    ro.set_targets(targets)
+    with pytest.raises(NoSolutionFound) as info:
+        ro.run(3)
+    idx, status, step = ro.failures()
+    assert np.array_equal(info.value.indices, idx) and set(idx) <= {0, 1, 2} and idx.size >= 1
+    assert (status == 1).all() and (step == 0).all()  # STATUS_MAX_ITER at the very first step, still visible after 3
+    q = ro.configurations()
+    assert np.array_equal(q[idx], q0[idx])  # frozen: the partial iterate was never applied
+    ok = np.setdiff1d(np.arange(B), idx)
+    assert np.isfinite(q).all() and ok.size >= 3
+    ro.free()
+    # initial configurations outside the joint limits are refused like solve_ik's check_limits does
+    bad = q0.copy()
+    j = int(np.nonzero(np.isfinite(model.upperPositionLimit))[0][0])
+    bad[2, j] = model.upperPositionLimit[j] + 0.5
+    with pytest.raises(NotWithinConfigurationLimits) as lim:
+        DeviceRollout(api, model, bad, specs, dt)
+    assert lim.value.instance == 2 and lim.value.joint == j
