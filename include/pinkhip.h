@@ -246,11 +246,15 @@ int pinkhip_integrate_checked_device(pinkhip_handle *h, const pinkhip_model *mod
  *   pinkhip_comm_init           every rank joins (collective call)
  *   pinkhip_comm_gather         count doubles from every rank's d_send to root's d_recv
  *                               [nranks * count] (device pointers; d_recv ignored off root);
- *                               enqueued on the handle's stream */
+ *                               enqueued on the handle's stream
+ *   pinkhip_comm_gather_bytes   same for raw bytes (the int32 status / iteration counts)
+ *   pinkhip_comm_allgather_bytes  every rank receives every shard: d_recv [nranks * nbytes] on all ranks */
 #define PINKHIP_COMM_ID_BYTES 128
 int pinkhip_comm_get_unique_id(char *id /* [PINKHIP_COMM_ID_BYTES] */);
 int pinkhip_comm_init(pinkhip_handle *h, const char *id, int rank, int nranks);
 int pinkhip_comm_gather(pinkhip_handle *h, const double *d_send, double *d_recv, int64_t count, int root);
+int pinkhip_comm_gather_bytes(pinkhip_handle *h, const void *d_send, void *d_recv, int64_t nbytes, int root);
+int pinkhip_comm_allgather_bytes(pinkhip_handle *h, const void *d_send, void *d_recv, int64_t nbytes);
 int pinkhip_comm_destroy(pinkhip_handle *h);
 
 /* ---- device memory, stream, timing ------------------------------------- */
@@ -258,6 +262,7 @@ int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
 int pinkhip_free(pinkhip_handle *h, void *dptr);
 int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes); /* stream-ordered, asynchronous */
 int pinkhip_sync(pinkhip_handle *h);
 /* HIP events recorded on the handle's stream around whatever is enqueued in
  * between; elapsed_ms is valid after pinkhip_timer_stop returns. */

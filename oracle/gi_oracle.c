@@ -71,7 +71,9 @@ int oracle_gi_solve_eq(int n, const double *P, const double *q, int m, int meq, 
   int *A = (int *)(uall + m);  /* n   active row indices (as ints)     */
   int *is_active = A + n + 2;  /* m                                    */
   int it = 0, qa = 0, eq_next = 0;
-  const double tol = 1e-13;
+  /* violation threshold relative to 1 + |b_i| / |n_i|: round-off of the iterate grows with the dimension
+   * (n dot products of length n per step), so does the threshold: 1e-13 up to n = 8, 1e-13 n / 8 beyond */
+  const double tol = 1e-13 * (n > 8 ? n / 8.0 : 1.0);
 
   if (iters) *iters = 0;
   if (max_iter <= 0) max_iter = 20 * (n + m) + 50;
@@ -350,7 +352,7 @@ int oracle_solve_ik_batch(long B, int nv, int T, const int *rows, const double *
     double *wj = c + nv;
     double *work = (double *)malloc(sizeof(double) * oracle_gi_work_size(nv, m));
     if (!H || !work) failed = 1;
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(static) /* contiguous chunks: one thread streams one range of the batch */
     for (long b = 0; b < B; ++b) {
       if (failed) continue;
       for (long i = 0; i < (long)nv * nv; ++i) H[i] = 0.0;

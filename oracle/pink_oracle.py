@@ -285,7 +285,7 @@ def goldfarb_idnani(
     active: list = []
     u = np.zeros(0)
     iterations = 0
-    tol = 1e-13
+    tol = 1e-13 * max(1.0, n / 8.0)  # grows with the dimension like the round-off of the iterate (gi_oracle.c)
 
     while True:
         s = N_all.T @ x - b_all

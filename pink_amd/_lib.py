@@ -91,9 +91,10 @@ ABI_SYMBOLS = (
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
     "pinkhip_fk_frame_tasks_device",
     "pinkhip_limits_posture_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
-    "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_destroy",
+    "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
+    "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_malloc", "pinkhip_free",
-    "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_sync", "pinkhip_timer_start",
+    "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
     "pinkhip_timer_stop",
 )
 
@@ -137,11 +138,14 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.pinkhip_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.pinkhip_comm_gather.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int]
+    lib.pinkhip_comm_gather_bytes.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int]
+    lib.pinkhip_comm_allgather_bytes.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_comm_destroy.argtypes = [vp]
     lib.pinkhip_malloc.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_int64]
     lib.pinkhip_free.argtypes = [vp, vp]
     lib.pinkhip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_memcpy_d2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_sync.argtypes = [vp]
     lib.pinkhip_timer_start.argtypes = [vp]
     lib.pinkhip_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]

@@ -222,6 +222,10 @@ class BatchSolver:
     def get(self, arr: np.ndarray, ptr: int) -> None:
         self._d2h(arr, ptr)
 
+    def copy_d2d(self, dst: int, src: int, nbytes: int) -> None:
+        """Stream-ordered device-to-device copy (asynchronous)."""
+        self._check(self._lib.pinkhip_memcpy_d2d(self._h, ctypes.c_void_p(dst), ctypes.c_void_p(src), int(nbytes)))
+
     def model_create(self, desc) -> int:
         m = ctypes.c_void_p()
         self._check(self._lib.pinkhip_model_create(self._h, ctypes.byref(desc), ctypes.byref(m)))
@@ -270,6 +274,13 @@ class BatchSolver:
         """``count`` doubles from every rank's device buffer to ``root``'s ``[nranks * count]``."""
         self._check(self._lib.pinkhip_comm_gather(self._h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv or 0),
                                                   int(count), int(root)))
+
+    def comm_gather_bytes(self, d_send: int, d_recv: Optional[int], nbytes: int, root: int = 0) -> None:
+        self._check(self._lib.pinkhip_comm_gather_bytes(self._h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv or 0),
+                                                        int(nbytes), int(root)))
+
+    def comm_allgather_bytes(self, d_send: int, d_recv: int, nbytes: int) -> None:
+        self._check(self._lib.pinkhip_comm_allgather_bytes(self._h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv), int(nbytes)))
 
     def comm_destroy(self) -> None:
         self._check(self._lib.pinkhip_comm_destroy(self._h))

@@ -6,8 +6,12 @@
 
 // X(NV, W): NV = nv padded to the next instantiated even size (padded coordinates cost FMAs and LDS traffic),
 // W = lanes per QP (64 / W QPs per wavefront).  Every pair is built with and without the dense-row machinery.
+#ifdef PINKHIP_DEV_NV  // kernel-development builds: one instantiation only (make DEV=1 [DEVNV=50 DEVW=64], ~20 s)
+#define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
+#else
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
-  X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(56, 64) X(64, 64)
+  X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
+#endif
 
 namespace pinkhip {
 

@@ -82,7 +82,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   constexpr double BIG = 1e300;
   // groups made of whole rows of 16 lanes multiply lane-held vectors into lane-local accumulators with the
   // broadcast-FMA of wave.h (no LDS); 8-lane groups keep the LDS broadcast
-  constexpr bool kBc = W >= 16;
+  // (NV = 64 keeps the LDS broadcast: with the broadcast-FMA its fully unrolled body sends LLVM's CodeGenPrepare
+  // pass from 2 minutes at NV = 56 to 8 minutes per translation unit)
+  constexpr bool kBc = W >= 16 && NV <= 56;
   using BcT = Bcast<(W >= 16 ? W : 16)>;
 
   const int lane = lane_id();
@@ -282,8 +284,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         }
       }
     }
+    // (columns nv .. NV of the staged rows: read by the eight-wide slack products, must be zero)
+    for (int idx = li; idx < md * (GP - nv); idx += W) Gs[(idx / (GP - nv)) * GP + nv + idx % (GP - nv)] = 0.0;
     wave_sync();
-    if (li < md) {  // md <= 32; for W < md the remaining rows are handled below
+    if (li < md) {  // dispatch.h guarantees md <= W: one lane per dense row
       hv = a.hd[b * (long long)md + li];
       double s = 0.0;
       for (int j = 0; j < nv; ++j) s += Gs[li * GP + j] * Gs[li * GP + j];
@@ -345,7 +349,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if constexpr (kBc) {
       // column j (lane m holds H~[m][j]) and the right-hand side stay in the lanes: pivot, y_j and the
       // trailing update read them through the DPP broadcast -- no LDS write, no barrier, no read-back
-      xb = bcast_prepare<W>(li < NV ? M[j] : 0.0);
+      xb = bcast_prepare<W>(M[j]);  // idle lanes (li >= NV) hold zero rows: nothing to mask
       const BcT yb = bcast_prepare<W>(cp);
       p = value_bcast<W, j>(xb);
       yraw = value_bcast<W, j>(yb);
@@ -381,7 +385,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       // of L (lane jj holds L[jj][j])
       Jr[j] *= rinv;
       if constexpr (j + 1 < NV) {
-        const BcT lb = bcast_prepare<W>((li > j && li < NV) ? lij : 0.0);
+        // only lanes jj > j are ever read from this vector (source lane of Jr[jj]'s update): no mask needed
+        const BcT lb = bcast_prepare<W>(lij);
         const double nyj = -Jr[j];
         static_for<j + 1, NV>([&](auto Jn) {
           constexpr int jj = decltype(Jn)::value;
@@ -443,7 +448,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   // ------------------------------------------------------------------ Goldfarb-Idnani, flat
   const double lbv = in ? a.lb[b * (long long)nv + li] : -INF;
   const double ubv = in ? a.ub[b * (long long)nv + li] : INF;
-  const double tol = 1e-13;
+  // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension (nv dot
+  // products of length nv per step) and so does the threshold; same rule as oracle/gi_oracle.c
+  const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
   const double thr_lo = (in && lbv > -INF) ? -tol * (1.0 + fabs(lbv)) : -INF;
   const double thr_up = (in && ubv < INF) ? -tol * (1.0 + fabs(ubv)) : -INF;
   const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
@@ -462,24 +469,42 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (wave_any(running && need_sel)) {
       double best = BIG, sd = 0.0;
       const double slo = x - lbv, sup = ubv - x;
-      if (bstate != 1 && slo < thr_lo) best = key_pack(slo, li);
-      if (bstate != 2 && sup < thr_up && sup < best) best = key_pack(sup, 64 + li);
+      int bestid = 0;
+      if (bstate != 1 && slo < thr_lo) best = slo, bestid = li;
+      if (bstate != 2 && sup < thr_up && sup < best) best = sup, bestid = 64 + li;
       if (md > 0) {
         if (li < NV) xs[li] = x;
         wave_sync();
         if (li < md) {
+          // slack of dense row li: eight entries of the row and of x per LDS round trip (columns nv..NV-1 of
+          // the staged rows are zero, x is zero there as well)
           double s = hv;
-          for (int j = 0; j < nv; ++j) s -= Gs[li * GP + j] * xs[j];
+          const double *gr = Gs + li * GP;
+#pragma unroll
+          for (int j0 = 0; j0 < NV; j0 += 8) {
+            if (j0 < nv) {
+              double gv[8], xv[8];
+#pragma unroll
+              for (int m = 0; m < 8; ++m) {
+                gv[m] = (j0 + m < NV) ? gr[j0 + m] : 0.0;
+                xv[m] = (j0 + m < NV) ? xs[j0 + m] : 0.0;
+              }
+              pin16(gv, xv);
+#pragma unroll
+              for (int m = 0; m < 8; ++m) s -= gv[m] * xv[m];
+              pin(s);
+            }
+          }
           sd = s;
           const double sc = s * ginv;
-          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best)
-            best = key_pack(sc, 128 + li);
+          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) best = sc, bestid = 128 + li;
         }
         wave_sync();
       }
-      best = group_min<W>(best);
+      // any violated constraint is a valid choice: the arg-min runs on a 32-bit key (one DPP min per step)
+      const float best32 = group_min32<W>(best < 0.0 ? key32_pack(best, bestid) : 3.0e38f);
+      const bool none = !(best32 < 0.0f);
       const bool sel = running && need_sel;
-      const bool none = !(best < 0.0);
       // equalities (the first n_eq dense rows; pink/solve_ik.py:140-149) are activated first, in
       // order, with the normal oriented so that the residual reads as a violation (kind 3 = +g)
       const bool eqsel = sel && eq_next < n_eq;
@@ -499,7 +524,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       }
       if (sel && !eqsel && none) running = false;  // optimal
       if (sel && !eqsel && !none) {
-        bid = key_payload(best);
+        bid = key32_payload(best32);
         kind = DENSE ? bid >> 6 : (bid >> 6) & 1;
         src = bid & 63;
         uplus = 0.0;
@@ -551,10 +576,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
     const bool lin_dep = !(d2n * 1e24 > dd);  // (the product sits on d2n: dd's broadcast is waited for after the reduction)
     const double dq_ = group_bcast<W>(dl, q < W ? q : W - 1);
-    const double rn2 = lin_dep ? 0.0 : fast_rsqrt(lin_dep ? 1.0 : d2n);
+    const double rn2 = lin_dep ? 0.0 : fast_rsqrt1(lin_dep ? 1.0 : d2n);
     const double nrm2 = d2n * rn2;
     const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
-    const double beta = lin_dep ? 0.0 : rn2 * fast_rcp(lin_dep ? 1.0 : nrm2 + fabs(dq_));
+    const double beta = lin_dep ? 0.0 : rn2 * fast_rcp1(lin_dep ? 1.0 : nrm2 + fabs(dq_));
     const double vv = (li > q) ? dl : (li == q ? dl + ((dl >= 0.0) ? nrm2 : -nrm2) : 0.0);  // lane q holds d_q itself
     if (li < NV) {
       ds[li] = (li < q) ? dl : 0.0;  // d1, followed by the zeros of zs
@@ -623,7 +648,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     // (c) step lengths
     const bool eq_pos = DENSE && (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
     const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
-    const double ratio = blocking ? u * fast_rcp(rv) : BIG;
+    const double ratio = blocking ? u * fast_rcp1(rv) : BIG;
     const double k1 = group_min<W>(blocking ? key_pack(ratio, li) : BIG);
     const int kd = key_payload(k1) & (W - 1);
     const double t1b = group_bcast<W>(ratio, kd);  // unconditional: cross-lane ops must not diverge
@@ -724,7 +749,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
         const double pc = inrow ? Ts[((mk * (2 * NV + 1 - mk)) >> 1) + kd] : 0.0;            // P[kd][li]
         const double pn = rl ? Ts[(((mk + 1) * (2 * NV - mk)) >> 1) + kd] : 0.0;              // P[kd][li + 1]
         const double S = group_scan_sum<W>(pc * pc);
-        const double rs = fast_rsqrt(rl ? S : 1.0), rn = fast_rsqrt(rl ? S + pn * pn : 1.0);
+        const double rs = fast_rsqrt1(rl ? S : 1.0), rn = fast_rsqrt1(rl ? S + pn * pn : 1.0);
         const double al = (li == kd) ? pc : S * rs;
         if (li < NV) {
           d2s[2 * li] = rl ? pn * rn : 1.0;    // cos

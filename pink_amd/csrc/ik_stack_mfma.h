@@ -18,8 +18,8 @@ namespace pinkhip {
 template <int NT>
 __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) {
   double *sm = shared_base();
-  double *was = sm;        // [K]   w_k^2
-  double *gws = sm + 128;  // [K]   gain_k w_k^2 e_k        (K <= 128 per pass)
+  double *was = sm;        // [128] w_k^2 of the current pass
+  double *gws = sm + 128;  // [128] gain_k w_k^2 e_k
   const int lane = lane_id();
   const int nv = a.nv, Kd = a.Kd, K = a.K;
   const int col = lane & 15, rq = lane >> 4;
@@ -27,83 +27,51 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
   const double *Jb = a.J + b * (long long)Kd * nv;
   const double *eb = a.e + b * (long long)K;
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
+  double *Hb = a.H_out + b * (long long)nv * nv;
 
-  v4d acc[NT][NT];
-#pragma unroll
-  for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[ti][tj][r] = 0.0;
-  double cpart[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) cpart[t] = 0.0;
-  double mu_l = 0.0;
-
-  // dense rows, 128 at a time through the LDS coefficient table; inside a pass, 32 rows (eight MFMA
-  // k-steps) of J are requested from HBM at once and the first request goes out before the table is
-  // built, so a wave pays one memory round trip per 32 rows instead of one per k-step
+  // Dense rows are consumed 32 at a time (eight MFMA k-steps requested from HBM at once: one memory round
+  // trip per 32 rows) and ONE ROW OF TILES at a time: NT accumulators are live and leave for HBM as soon as
+  // their K loop is done, instead of NT x NT tiles (276 VGPRs = one wave per SIMD at NT = 4; a streaming
+  // kernel needs the occupancy to hide the HBM latency).  When all dense rows fit one request (Kd <= 32:
+  // every BASELINE configuration) J stays in registers for all tile rows; larger task stacks re-request it
+  // per tile row and are served by L2.
   constexpr int kSteps = 8;
-  for (int r0 = 0; r0 < Kd; r0 += 128) {
-    const int rc = (Kd - r0 < 128) ? Kd - r0 : 128;
-    double Jp[kSteps][NT];
-    auto request = [&](int c0) {
+  const bool one_pass = Kd <= 4 * kSteps;
+  double Jp[kSteps][NT];
+  auto request = [&](int r0) {
 #pragma unroll
-      for (int st = 0; st < kSteps; ++st) {
-        const int kk = c0 + 4 * st + rq;  // this lane's task row inside the pass
+    for (int st = 0; st < kSteps; ++st) {
+      const int kk = r0 + 4 * st + rq;  // this lane's task row
 #pragma unroll
-        for (int tc = 0; tc < NT; ++tc) {
-          const int j = 16 * tc + col;
-          Jp[st][tc] = (kk < rc && j < nv) ? Jb[(long long)(r0 + kk) * nv + j] : 0.0;
-        }
+      for (int tc = 0; tc < NT; ++tc) {
+        const int j = 16 * tc + col;
+        Jp[st][tc] = (kk < Kd && j < nv) ? Jb[(long long)kk * nv + j] : 0.0;
       }
-    };
-    request(0);
+    }
+  };
+  auto build_table = [&](int p0) {  // coefficients of the 128 rows from p0 on
+    const int rc = (Kd - p0 < 128) ? Kd - p0 : 128;
     wave_sync();
     for (int rr = lane; rr < rc; rr += kWave) {
-      const int k = r0 + rr;
-      const double w = costb[k], ev = eb[k], g = a.row_gain[k], l = a.row_lm[k];
+      const int k = p0 + rr;
+      const double w = costb[k], ev = eb[k];
       const double wa = w * w;
       was[rr] = wa;
-      gws[rr] = g * wa * ev;
-      mu_l += l * (g * g) * wa * ev * ev;
+      gws[rr] = a.row_gain[k] * wa * ev;
     }
     wave_sync();
-    for (int c0 = 0; c0 < rc; c0 += 4 * kSteps) {
-      if (c0 > 0) request(c0);
-#pragma unroll
-      for (int st = 0; st < kSteps; ++st) {
-        if (c0 + 4 * st < rc) {  // wave-uniform
-          const int kk = c0 + 4 * st + rq;
-          const bool krow = kk < rc;
-          const double wa = krow ? was[kk] : 0.0;
-          const double gw = krow ? gws[kk] : 0.0;
-          double Av[NT];
-#pragma unroll
-          for (int tc = 0; tc < NT; ++tc) {
-            Av[tc] = wa * Jp[st][tc];
-            cpart[tc] += gw * Jp[st][tc];
-          }
-#pragma unroll
-          for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = mfma_f64_16x16x4(Av[ti], Jp[st][tj], acc[ti][tj]);
-        }
-      }
-    }
-  }
+  };
+  if (Kd > 0) request(0);  // in flight while the scalars are computed
 
-  // c of the dense tasks: sum the four row quarters, lane i keeps coordinate i
-  double ci = 0.0;
-#pragma unroll
-  for (int tc = 0; tc < NT; ++tc) {
-    double s = cpart[tc];
-    s += lane_shfl(s, lane ^ 16);
-    s += lane_shfl(s, lane ^ 32);
-    if (rq == tc) ci = s;
+  // ---- scalars: Levenberg-Marquardt mu over all task rows, c and diagonal of the diagonal tasks, barriers
+  double mu_l = 0.0;
+  for (int k = lane; k < Kd; k += kWave) {
+    const double w = costb[k], ev = eb[k], g = a.row_gain[k];
+    mu_l += a.row_lm[k] * (g * g) * (w * w) * ev * ev;
   }
   // diagonal tasks (J = eye[col0:col0+k], posture_task.py:128-129) in the lane = coordinate layout
   const bool in = lane < nv;
+  double ci = 0.0;
   if (in) {
     for (int t = 0; t < a.n_dtasks; ++t) {
       const int off = lane - a.dtask_col0[t];
@@ -129,10 +97,45 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
       diag += r / (s * a.dt * a.dt);
     }
   }
-  // diagonal entries live in lanes with (lane >> 4) == (col & 3), element col >> 2 of the diagonal tiles
-  if (rq == (col & 3)) {
+  if (one_pass && Kd > 0) build_table(0);
+
+  double cpart[NT];
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
+  for (int t = 0; t < NT; ++t) cpart[t] = 0.0;
+
+  // ---- one row of tiles at a time
+  static_for<0, NT>([&](auto TI) {
+    constexpr int ti = decltype(TI)::value;
+    v4d acc[NT];
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[tj][r] = 0.0;
+    for (int p0 = 0; p0 < Kd; p0 += 128) {
+      const int rc = (Kd - p0 < 128) ? Kd - p0 : 128;
+      if (!one_pass) build_table(p0);
+      for (int c0 = 0; c0 < rc; c0 += 4 * kSteps) {
+        if (!one_pass) request(p0 + c0);
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+          if (c0 + 4 * st < rc) {  // wave-uniform
+            const int kk = c0 + 4 * st + rq;
+            const bool krow = kk < rc;
+            const double wa = krow ? was[kk] : 0.0;
+            const double Av = wa * Jp[st][ti];
+            if constexpr (ti == 0) {
+              const double gw = krow ? gws[kk] : 0.0;
+#pragma unroll
+              for (int tc = 0; tc < NT; ++tc) cpart[tc] += gw * Jp[st][tc];
+            }
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[tj] = mfma_f64_16x16x4(Av, Jp[st][tj], acc[tj]);
+          }
+        }
+      }
+    }
+    // diagonal entries live in lanes with (lane >> 4) == (col & 3), element col >> 2 of the diagonal tile
+    if (rq == (col & 3)) {
       const int i = 16 * ti + col;
       double dd = diag;
       for (int t = 0; t < a.n_dtasks; ++t) {
@@ -144,22 +147,28 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (r == (col >> 2)) acc[ti][ti][r] += dd;
+        if (r == (col >> 2)) acc[ti][r] += dd;
     }
-  }
-  // write-out: element r of tile (ti, tj) is H[16 ti + rq + 4 r][16 tj + col]
-  double *Hb = a.H_out + b * (long long)nv * nv;
-#pragma unroll
-  for (int ti = 0; ti < NT; ++ti)
+    // write-out: element r of tile (ti, tj) is H[16 ti + rq + 4 r][16 tj + col] (16 lanes = 128 contiguous bytes)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * ti + rq + 4 * r;
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
         const int j = 16 * tj + col;
-        if (i < nv && j < nv) Hb[(long long)i * nv + j] = acc[ti][tj][r];
+        if (i < nv && j < nv) Hb[(long long)i * nv + j] = acc[tj][r];
       }
     }
+  });
+
+  // c of the dense tasks: sum the four row quarters, lane i keeps coordinate i
+#pragma unroll
+  for (int tc = 0; tc < NT; ++tc) {
+    double s = cpart[tc];
+    s += lane_shfl(s, lane ^ 16);
+    s += lane_shfl(s, lane ^ 32);
+    if (rq == tc) ci += s;
+  }
   if (in) a.c_out[b * (long long)nv + lane] = ci;
 }
 

@@ -613,6 +613,7 @@ struct Rccl {
   int (*CommInitRank)(void **, int, pinkhip_unique_id_t, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   int (*Gather)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl &rccl() {
@@ -630,8 +631,9 @@ int rccl_load(pinkhip_handle *h) {
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
   r.Gather = reinterpret_cast<decltype(r.Gather)>(dlsym(r.so, "ncclGather"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather || !r.GetErrorString) {
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather || !r.AllGather || !r.GetErrorString) {
     r.so = nullptr;
     return fail(h, PINKHIP_E_COMM, "librccl lacks ncclGather / ncclCommInitRank");
   }
@@ -680,6 +682,27 @@ int pinkhip_comm_gather(pinkhip_handle *h, const double *d_send, double *d_recv,
   return PINKHIP_OK;
 }
 
+int pinkhip_comm_gather_bytes(pinkhip_handle *h, const void *d_send, void *d_recv, int64_t nbytes, int root) {
+  if (!h || !h->comm) return fail(h, PINKHIP_E_INVALID, "communicator not initialised");
+  if (nbytes < 0 || root < 0 || root >= h->comm_size || !d_send || (h->comm_rank == root && !d_recv))
+    return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (nbytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  const int rc = rccl().Gather(d_send, d_recv, static_cast<size_t>(nbytes), 0 /* ncclInt8 */, root, h->comm, h->stream);
+  if (rc) return rccl_fail(h, "ncclGather", rc);
+  return PINKHIP_OK;
+}
+
+int pinkhip_comm_allgather_bytes(pinkhip_handle *h, const void *d_send, void *d_recv, int64_t nbytes) {
+  if (!h || !h->comm) return fail(h, PINKHIP_E_INVALID, "communicator not initialised");
+  if (nbytes < 0 || !d_send || !d_recv) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (nbytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  const int rc = rccl().AllGather(d_send, d_recv, static_cast<size_t>(nbytes), 0 /* ncclInt8 */, h->comm, h->stream);
+  if (rc) return rccl_fail(h, "ncclAllGather", rc);
+  return PINKHIP_OK;
+}
+
 int pinkhip_comm_destroy(pinkhip_handle *h) {
   if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
   if (h->comm) {
@@ -723,6 +746,14 @@ int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t by
   PH_HIP(h, hipSetDevice(h->device));
   PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, h->stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToDevice, h->stream));
   return PINKHIP_OK;
 }
 

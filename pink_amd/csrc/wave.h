@@ -170,6 +170,19 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return fma(0.5 * y, e, y);
 }
 
+// One Newton step (~2e-14 relative): for quantities that only steer the active-set iteration or are
+// re-orthogonalised anyway; the Cholesky pivots keep the two-step version.
+__device__ __forceinline__ double fast_rcp1(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double fast_rsqrt1(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
 
@@ -288,6 +301,34 @@ __device__ __forceinline__ double group_min(double v) {
   if (W == 64) v = min_raw(bcast(v, 0), bcast(v, 32));
   return v;
 }
+// Arg-min over a group on a 32-bit key (float with an 8-bit payload in the low mantissa bits): one
+// v_min_f32_dpp per butterfly step.  Only for *choosing* a lane where any candidate is a valid choice (the
+// most violated constraint); exact values are fetched from the winner afterwards.
+__device__ __forceinline__ float key32_pack(double v, int payload) {
+  const float f = static_cast<float>(v);
+  return __int_as_float((__float_as_int(f) & ~0xFF) | (payload & 0xFF));
+}
+__device__ __forceinline__ int key32_payload(float k) { return __float_as_int(k) & 0xFF; }
+#define PINKHIP_MIN32_DPP(ctrl)                                                                          \
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v)); \
+  v = r;
+template <int W>
+__device__ __forceinline__ float group_min32(float v) {
+  float r;
+  PINKHIP_MIN32_DPP("quad_perm:[1,0,3,2]")
+  PINKHIP_MIN32_DPP("quad_perm:[2,3,0,1]")
+  PINKHIP_MIN32_DPP("row_half_mirror")
+  if (W >= 16) { PINKHIP_MIN32_DPP("row_mirror") }
+  if (W >= 32) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fminf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  if (W == 64) v = fminf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0)),
+                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32)));
+  return v;
+}
+#undef PINKHIP_MIN32_DPP
+
 // Inclusive prefix sum inside each group of W lanes (lane li gets v_0 + ... + v_li): Hillis-Steele with
 // DPP row shifts inside the rows of 16, then the row totals through row_bcast15 / row_bcast31.
 template <int N>

@@ -1,10 +1,14 @@
-"""Batch sharding over the GPUs of one node (one process per GPU).
+"""Batch sharding over the GPUs of one node (one process per GPU) -- no PyTorch.
 
 IK instances are independent, so a batch is split into contiguous ranges
 (SURVEY.md section 8e): rank ``r`` of ``W`` solves ``[lo, hi)`` on its own
 device and nothing is exchanged while solving.  The only collective is the
-optional gather of ``dq`` to one rank afterwards (RCCL when the process group
-is ``nccl``, gloo on CPU for tests).
+optional gather of ``dq`` (+ status, iteration counts) to one rank afterwards:
+``ncclGather`` over xGMI through the C ABI (:class:`pink_amd.comm.RcclComm`), from
+the device buffers the solve kernel wrote into device buffers of the root, then
+one D2H copy.  :class:`pink_amd.comm.HostComm` moves host arrays over the
+rendezvous sockets instead (solvers without device memory: the CPU wave emulator
+of the tests).
 """
 
 from __future__ import annotations
@@ -15,6 +19,7 @@ import numpy as np
 
 from .batch import IKBatch
 from .batch_solver import BatchResult
+from .comm import RcclComm
 
 
 def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
@@ -26,37 +31,68 @@ def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def solve_sharded(batch: IKBatch, solver, rank: int, world: int, gather_to: Optional[int] = 0,
-                  group=None, device: str = "cpu") -> Optional[BatchResult]:
-    """Solve this rank's shard with ``solver`` and gather the results.
+def _assemble(parts, sizes, nv) -> BatchResult:
+    """``parts[r] = (dq, status, iters)`` padded to the largest shard -> the full batch."""
+    dq = np.concatenate([np.asarray(p[0]).reshape(-1, nv)[: h - l] for p, (l, h) in zip(parts, sizes)], axis=0)
+    st = np.concatenate([np.asarray(p[1])[: h - l] for p, (l, h) in zip(parts, sizes)])
+    it = np.concatenate([np.asarray(p[2])[: h - l] for p, (l, h) in zip(parts, sizes)])
+    return BatchResult(np.ascontiguousarray(dq), np.ascontiguousarray(st, dtype=np.int32), np.ascontiguousarray(it, dtype=np.int32))
+
+
+def solve_sharded(batch: IKBatch, solver, comm, gather_to: Optional[int] = 0) -> Optional[BatchResult]:
+    """Solve this rank's shard with ``solver`` and gather the results through ``comm``.
 
     Returns the full :class:`BatchResult` on rank ``gather_to`` (every rank when
-    ``gather_to`` is ``None``: all-gather), ``None`` elsewhere.  ``device`` is where
-    the collective's buffers live ("cuda" with the nccl/RCCL backend).
+    ``gather_to`` is ``None``: all-gather), ``None`` elsewhere.  With an
+    :class:`~pink_amd.comm.RcclComm` the shard stays on the device between the
+    solve and the collective; any other comm object only needs
+    ``rank, world, gather_arrays(arrays, root)``.
     """
+    rank, world = comm.rank, comm.world
     lo, hi = shard_bounds(batch.B, rank, world)
-    local = solver.solve(batch.slice(lo, hi))
+    shard = batch.slice(lo, hi)
     if world == 1:
-        return local
-    import torch
-    import torch.distributed as dist
-
-    nv = batch.nv
+        return solver.solve(shard)
+    nv, n = batch.nv, hi - lo
     sizes = [shard_bounds(batch.B, r, world) for r in range(world)]
-    nmax = max(h - l for l, h in sizes)
-    # pad to the largest shard so every rank contributes equally sized buffers
-    buf = torch.zeros((nmax, nv + 2), dtype=torch.float64, device=device)
-    n = hi - lo
-    buf[:n, :nv] = torch.from_numpy(local.dq)
-    buf[:n, nv] = torch.from_numpy(local.status.astype(np.float64))
-    buf[:n, nv + 1] = torch.from_numpy(local.iters.astype(np.float64))
-    if gather_to is None:
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-    else:
-        parts = [torch.empty_like(buf) for _ in range(world)] if rank == gather_to else None
-        dist.gather(buf, parts, dst=gather_to, group=group)
-        if rank != gather_to:
-            return None
-    full = np.concatenate([p[: h - l].cpu().numpy() for p, (l, h) in zip(parts, sizes)], axis=0)
-    return BatchResult(np.ascontiguousarray(full[:, :nv]), full[:, nv].astype(np.int32), full[:, nv + 1].astype(np.int32))
+    nmax = max(h - l for l, h in sizes)  # every rank contributes equally sized (padded) buffers
+    receiver = gather_to is None or rank == gather_to
+    if isinstance(comm, RcclComm):
+        # device path: kernel outputs -> padded device buffers -> ncclGather -> one D2H on the root
+        dev = solver.upload(shard)
+        solver.solve_device(dev)
+        out = None
+        try:
+            recv = []
+            for ptr, item in ((dev.d_dq, 8 * nv), (dev.d_status, 4), (dev.d_iters, 4)):
+                nbytes = nmax * item
+                send = ptr
+                pad = None
+                if n < nmax:  # shorter shard: stage into a buffer of the common size
+                    pad = solver.alloc(nbytes)
+                    solver.put(pad, np.zeros(nbytes, dtype=np.uint8))
+                    solver.copy_d2d(pad, ptr, n * item)
+                    send = pad
+                recv.append((comm.gather_device(send, nbytes, gather_to), nbytes, pad))
+            solver.sync()
+            if receiver:
+                parts = [[None] * 3 for _ in range(world)]
+                for k, ((d_recv, nbytes, _), dt) in enumerate(zip(recv, (np.float64, np.int32, np.int32))):
+                    host = np.zeros(world * nbytes, dtype=np.uint8)
+                    solver.get(host, d_recv)
+                    for r in range(world):
+                        parts[r][k] = host[r * nbytes:(r + 1) * nbytes].view(dt)
+                out = _assemble(parts, sizes, nv)
+        finally:
+            for d_recv, _, pad in recv:
+                solver.release(d_recv)
+                solver.release(pad)
+            dev.free()
+        return out
+    local = solver.solve(shard)
+    dq = np.zeros((nmax, nv))
+    st = np.zeros(nmax, dtype=np.int32)
+    it = np.zeros(nmax, dtype=np.int32)
+    dq[:n], st[:n], it[:n] = local.dq, local.status, local.iters
+    parts = comm.gather_arrays([dq, st, it], gather_to)
+    return _assemble(parts, sizes, nv) if receiver else None

@@ -168,6 +168,8 @@ inline int key_payload(double k) {
 }
 inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+inline double fast_rcp1(double x) { return 1.0 / x; }
+inline double fast_rsqrt1(double x) { return 1.0 / std::sqrt(x); }
 
 inline bool wave_any(bool p) {
   Emu &e = emu();
@@ -244,6 +246,25 @@ inline double group_sum(double v) {
 template <int W>
 inline double group_min(double v) {
   return emu_group_reduce<W>(v, [](double a, double b) { return std::fmin(a, b); }, 22);
+}
+// 32-bit arg-min key (wave.h): float with the payload in its low 8 mantissa bits
+inline float key32_pack(double v, int payload) {
+  const float f = static_cast<float>(v);
+  int b;
+  std::memcpy(&b, &f, 4);
+  b = (b & ~0xFF) | (payload & 0xFF);
+  float r;
+  std::memcpy(&r, &b, 4);
+  return r;
+}
+inline int key32_payload(float k) {
+  int b;
+  std::memcpy(&b, &k, 4);
+  return b & 0xFF;
+}
+template <int W>
+inline float group_min32(float v) {
+  return static_cast<float>(emu_group_reduce<W>(static_cast<double>(v), [](double a, double b) { return std::fmin(a, b); }, 23));
 }
 // same association order as wave.h: shifts by 1, 2, 4, 8 inside the rows of 16, then the row totals
 template <int W>

@@ -74,6 +74,72 @@ class FakeModel:
         return np.ones(self.nq, dtype=bool)
 
 
+def time_reference_build_ik(terms, repeats=10, sample=16):
+    """Wall time of the reference's own ``pink.build_ik`` (``pink/solve_ik.py:152-203``: the stacking half of
+    ``solve_ik``; its QP solve needs quadprog) called once per instance on a synthetic batch of
+    ``pink_amd.synthetic`` terms -- bench.py's CPU baseline B0'.  Needs /root/reference."""
+    import statistics
+    import time
+
+    install_stubs()
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    import pink
+    from pink.limits import ConfigurationLimit, VelocityLimit
+    from pink.tasks import Task
+    from pink.utils import VectorSpace
+
+    class SyntheticTask(Task):
+        def __init__(self, J, e, **kw):
+            super().__init__(**kw)
+            self.J, self.e = J, e
+
+        def compute_error(self, configuration):
+            return self.e
+
+        def compute_jacobian(self, configuration):
+            return self.J
+
+        def __repr__(self):
+            return "SyntheticTask()"
+
+    nv, n = terms.nv, min(sample, terms.B)
+    q_min = np.full(nv, -np.inf)
+    q_max = np.full(nv, np.inf)
+    v_max = np.full(nv, np.inf)
+    problems = []
+    for b in range(n):
+        q = np.zeros(nv)
+        q_min[terms.limit_idx] = 2.0 * terms.cfg_lo[b]  # gamma = 0.5: gamma (q_min - q) = cfg_lo
+        q_max[terms.limit_idx] = 2.0 * terms.cfg_hi[b]
+        v_max[terms.limit_idx] = terms.vel[b] / terms.dt
+        model = FakeModel(nv, q_min.copy(), q_max.copy(), v_max.copy())
+        cfg = type("Cfg", (), {})()
+        cfg.model, cfg.q, cfg.tangent = model, q, VectorSpace(nv)
+        tasks = [SyntheticTask(t.J[b], t.e[b], cost=np.asarray(t.cost, float), gain=t.gain, lm_damping=t.lm_damping)
+                 for t in terms.dense_tasks]
+        for t in terms.diag_tasks:
+            k = t.e.shape[1]
+            tasks.append(SyntheticTask(np.eye(nv)[t.col0:t.col0 + k], t.e[b], cost=float(t.cost), gain=t.gain,
+                                       lm_damping=t.lm_damping))
+        problems.append((cfg, tasks, [ConfigurationLimit(model), VelocityLimit(model)]))
+
+    def run():
+        for cfg, tasks, limits in problems:
+            pink.build_ik(cfg, tasks, terms.dt, damping=terms.damping, limits=limits)
+
+    run()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    return {"available": True, "calls_per_s": n / med, "us_per_call_median": med / n * 1e6, "us_per_call_best": min(ts) / n * 1e6,
+            "repeats": repeats, "sample": n, "threads": 1, "pink_version": pink.__version__,
+            "what": "pink.build_ik only (objective + inequality stacking in NumPy); Pinocchio and the quadprog solve excluded"}
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REFERENCE)

@@ -295,3 +295,67 @@ def fuzz(solver, seeds):
             assert (err <= np.maximum(TOL_DQ, 100 * np.finfo(float).eps * cond * xmax)).all(), (sd, err.max())
             n_checked += int(ok.sum())
     return n_checked
+
+
+def kkt_certificate(solver, seeds):
+    """Independent of any Goldfarb-Idnani restatement: the solution the kernel returns must satisfy the KKT
+    conditions of the QP the *reference* would build (stationarity with non-negative multipliers on the
+    active rows = dual feasibility + complementarity, primal feasibility, equalities) -- a strictly convex
+    QP has one minimiser, so the certificate proves dq is it.  Random boxes, dense rows, barriers with safe
+    displacements, equalities, LM damping."""
+    from pink_amd.batch import BarrierTerm
+
+    n_checked = 0
+    for sd in seeds:
+        rng = np.random.default_rng(sd)
+        nv = int(rng.integers(2, 34))
+        B = int(rng.integers(1, 5))
+        k = int(rng.integers(1, 7))
+        neq = int(rng.integers(0, min(3, nv - 1) + 1)) if rng.random() < 0.5 else 0
+        mdi = int(rng.integers(0, 4))
+        nbar = int(rng.integers(0, 3))
+        dt = 0.005
+        J = rng.normal(0, 0.5, size=(B, k, nv))
+        e = 0.1 * rng.normal(size=(B, k))
+        ep = rng.uniform(-0.5, 0.5, size=(B, nv))
+        cost = rng.uniform(0.5, 2, size=k)
+        lm = float(rng.choice([0.0, 0.3]))
+        gain = float(rng.uniform(0.4, 1.0))
+        lb = -rng.uniform(0.002, 0.05, size=(B, nv))
+        ub = rng.uniform(0.002, 0.05, size=(B, nv))
+        m = rng.random(size=(B, nv))
+        lb[m < 0.15] = -np.inf
+        ub[(m > 0.15) & (m < 0.3)] = np.inf
+        A = rng.normal(size=(B, neq, nv))
+        bv = 0.005 * rng.normal(size=(B, neq))
+        Gi = rng.normal(size=(B, mdi, nv))
+        hi = rng.uniform(0.0, 0.05, size=(B, mdi))
+        bars = []
+        for _ in range(nbar):
+            Jh = rng.normal(0, 0.3, size=(B, 3, nv))
+            bars.append(BarrierTerm(J_h=Jh, h=rng.uniform(0.0, 0.05, size=(B, 3)), gain=100.0,
+                                    safe_displacement_gain=float(rng.choice([0.0, 1.0, 2.5])),
+                                    safe_displacement=0.01 * rng.normal(size=(B, nv)) if rng.random() < 0.6 else None))
+        batch = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=cost, gain=gain, lm_damping=lm), DiagonalTaskTerm(col0=0, e=ep, cost=0.1)],
+                           dt, 1e-12, boxes=[(lb, ub)], dense_rows=[(Gi, hi)] if mdi else (), barriers=bars,
+                           equality_rows=[(A, bv)] if neq else (), batch_size=B)
+        out = solver.solve(batch)
+        eye = np.eye(nv)
+        for b in range(B):
+            # the QP as pink.build_ik states it (oracle stacking is pinned by the reference fixtures)
+            tasks = [(J[b], e[b], cost, gain, lm), (eye, ep[b], 0.1, 1.0, 0.0)]
+            bt = [(t.J_h[b], t.h[b], 100.0, t.safe_displacement_gain,
+                   None if t.safe_displacement is None else t.safe_displacement[b]) for t in bars]
+            fin_u, fin_l = np.isfinite(ub[b]), np.isfinite(lb[b])
+            blocks = [(eye[fin_u], ub[b][fin_u]), (-eye[fin_l], -lb[b][fin_l])]
+            if mdi:
+                blocks.append((Gi[b], hi[b]))
+            P, q, G, h = po.build_qp(nv, tasks, 1e-12, blocks, bt, dt)
+            if out.status[b] != 0:
+                continue  # infeasible draws are covered by fuzz() against the oracle's verdict
+            x = out.dq[b]
+            stat, viol, lam = po.kkt_residuals(P, q, G, h, x, A=A[b] if neq else None, b=bv[b] if neq else None)
+            scale = max(1.0, np.abs(q).max())
+            assert stat <= 1e-9 * scale and viol <= 1e-10, (sd, b, stat, viol)
+            n_checked += 1
+    return n_checked

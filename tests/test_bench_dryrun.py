@@ -17,6 +17,7 @@ WORKER = textwrap.dedent(
     """
     import ctypes, os, sys, time
     sys.path.insert(0, %(root)r)
+    EXTRA = %(extra)r
     import numpy as np
     from pink_amd import batch_solver
     from pink_amd._lib import Desc, Problem, Result
@@ -28,29 +29,29 @@ WORKER = textwrap.dedent(
     lib.pinkhip_emu_last_error.restype = ctypes.c_char_p
 
     class FakeDev:
-        def __init__(self, batch, out_ptrs):
-            self.batch, self.out_ptrs = batch, out_ptrs
+        def __init__(self, batch):
+            from pink_amd._lib import PackedArgs
+            self.batch, self.args = batch, PackedArgs(batch)
             self.res = None
         def free(self):
             pass
 
-    class FakeSolver:  # same surface as BatchSolver for what bench.py uses
+    class FakeSolver:  # same surface as BatchSolver for what bench.py uses (no device, no RCCL binding)
         def __init__(self, device_id=0):
             self.emu = EmuSolver(lib)
             self.t0 = 0.0
         def device_info(self):
             return {"gcn_arch": "cpu-emulator"}
         def upload(self, batch, max_iter=0, out_ptrs=None):
-            return FakeDev(batch, out_ptrs)
+            return FakeDev(batch)
         def solve_device(self, dev):
-            dev.res = r = self.emu.solve(dev.batch)
-            if dev.out_ptrs is not None:
-                for ptr, arr in zip(dev.out_ptrs, (r.dq, r.status, r.iters)):
-                    ctypes.memmove(ptr, arr.ctypes.data, arr.nbytes)
+            dev.res = self.emu.solve(dev.batch)
         def stack_device(self, dev):
             self.emu.stack(dev.batch)
         def download(self, dev):
             return dev.res
+        def solve(self, batch, max_iter=0):
+            return self.emu.solve(batch)
         def sync(self):
             pass
         def timer_start(self):
@@ -63,36 +64,54 @@ WORKER = textwrap.dedent(
     batch_solver.BatchSolver = FakeSolver
     import __graft_entry__ as g
     g.build_hip = lambda force=False: None
-    sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "ur5", "--batch", "6",
-                "--cpu-sample", "6"]
+    sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "ur5", "--batch", "6"] + EXTRA
     import bench
     bench.main()
     """
 )
 
 
-def test_two_rank_bench_control_flow(built, tmp_path):
+def _run(tmp_path, extra):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+    script.write_text(WORKER % {"root": ROOT, "extra": extra})
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), PINKHIP_BENCH_DEVICE="cpu", PINKHIP_BENCH_BACKEND="gloo")
+                   MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True, cwd=ROOT))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = [p.communicate(timeout=900) for p in procs]
     for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e[-2000:]
+        assert p.returncode == 0, e[-3000:]
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_control_flow(built, tmp_path):
+    line = _run(tmp_path, [])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 12 and line["value"] > 0
-    assert isinstance(line["gather_ms"], float)
-    assert line["solver_stats"]["failed"] == 0
+    assert isinstance(line["gather"]["ms"], float) and line["gather"]["rank0_shard_intact"] is True
+    assert line["solver_stats"]["failed"] == 0 and len(line["per_rank_kernel_ms"]) == 2
     assert line["parity"]["max_abs_dq_err_vs_oracle"] < 1e-10
-    for key in ("roofline", "cpu_baseline", "stack_only", "metric", "unit", "dtype", "vs_baseline"):
-        assert key in line
+    for key in ("roofline", "roofline_fp64", "cpu_baseline", "stack_only", "configs", "end_to_end", "latency_B1_us",
+                "metric", "unit", "dtype", "vs_baseline"):
+        assert key in line, key
+    base = line["cpu_baseline"]
+    for leg in ("B0_numpy_per_call", "B1_c_single_thread", "B2_c_all_cores", "B0prime_reference_build_ik"):
+        assert leg in base, leg
+    assert base["B1_c_single_thread"]["repeats"] >= 10 and base["kind"] == "port" and base["cores"] >= 1
+    assert line["roofline"]["frac"] > 0 and line["roofline_fp64"]["peak"] == 78.6
+    for cfg in ("ur5_B4096", "jvrc_B65536"):
+        c = line["configs"][cfg]
+        assert c["failed"] == 0 and c["parity"]["max_abs_dq_err_vs_oracle"] < 1e-9 and c["stack_only"]["frac"] > 0
+
+
+def test_two_rank_strong_scaling_splits_the_global_batch(built, tmp_path):
+    line = _run(tmp_path, ["--scaling", "strong", "--global-batch", "10", "--headline-only", "--no-cpu-baseline"])
+    assert line["scaling"] == "strong" and line["config"]["global_batch"] == 10 and line["config"]["batch_per_gpu"] == 5
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather"]["bytes_per_rank"] == 8 * 5 * 6

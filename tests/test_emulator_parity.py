@@ -89,3 +89,7 @@ def test_equality_edge_cases(emu):
 
 def test_fuzz(emu):
     assert ps.fuzz(emu, range(5000, 5060)) > 100
+
+
+def test_kkt_certificate_independent_of_the_oracle_solver(emu):
+    assert ps.kkt_certificate(emu, range(9000, 9060)) > 80

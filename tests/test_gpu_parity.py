@@ -165,3 +165,7 @@ def test_api_errors(gpu_solver):
     batch.dt = 0.0
     with pytest.raises(PinkHipError):
         gpu_solver.solve(batch)
+
+
+def test_kkt_certificate_independent_of_the_oracle_solver(gpu_solver):
+    assert ps.kkt_certificate(gpu_solver, range(9000, 9400)) > 500
