@@ -258,6 +258,10 @@ int pinkhip_comm_allgather_bytes(pinkhip_handle *h, const void *d_send, void *d_
 int pinkhip_comm_destroy(pinkhip_handle *h);
 
 /* ---- device memory, stream, timing ------------------------------------- */
+/* page-locked host memory: buffers handed to the *_host entry points from here are copied by DMA at the PCIe
+ * rate and overlap with the kernels (pageable buffers work too, staged by the HIP runtime) */
+int pinkhip_host_alloc(pinkhip_handle *h, void **hptr, int64_t bytes);
+int pinkhip_host_free(pinkhip_handle *h, void *hptr);
 int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
 int pinkhip_free(pinkhip_handle *h, void *dptr);
 int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);

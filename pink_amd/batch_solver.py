@@ -109,9 +109,9 @@ class BatchSolver:
         self._check(self._lib.pinkhip_memcpy_d2h(self._h, arr.ctypes.data, ctypes.c_void_p(dptr), arr.nbytes))
 
     def close(self) -> None:
-        if self._h is not None:
+        if self._h is not None and self._h.value is not None:
             self._lib.pinkhip_destroy(self._h)
-            self._h = None
+            self._h.value = None  # finalizers of page-locked arrays see a closed handle (the driver frees them)
 
     def __enter__(self):
         return self
@@ -130,18 +130,28 @@ class BatchSolver:
         )
 
     # -- host-memory path ------------------------------------------------------
-    def solve(self, batch: IKBatch, max_iter: int = 0) -> BatchResult:
-        """Stack and solve every instance of ``batch`` (host buffers in, host out)."""
+    def solve(self, batch: IKBatch, max_iter: int = 0, out: Optional[BatchResult] = None) -> BatchResult:
+        """Stack and solve every instance of ``batch`` (host buffers in, host out).  ``out`` re-uses the result
+        arrays of an earlier call (e.g. page-locked ones from :meth:`pinned_result`)."""
         a = PackedArgs(batch, max_iter)
         B, nv = batch.B, batch.nv
-        dq = np.zeros((B, nv))
-        status = np.zeros(B, dtype=np.int32)
-        iters = np.zeros(B, dtype=np.int32)
+        if out is not None:
+            dq, status, iters = out.dq, out.status, out.iters
+            if dq.shape != (B, nv) or status.shape != (B,) or iters.shape != (B,):
+                raise ValueError("out has the wrong shape")
+        else:
+            dq = np.zeros((B, nv))
+            status = np.zeros(B, dtype=np.int32)
+            iters = np.zeros(B, dtype=np.int32)
         r = Result()
         r.dq, r.status, r.iters = dq.ctypes.data, status.ctypes.data, iters.ctypes.data
         p = a.host_problem()
         self._check(self._lib.pinkhip_solve_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r)))
         return BatchResult(dq, status, iters)
+
+    def pinned_result(self, B: int, nv: int) -> BatchResult:
+        """Result arrays in page-locked memory, for ``solve(..., out=)``."""
+        return BatchResult(self.pinned_empty((B, nv)), self.pinned_empty((B,), np.int32), self.pinned_empty((B,), np.int32))
 
     def stack(self, batch: IKBatch) -> Tuple[np.ndarray, np.ndarray]:
         """QP objective only: ``H [B, nv, nv]``, ``c [B, nv]`` (``build_ik``'s P, q)."""
@@ -170,6 +180,39 @@ class BatchSolver:
         self._check(self._lib.pinkhip_frame_task_host(self._h, B, nv, Tf.ctypes.data, Tt.ctypes.data, Jb.ctypes.data,
                                                       e.ctypes.data, J.ctypes.data))
         return e, J
+
+    # -- page-locked host buffers ------------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """Uninitialised NumPy array in page-locked host memory (``pinkhip_host_alloc``): ``solve`` copies such
+        arrays by DMA at the PCIe rate.  The memory is released when the array (and every view of it) is gone."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes == 0:
+            return np.empty(shape, dtype=dtype)
+        p = ctypes.c_void_p()
+        self._check(self._lib.pinkhip_host_alloc(self._h, ctypes.byref(p), nbytes))
+        buf = (ctypes.c_char * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        lib, h, addr = self._lib, self._h, p.value
+        import weakref
+
+        weakref.finalize(buf, lambda: h.value is not None and lib.pinkhip_host_free(h, ctypes.c_void_p(addr)))
+        return arr
+
+    def pin(self, batch: IKBatch) -> IKBatch:
+        """Copy of ``batch`` whose per-instance streams live in page-locked memory (for repeated ``solve`` calls
+        on buffers that are refilled in place: ``np.copyto(pinned.J, J)``)."""
+        import dataclasses
+
+        def mv(a):
+            if a is None:
+                return None
+            out = self.pinned_empty(a.shape, a.dtype)
+            np.copyto(out, a)
+            return out
+
+        return dataclasses.replace(batch, J=mv(batch.J), e=mv(batch.e), cost=mv(batch.cost), lb=mv(batch.lb), ub=mv(batch.ub),
+                                   Gd=mv(batch.Gd), hd=mv(batch.hd), c_extra=mv(batch.c_extra))
 
     # -- HBM-resident path -----------------------------------------------------
     def upload(self, batch: IKBatch, max_iter: int = 0, out_ptrs=None) -> DeviceBatch:

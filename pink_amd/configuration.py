@@ -280,6 +280,26 @@ class Configuration:
             j = jt.parent
         return J
 
+    def get_joint_jacobian_world_aligned(self, joint: int) -> np.ndarray:
+        """Jacobian of joint ``joint`` in the frame centred at the joint origin with the world's axes
+        (``pin.getJointJacobian(..., LOCAL_WORLD_ALIGNED)``): ``[R 0; 0 R]`` times the body Jacobian."""
+        m = self.model
+        J = np.zeros((6, m.nv))
+        oMj_inv = self.oMi[joint].inverse()
+        j = joint
+        while j >= 0:
+            jt = m.joints[j]
+            A = _adjoint(oMj_inv * self.oMi[j])
+            if jt.kind == "revolute":
+                J[:, jt.idx_v] = A[:, 3:] @ jt.axis
+            elif jt.kind == "prismatic":
+                J[:, jt.idx_v] = A[:, :3] @ jt.axis
+            else:
+                J[:, jt.idx_v:jt.idx_v + 6] = A
+            j = jt.parent
+        R = self.oMi[joint].rotation
+        return np.vstack([R @ J[:3], R @ J[3:]])
+
     def get_transform_frame_to_world(self, frame: str) -> SE3:
         return self.oMf[self.model.getFrameId(frame)].copy()
 

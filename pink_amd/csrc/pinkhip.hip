@@ -41,6 +41,8 @@ struct pinkhip_model {
 struct pinkhip_handle {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of the chunked *_host path (overlaps the kernels on `stream`)
+  std::vector<hipEvent_t> chunk_events;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   char *d_tables = nullptr;          // device copy of the broadcast tables
@@ -279,6 +281,7 @@ int pinkhip_create(pinkhip_handle **out, int device_id) {
     return fail(nullptr, PINKHIP_E_NODEVICE, "device is " + arch + ", kernels are built for gfx950 only");
   }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_tables), kTableBytes);
@@ -300,6 +303,8 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t ev : h->chunk_events) (void)hipEventDestroy(ev);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PINKHIP_OK;
@@ -351,6 +356,31 @@ int pinkhip_stack_device(pinkhip_handle *h, const pinkhip_desc *desc, const pink
   return launch(h, a, false);
 }
 
+// Device layout of one uploaded batch inside the arena (offsets of the eight input streams + outputs).
+namespace {
+struct ArenaPlan {
+  size_t n[8], off[8], stride[8];  // bytes, offset, bytes per instance (0: broadcast stream)
+  size_t out_off, total;
+};
+ArenaPlan plan_arena(const pinkhip_desc *d, const pinkhip_problem *in, size_t extra_out) {
+  const size_t B = static_cast<size_t>(d->B), nv = d->nv;
+  ArenaPlan p{};
+  const size_t per[8] = {8 * (size_t)d->Kd * nv, 8 * (size_t)d->K, d->cost_is_batched ? 8 * (size_t)d->K : 0, 8 * nv, 8 * nv,
+                         8 * (size_t)d->md * nv, 8 * (size_t)d->md, in->c_extra ? 8 * nv : 0};
+  size_t total = 0;
+  for (int i = 0; i < 8; ++i) {
+    p.stride[i] = per[i];
+    p.n[i] = per[i] * B;
+    if (i == 2 && !d->cost_is_batched) p.n[i] = 8 * (size_t)d->K;
+    p.off[i] = total;
+    total += align256(p.n[i]);
+  }
+  p.out_off = total;
+  p.total = total + align256(extra_out);
+  return p;
+}
+}  // namespace
+
 int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
                        const pinkhip_result *host_out) {
   KernelArgs a{};
@@ -362,18 +392,53 @@ int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
   if (desc->B == 0) return PINKHIP_OK;
   const size_t B = static_cast<size_t>(desc->B), nv = desc->nv;
   const size_t n_dq = align256(8 * B * nv), n_st = align256(4 * B);
-  pinkhip_problem dev{};
-  char *out = nullptr;
-  if ((rc = upload(h, desc, host_in, n_dq + 2 * n_st, dev, out))) return rc;
-  set_problem(a, &dev);
-  a.dq = reinterpret_cast<double *>(out);
-  a.status = reinterpret_cast<int *>(out + n_dq);
-  a.iters = reinterpret_cast<int *>(out + n_dq + n_st);
-  if ((rc = launch(h, a, true))) return rc;
-  PH_HIP(h, hipMemcpyAsync(host_out->dq, a.dq, 8 * B * nv, hipMemcpyDeviceToHost, h->stream));
-  PH_HIP(h, hipMemcpyAsync(host_out->status, a.status, 4 * B, hipMemcpyDeviceToHost, h->stream));
-  if (host_out->iters)
-    PH_HIP(h, hipMemcpyAsync(host_out->iters, a.iters, 4 * B, hipMemcpyDeviceToHost, h->stream));
+  const ArenaPlan p = plan_arena(desc, host_in, n_dq + 2 * n_st);
+  if ((rc = ensure_arena(h, p.total))) return rc;
+  const void *src[8] = {host_in->J, host_in->e, host_in->cost, host_in->lb, host_in->ub, host_in->Gd, host_in->hd, host_in->c_extra};
+  char *dev[8];
+  for (int i = 0; i < 8; ++i) dev[i] = (p.n[i] && src[i]) ? h->arena + p.off[i] : nullptr;
+  char *out = h->arena + p.out_off;
+  double *d_dq = reinterpret_cast<double *>(out);
+  int *d_st = reinterpret_cast<int *>(out + n_dq), *d_it = reinterpret_cast<int *>(out + n_dq + n_st);
+
+  // The batch is cut into chunks of ~32 MB: the H2D copy of chunk c + 1 (copy stream) runs while chunk c is
+  // solved and its results go home (compute stream).  From pinned host memory (pinkhip_host_alloc) the copies
+  // are true DMA and the call approaches the PCIe rate; pageable buffers are staged by the HIP runtime and
+  // still overlap with the kernels.
+  size_t per_inst = 0;
+  for (int i = 0; i < 8; ++i) per_inst += src[i] ? p.stride[i] : 0;
+  size_t chunk = per_inst ? (size_t(32) << 20) / per_inst : B;
+  chunk = chunk < 2048 ? 2048 : (chunk & ~size_t(63));
+  const size_t n_chunks = (B + chunk - 1) / chunk;
+  if (n_chunks > h->chunk_events.size()) {
+    const size_t old = h->chunk_events.size();
+    h->chunk_events.resize(n_chunks, nullptr);
+    for (size_t i = old; i < n_chunks; ++i) PH_HIP(h, hipEventCreateWithFlags(&h->chunk_events[i], hipEventDisableTiming));
+  }
+  // broadcast stream (cost [K]) once, ahead of the first chunk
+  if (!desc->cost_is_batched && dev[2]) PH_HIP(h, hipMemcpyAsync(dev[2], src[2], p.n[2], hipMemcpyHostToDevice, h->copy_stream));
+  // the copy stream must not overwrite the arena while an earlier call's kernels still read it
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  for (size_t c = 0; c < n_chunks; ++c) {
+    const size_t c0 = c * chunk, cb = (B - c0 < chunk) ? B - c0 : chunk;
+    for (int i = 0; i < 8; ++i)
+      if (dev[i] && p.stride[i])
+        PH_HIP(h, hipMemcpyAsync(dev[i] + c0 * p.stride[i], static_cast<const char *>(src[i]) + c0 * p.stride[i],
+                                 cb * p.stride[i], hipMemcpyHostToDevice, h->copy_stream));
+    PH_HIP(h, hipEventRecord(h->chunk_events[c], h->copy_stream));
+    PH_HIP(h, hipStreamWaitEvent(h->stream, h->chunk_events[c], 0));
+    KernelArgs ac = a;
+    ac.B = static_cast<long long>(cb);
+    auto at = [&](int i) { return dev[i] ? reinterpret_cast<const double *>(dev[i] + c0 * p.stride[i]) : nullptr; };
+    ac.J = at(0), ac.e = at(1), ac.cost = at(2), ac.lb = at(3), ac.ub = at(4), ac.Gd = at(5), ac.hd = at(6), ac.c_extra = at(7);
+    ac.dq = d_dq + c0 * nv;
+    ac.status = d_st + c0;
+    ac.iters = d_it + c0;
+    if ((rc = launch(h, ac, true))) return rc;
+    PH_HIP(h, hipMemcpyAsync(host_out->dq + c0 * nv, ac.dq, 8 * cb * nv, hipMemcpyDeviceToHost, h->stream));
+    PH_HIP(h, hipMemcpyAsync(host_out->status + c0, ac.status, 4 * cb, hipMemcpyDeviceToHost, h->stream));
+    if (host_out->iters) PH_HIP(h, hipMemcpyAsync(host_out->iters + c0, ac.iters, 4 * cb, hipMemcpyDeviceToHost, h->stream));
+  }
   PH_HIP(h, hipStreamSynchronize(h->stream));
   return PINKHIP_OK;
 }
@@ -710,6 +775,24 @@ int pinkhip_comm_destroy(pinkhip_handle *h) {
     rccl().CommDestroy(h->comm);
     h->comm = nullptr;
   }
+  return PINKHIP_OK;
+}
+
+int pinkhip_host_alloc(pinkhip_handle *h, void **hptr, int64_t bytes) {
+  if (!h || !hptr || bytes < 0) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  *hptr = nullptr;
+  PH_HIP(h, hipSetDevice(h->device));
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipHostMalloc(hptr, static_cast<size_t>(bytes), hipHostMallocDefault));
+  return PINKHIP_OK;
+}
+
+int pinkhip_host_free(pinkhip_handle *h, void *hptr) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (!hptr) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  PH_HIP(h, hipHostFree(hptr));
   return PINKHIP_OK;
 }
 

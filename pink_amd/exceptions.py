@@ -67,5 +67,9 @@ class TaskJacobianNotSet(PinkError):
     """A task Jacobian is read before being set."""
 
 
+class InvalidCollisionPairs(PinkError):
+    """Ill-formed set of collision pairs (``pink/exceptions.py``)."""
+
+
 class NegativeMinimumDistance(PinkError):
     """A barrier is given a negative minimum distance (``pink/exceptions.py``)."""

@@ -73,6 +73,10 @@ class SE3:
     def actInv(self, other: "SE3") -> "SE3":
         return self.inverse() * other
 
+    def act(self, point) -> np.ndarray:
+        """Image of a point given in this frame (``pin.SE3.act`` on a 3-vector)."""
+        return self.rotation @ np.asarray(point, dtype=float) + self.translation
+
     @property
     def action(self) -> np.ndarray:
         """6 x 6 adjoint acting on twists ``[linear; angular]`` (``pin.SE3.action``)."""

@@ -138,3 +138,56 @@ def test_body_spherical_barrier(backend):
     p1 = cfg.get_transform_frame_to_world("tool0").translation
     p2 = cfg.get_transform_frame_to_world("joint_2").translation
     assert np.linalg.norm(p1 - p2) >= 0.9 * dist - 1e-3
+
+
+def test_self_collision_barrier_rows_and_solve(backend):
+    """pink/barriers/self_collision_barrier.py:95-224 with sphere pairs as the distance query: barrier values
+    are the `dim` smallest distances minus d_min, the Jacobian rows match finite differences of those
+    distances, and solve_ik keeps the spheres from approaching faster than the barrier allows."""
+    from pink_amd.barriers import SelfCollisionBarrier, SpherePairs
+    from pink_amd.exceptions import InvalidCollisionPairs, NegativeMinimumDistance
+
+    m = build_chain(7, free_flyer=True, seed=5)
+    rng = np.random.default_rng(12)
+    q = m.neutral()
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[j.idx_q] = rng.uniform(-0.9, 0.9)
+    cfg = Configuration(m, q)
+    nj = len(m.joints)
+    pairs = SpherePairs([(1, [0.02, 0, 0.01], 0.03, nj - 1, [0, 0.01, 0.02], 0.04),
+                         (2, [0, 0, 0], 0.02, nj - 2, [0.01, 0, 0], 0.03),
+                         (0, [0.1, 0, 0], 0.05, nj - 1, [0, 0, 0.05], 0.02)])
+    bar = SelfCollisionBarrier(2, gain=50.0, safe_displacement_gain=1.0, d_min=0.01, distance_query=pairs)
+    dists = np.array([p.min_distance for p in pairs(cfg)])
+    h = bar.compute_barrier(cfg)
+    assert np.allclose(np.sort(h), np.sort(dists)[:2] - 0.01)
+    J = bar.compute_jacobian(cfg)
+    assert J.shape == (2, m.nv)
+    # finite differences of the distances along tangent directions (tests/test_jacobians.py:47-75 pattern)
+    order = np.argpartition(-dists, -2)[-2:]
+    eps = 1e-6
+    for i in range(m.nv):
+        dv = np.zeros(m.nv)
+        dv[i] = eps
+        d_plus = np.array([p.min_distance for p in pairs(Configuration(m, m.integrate(q, dv)))])
+        d_minus = np.array([p.min_distance for p in pairs(Configuration(m, m.integrate(q, -dv)))])
+        assert np.abs((d_plus - d_minus)[order] / (2 * eps) - J[:, i]).max() < 1e-6
+    G, hh = bar.compute_qp_inequalities(cfg, 5e-3)
+    assert G.shape == (2, m.nv) and np.allclose(G, -J / 5e-3) and np.allclose(hh, 50.0 * h)
+    # in the QP: a posture task that would fold the chain is slowed down by the barrier rows
+    post = PostureTask(cost=1.0)
+    post.set_target(m.neutral())
+    v_free = solve_ik(cfg, [post], 5e-3)
+    tight = SelfCollisionBarrier(3, gain=1.0, safe_displacement_gain=0.0, d_min=float(dists.min()) - 1e-4, distance_query=pairs)
+    v_bar = solve_ik(cfg, [post], 5e-3, barriers=[tight])
+    Gt, ht = tight.compute_qp_inequalities(cfg, 5e-3)
+    assert (Gt @ (v_bar * 5e-3) <= ht + 1e-12).all()
+    if (Gt @ (v_free * 5e-3) > ht + 1e-9).any():
+        assert np.abs(v_bar - v_free).max() > 1e-6
+    with pytest.raises(NegativeMinimumDistance):
+        SelfCollisionBarrier(1, d_min=-1.0)
+    with pytest.raises(InvalidCollisionPairs):
+        SelfCollisionBarrier(5, distance_query=pairs).compute_barrier(cfg)
+    with pytest.raises(InvalidCollisionPairs):
+        SelfCollisionBarrier(1).compute_barrier(cfg)
