@@ -220,6 +220,30 @@ int pinkhip_fk_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, 
 int pinkhip_fk_frame_tasks_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const double *q,
                                   const double *T_target, double *T_frames, double *e, int64_t sE, double *J,
                                   int64_t sJ);
+/* Whole control step around the solve in ONE launch: q <- q (+) dq_prev for the instances whose previous solve
+ * succeeded (as pinkhip_integrate_checked_device), forward kinematics, the FrameTask rows of every model frame
+ * (as pinkhip_fk_frame_tasks_device), the merged box limits and the PostureTask error (as
+ * pinkhip_limits_posture_device).  A closed loop is then  step -> solve -> step -> solve ...  with a final
+ * pinkhip_integrate_checked_device.  All pointers are device pointers. */
+typedef struct pinkhip_step {
+  double *q;                  /* [B,nq] in / out */
+  const double *dq_prev;      /* [B,nv] displacement of the previous solve, NULL on the first step */
+  const int32_t *status;      /* [B] status of that solve (required with dq_prev) */
+  int32_t *first_failure;     /* [B] sticky `status | (step << 8)`, may be NULL */
+  int32_t step;               /* index recorded in first_failure */
+  int32_t target_batched;     /* q_target is [B,nq] (1) or [nq] (0) */
+  const double *T_target;     /* [B,nf,12] FrameTask targets */
+  double *T_frames;           /* [B,nf,12] frame poses out, may be NULL */
+  double *e;                  /* task errors: frame f at e[b*sE + 6f ..], posture rows at e[b*sE + e_off ..] */
+  int64_t sE;
+  double *J;                  /* frame-task Jacobians: rows 6f..6f+5 at J[b*sJ + ...], pitch nv */
+  int64_t sJ;
+  double dt, config_limit_gain;
+  const double *q_target;     /* posture target, NULL: no posture rows */
+  double *lb, *ub;            /* [B,nv] */
+  int32_t e_off;
+} pinkhip_step;
+int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const pinkhip_step *args);
 /* q [B,nq], q_target [nq] or [B,nq] -> lb, ub [B,nv]; posture error written into e [B,K] at columns
  * e_off .. e_off + nv - root_nv (e may be NULL) */
 int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double dt,

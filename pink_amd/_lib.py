@@ -83,13 +83,26 @@ class DeviceInfo(ctypes.Structure):
     ]
 
 
+class Step(ctypes.Structure):
+    """``pinkhip_step``."""
+
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("dq_prev", ctypes.c_void_p), ("status", ctypes.c_void_p), ("first_failure", ctypes.c_void_p),
+        ("step", ctypes.c_int32), ("target_batched", ctypes.c_int32),
+        ("T_target", ctypes.c_void_p), ("T_frames", ctypes.c_void_p),
+        ("e", ctypes.c_void_p), ("sE", ctypes.c_int64), ("J", ctypes.c_void_p), ("sJ", ctypes.c_int64),
+        ("dt", ctypes.c_double), ("config_limit_gain", ctypes.c_double),
+        ("q_target", ctypes.c_void_p), ("lb", ctypes.c_void_p), ("ub", ctypes.c_void_p), ("e_off", ctypes.c_int32),
+    ]
+
+
 # every symbol include/pinkhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
     "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
-    "pinkhip_fk_frame_tasks_device",
+    "pinkhip_fk_frame_tasks_device", "pinkhip_step_device",
     "pinkhip_limits_posture_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
@@ -132,6 +145,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_model_destroy.argtypes = [vp, vp]
     lib.pinkhip_fk_device.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.pinkhip_fk_frame_tasks_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64]
+    lib.pinkhip_step_device.argtypes = [vp, vp, i64, ctypes.POINTER(Step)]
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
     lib.pinkhip_integrate_checked_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32]

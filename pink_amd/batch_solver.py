@@ -285,6 +285,10 @@ class BatchSolver:
         self._check(self._lib.pinkhip_fk_frame_tasks_device(self._h, ctypes.c_void_p(model), B, q, T_target, T_frames,
                                                             e, sE, J, sJ))
 
+    def step_kernel(self, model: int, B: int, args) -> None:
+        """Whole control step around the solve in one launch (``pinkhip_step_device``)."""
+        self._check(self._lib.pinkhip_step_device(self._h, ctypes.c_void_p(model), B, ctypes.byref(args)))
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ) -> None:
         self._check(self._lib.pinkhip_frame_task_strided_device(self._h, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ))
 

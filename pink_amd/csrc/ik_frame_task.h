@@ -86,7 +86,8 @@ __device__ inline void alpha_beta(double th, double &alpha, double &beta) {
     alpha = 1.0 - th * th / 12.0;
     beta = 1.0 / 12.0 + th * th / 720.0;
   } else {
-    const double s = sin(th), c = cos(th);
+    double s, c;
+    fast_sincos(th, s, c);
     alpha = th * s / (2.0 * (1.0 - c));
     beta = 1.0 / (th * th) - s / (2.0 * th * (1.0 - c));
   }
@@ -118,7 +119,8 @@ __device__ inline void jlog6(const double *R, const double *p, double *Jl) {
     beta = a;
     beta_dot = 1.0 / 360.0;
   } else {
-    const double s = sin(th), c = cos(th);
+    double s, c;
+    fast_sincos(th, s, c);
     a = 1.0 / (th * th) - s / (2.0 * th * (1.0 - c));
     d = 0.5 * th * s / (1.0 - c);
     beta = a;

@@ -53,7 +53,9 @@ __device__ inline void se3_mul(const double *A, const double *Bm, double *C) {
 
 // rotation about unit axis u by angle t (Rodrigues), row-major
 __device__ inline void rot_axis(const double *u, double t, double *R) {
-  const double s = sin(t), c = cos(t), v = 1.0 - c;
+  double s, c;
+  fast_sincos(t, s, c);
+  const double v = 1.0 - c;
   R[0] = c + v * u[0] * u[0];
   R[1] = v * u[0] * u[1] - s * u[2];
   R[2] = v * u[0] * u[2] + s * u[1];
@@ -79,23 +81,92 @@ __device__ inline void quat_to_rot(const double *qv, double *R) {  // (x, y, z, 
   R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// local transform of joint a at configuration q
-__device__ inline void joint_transform(const ModelDev &m, int a, const double *q, double *T) {
-  const int t = m.jtype[a], iq = m.idx_q[a];
-  if (t == JOINT_REVOLUTE) {
-    rot_axis(m.axis + 3 * a, q[iq], T);
-    T[9] = T[10] = T[11] = 0.0;
-  } else if (t == JOINT_PRISMATIC) {
+// local transform of joint a at configuration q.  Written without per-type branches around the output array:
+// a prismatic joint is a rotation by zero plus a translation along the axis; merging three differently
+// filled arrays at a join point had the compiler keep part of T in private memory (24 B of scratch).
+__device__ inline void joint_transform(const ModelDev &m, int a, const double *qj, double *T) {
+  const int t = m.jtype[a];  // qj = the joint's own entries of q (1, or 7 for the free-flyer)
+  const double *ax = m.axis + 3 * a;
+  const double qa = qj[0];
+  rot_axis(ax, t == JOINT_REVOLUTE ? qa : 0.0, T);
+  const double lin = t == JOINT_PRISMATIC ? qa : 0.0;
+  T[9] = ax[0] * lin;
+  T[10] = ax[1] * lin;
+  T[11] = ax[2] * lin;
+  if (t == JOINT_FREE_FLYER) {
+    double R[9];
+    quat_to_rot(qj + 3, R);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) T[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    T[9] = m.axis[3 * a] * q[iq];
-    T[10] = m.axis[3 * a + 1] * q[iq];
-    T[11] = m.axis[3 * a + 2] * q[iq];
+    for (int i = 0; i < 9; ++i) T[i] = R[i];
+    T[9] = qa;
+    T[10] = qj[1];
+    T[11] = qj[2];
+  }
+}
+
+// q_j <- q_j (+) v_j for one joint, in place (pink/configuration.py:273-293: pin.integrate)
+__device__ inline void integrate_joint(const ModelDev &m, int j, double *q, const double *v) {
+  if (m.jtype[j] != JOINT_FREE_FLYER) {
+    q[0] += v[0];
+    return;
+  }
+  // M <- M exp6(v): p += R V(w) v_lin, quat <- quat * exp(w / 2)
+  double R[9];
+  quat_to_rot(q + 3, R);
+  const double wx = v[3], wy = v[4], wz = v[5];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  double A, Bc;  // V = I + A [w]x + Bc [w]x^2
+  if (th < 1e-8) {
+    A = 0.5;
+    Bc = 1.0 / 6.0;
   } else {
-    quat_to_rot(q + iq + 3, T);
-    T[9] = q[iq];
-    T[10] = q[iq + 1];
-    T[11] = q[iq + 2];
+    double s_t, c_t;
+    fast_sincos(th, s_t, c_t);
+    A = (1.0 - c_t) / th2;
+    Bc = (th - s_t) / (th2 * th);
+  }
+  const double cx = wy * v[2] - wz * v[1], cy = wz * v[0] - wx * v[2], cz = wx * v[1] - wy * v[0];  // w x v
+  const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;          // w x (w x v)
+  const double tx = v[0] + A * cx + Bc * ccx, ty = v[1] + A * cy + Bc * ccy, tz = v[2] + A * cz + Bc * ccz;
+  q[0] += R[0] * tx + R[1] * ty + R[2] * tz;
+  q[1] += R[3] * tx + R[4] * ty + R[5] * tz;
+  q[2] += R[6] * tx + R[7] * ty + R[8] * tz;
+  double s_h, c_h;  // unit quaternion of exp(w): (sin(th/2)/th w, cos(th/2))
+  if (th < 1e-8) {
+    s_h = 0.5;
+    c_h = 1.0;
+  } else {
+    fast_sincos(0.5 * th, s_h, c_h);
+    s_h /= th;
+  }
+  const double dx = s_h * wx, dy = s_h * wy, dz = s_h * wz, dw = c_h;
+  const double x = q[3], y = q[4], z = q[5], w = q[6];
+  double nx = w * dx + x * dw + y * dz - z * dy;
+  double ny = w * dy - x * dz + y * dw + z * dx;
+  double nz = w * dz + x * dy - y * dx + z * dw;
+  double nw = w * dw - x * dx - y * dy - z * dz;
+  const double n = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  q[3] = nx * n;
+  q[4] = ny * n;
+  q[5] = nz * n;
+  q[6] = nw * n;
+}
+
+// merged box of ConfigurationLimit + VelocityLimit for tangent coordinate j whose joint has the scalar
+// configuration qi (configuration_limit.py:50-56, 111-120; velocity_limit.py:61-64, 118-120)
+__device__ inline void coordinate_box(const ModelDev &m, int j, int jt, double qi, double dt, double gain, double &lo, double &hi) {
+  lo = -INFINITY;
+  hi = INFINITY;
+  if (m.jtype[jt] == JOINT_FREE_FLYER) return;
+  const int iq = m.idx_q[jt];
+  const double qmin = m.q_min[iq], qmax = m.q_max[iq], vmax = m.v_max[j];
+  if (qmax < 1e20 && qmax > qmin + 1e-10) {
+    lo = gain * (qmin - qi);
+    hi = gain * (qmax - qi);
+  }
+  if (vmax < 1e20 && vmax > 1e-10) {
+    lo = fmax(lo, -dt * vmax);
+    hi = fmin(hi, dt * vmax);
   }
 }
 
@@ -112,10 +183,24 @@ struct FkArgs {
   double *e_out = nullptr;
   double *J_out = nullptr;
   long long sE = 0, sJo = 0;
+  // whole-step kernel (STEP = true): q is first advanced by the previous solve (q <- q (+) dq_prev for the
+  // instances whose status is 0, written back in place), and the merged box limits + the posture error are
+  // produced next to the frame-task rows -- one launch per control step besides the solve
+  double *q_rw = nullptr;           // [B, nq] the same buffer as q, writable
+  const double *dq_prev = nullptr;  // [B, nv] or NULL (first step)
+  const int *status = nullptr;      // [B] status of the solve that produced dq_prev
+  int *first_failure = nullptr;     // [B] sticky status | (step << 8), may be NULL
+  int step = 0;
+  double dt = 0.0, config_limit_gain = 0.5;
+  const double *q_target = nullptr;  // [B, nq] / [nq] posture target, NULL: no posture rows
+  int target_batched = 0;
+  double *lb = nullptr, *ub = nullptr;  // [B, nv]
+  int e_off = 0;                        // posture rows go to e_out[b * sE + e_off ...]
 };
 
-// LDS per instance: oM [nj, 12] + inverse frame poses [nf, 12] + ancestor pointers [nj] + Jlog6 [nf, 36]
-__device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj + nf) + ((nj + 1) & ~1) + 36 * nf; }
+// LDS per instance: oM [nj, 12] + inverse frame poses [nf, 12] + ancestor pointers [nj] + Jlog6 [nf, 36] + the
+// scalar configuration of every joint [nj] (whole-step kernel)
+__device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj + nf) + ((nj + 1) & ~1) + 36 * nf + ((nj + 1) & ~1); }
 
 // Forward kinematics and body (LOCAL) frame Jacobians of one instance by a group of W lanes (W >= nj).
 //   1. lane = joint: local transform (sin / cos), pose in the parent frame;
@@ -126,7 +211,7 @@ __device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj 
 //      by -Jlog6 and written straight into the rows of the packed task Jacobian.
 // FUSED = true moves 8 (nq + 12 nf + nf (6 + 6 nv)) bytes per instance instead of 8 (nq + 12 nf + 6 nf nv)
 // written by the FK launch and 8 nf (24 + 12 nv + 6) re-read and written by nf frame-task launches.
-template <int W, bool FUSED = false>
+template <int W, bool FUSED = false, bool STEP = false>
 __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.m;
@@ -139,15 +224,42 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   double *fMo = oM + 12 * m.nj;  // frame-from-world transforms
   int *anc = reinterpret_cast<int *>(fMo + 12 * m.nf);
   double *Jls = fMo + 12 * m.nf + ((m.nj + 1) & ~1);
+  double *qs = Jls + 36 * m.nf;  // scalar configuration of every joint (STEP)
   const double *q = a.q + b * (long long)m.nq;
 
   // 1. pose of joint li in its parent's frame
   const bool isj = li < m.nj;
   const int jl = isj ? li : 0;
   double T[12];
-  {
+  if constexpr (STEP) {
+    // 0. the joint's configuration in registers, advanced by the previous solve unless that solve failed (the
+    //    reference raises NoSolutionFound before integrating, pink/solve_ik.py:271-275)
+    const int iq = m.idx_q[jl];
+    const bool ff = m.jtype[jl] == JOINT_FREE_FLYER;
+    double qj[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) qj[i] = (i == 0 || ff) ? q[iq + i] : 0.0;
+    if (a.dq_prev) {
+      const int st = a.status[b];
+      if (st == 0) {
+        integrate_joint(m, jl, qj, a.dq_prev + b * (long long)m.nv + m.idx_v[jl]);
+        if (valid && isj) {
+          double *qw = a.q_rw + b * (long long)m.nq + iq;
+#pragma unroll
+          for (int i = 0; i < 7; ++i)
+            if (i == 0 || ff) qw[i] = qj[i];
+        }
+      } else if (valid && li == 0 && a.first_failure && a.first_failure[b] == 0) {
+        a.first_failure[b] = st | (a.step << 8);
+      }
+    }
+    if (isj) qs[li] = qj[0];
     double Tj[12];
-    joint_transform(m, jl, q, Tj);
+    joint_transform(m, jl, qj, Tj);
+    se3_mul(m.placement + 12 * jl, Tj, T);
+  } else {
+    double Tj[12];
+    joint_transform(m, jl, q + m.idx_q[jl], Tj);
     se3_mul(m.placement + 12 * jl, Tj, T);
   }
   int up = isj ? m.parent[jl] : -1;
@@ -228,10 +340,10 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
         se3_mul(fMo + 12 * f, oM + 12 * jt, X);  // joint frame -> frame
         double u[3];
         if (ty == JOINT_FREE_FLYER) {
-          const int k = sub % 3;
-          u[0] = X[k];
-          u[1] = X[3 + k];
-          u[2] = X[6 + k];  // R[:, k]
+          const int k = sub % 3;  // R[:, k], selected without indexing the register array dynamically (scratch)
+          u[0] = k == 0 ? X[0] : (k == 1 ? X[1] : X[2]);
+          u[1] = k == 0 ? X[3] : (k == 1 ? X[4] : X[5]);
+          u[2] = k == 0 ? X[6] : (k == 1 ? X[7] : X[8]);
         } else {
           const double *ax = m.axis + 3 * jt;
 #pragma unroll
@@ -268,6 +380,21 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
         }
       }
     }
+    if constexpr (STEP) {
+      // 5. merged box limits and the posture error of tangent coordinate j (qs was published before step 2's barriers)
+      const double qi = qs[jt];
+      double lo, hi;
+      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
+      if (valid) {
+        a.lb[b * m.nv + j] = lo;
+        a.ub[b * m.nv + j] = hi;
+        if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q*
+          const int iq = m.idx_q[jt];
+          const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
+          a.e_out[b * a.sE + a.e_off + (j - m.root_nv)] = qi - qt;
+        }
+      }
+    }
   }
 }
 
@@ -276,8 +403,14 @@ __global__ void __launch_bounds__(kWave) ik_fk_kernel(FkArgs a) {
   ik_fk_instance<W, false>(a, block_id());
 }
 template <int W>
-__global__ void __launch_bounds__(kWave) ik_fk_frame_tasks_kernel(FkArgs a) {
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_FK
+ik_fk_frame_tasks_kernel(FkArgs a) {
   ik_fk_instance<W, true>(a, block_id());
+}
+template <int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_FK
+ik_step_kernel(FkArgs a) {
+  ik_fk_instance<W, true, true>(a, block_id());
 }
 
 struct LimitsPostureArgs {
@@ -299,23 +432,13 @@ __device__ inline void ik_limits_posture_thread(const LimitsPostureArgs &a, long
   const long long b = t / m.nv;
   const int j = (int)(t - b * m.nv);
   const int jt = m.dof_joint[j];
-  double lo = -INFINITY, hi = INFINITY;
-  if (m.jtype[jt] != JOINT_FREE_FLYER) {
+  const double qi = a.q[b * m.nq + m.idx_q[jt]];
+  double lo, hi;
+  coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
+  if (m.jtype[jt] != JOINT_FREE_FLYER && a.e && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q* on the actuated coordinates
     const int iq = m.idx_q[jt];
-    const double qi = a.q[b * m.nq + iq];
-    const double qmin = m.q_min[iq], qmax = m.q_max[iq], vmax = m.v_max[j];
-    if (qmax < 1e20 && qmax > qmin + 1e-10) {  // configuration_limit.py:50-56, 111-120
-      lo = a.config_limit_gain * (qmin - qi);
-      hi = a.config_limit_gain * (qmax - qi);
-    }
-    if (vmax < 1e20 && vmax > 1e-10) {  // velocity_limit.py:61-64, 118-120
-      lo = fmax(lo, -a.dt * vmax);
-      hi = fmin(hi, a.dt * vmax);
-    }
-    if (a.e && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q* on the actuated coordinates
-      const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
-      a.e[b * a.K + a.e_off + (j - m.root_nv)] = qi - qt;
-    }
+    const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
+    a.e[b * a.K + a.e_off + (j - m.root_nv)] = qi - qt;
   }
   a.lb[b * m.nv + j] = lo;
   a.ub[b * m.nv + j] = hi;
@@ -348,50 +471,7 @@ __device__ inline void ik_integrate_thread(const IntegrateArgs &a, long long t) 
       return;
     }
   }
-  double *q = a.q + b * m.nq + m.idx_q[j];
-  const double *v = a.dq + b * m.nv + m.idx_v[j];
-  if (m.jtype[j] != JOINT_FREE_FLYER) {
-    q[0] += v[0];
-    return;
-  }
-  // M <- M exp6(v): p += R V(w) v_lin, quat <- quat * exp(w / 2)
-  double R[9];
-  quat_to_rot(q + 3, R);
-  const double wx = v[3], wy = v[4], wz = v[5];
-  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-  double A, Bc;  // V = I + A [w]x + Bc [w]x^2
-  if (th < 1e-8) {
-    A = 0.5;
-    Bc = 1.0 / 6.0;
-  } else {
-    A = (1.0 - cos(th)) / th2;
-    Bc = (th - sin(th)) / (th2 * th);
-  }
-  const double cx = wy * v[2] - wz * v[1], cy = wz * v[0] - wx * v[2], cz = wx * v[1] - wy * v[0];  // w x v
-  const double ccx = wy * cz - wz * cy, ccy = wz * cx - wx * cz, ccz = wx * cy - wy * cx;          // w x (w x v)
-  const double tx = v[0] + A * cx + Bc * ccx, ty = v[1] + A * cy + Bc * ccy, tz = v[2] + A * cz + Bc * ccz;
-  q[0] += R[0] * tx + R[1] * ty + R[2] * tz;
-  q[1] += R[3] * tx + R[4] * ty + R[5] * tz;
-  q[2] += R[6] * tx + R[7] * ty + R[8] * tz;
-  double s_h, c_h;  // unit quaternion of exp(w): (sin(th/2)/th w, cos(th/2))
-  if (th < 1e-8) {
-    s_h = 0.5;
-    c_h = 1.0;
-  } else {
-    s_h = sin(0.5 * th) / th;
-    c_h = cos(0.5 * th);
-  }
-  const double dx = s_h * wx, dy = s_h * wy, dz = s_h * wz, dw = c_h;
-  const double x = q[3], y = q[4], z = q[5], w = q[6];
-  double nx = w * dx + x * dw + y * dz - z * dy;
-  double ny = w * dy - x * dz + y * dw + z * dx;
-  double nz = w * dz + x * dy - y * dx + z * dw;
-  double nw = w * dw - x * dx - y * dy - z * dz;
-  const double n = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
-  q[3] = nx * n;
-  q[4] = ny * n;
-  q[5] = nz * n;
-  q[6] = nw * n;
+  integrate_joint(m, j, a.q + b * m.nq + m.idx_q[j], a.dq + b * m.nv + m.idx_v[j]);
 }
 
 __global__ void __launch_bounds__(256) ik_integrate_kernel(IntegrateArgs a) {

@@ -32,6 +32,12 @@
 #define PINKHIP_OCCUPANCY_PACKED(NV) \
   __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
 
+// fused forward-kinematics kernels: ~210 live registers in the log6 / Jlog6 section
+#ifndef PINKHIP_FK_WAVES
+#define PINKHIP_FK_WAVES 2
+#endif
+#define PINKHIP_OCCUPANCY_FK __attribute__((amdgpu_waves_per_eu(PINKHIP_FK_WAVES, PINKHIP_FK_WAVES)))
+
 namespace pinkhip {
 
 constexpr int kWave = 64;
@@ -168,6 +174,28 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = fma(0.5 * y, e, y);
   e = fma(-(x * y), y, 1.0);
   return fma(0.5 * y, e, y);
+}
+
+// sin and cos of a joint angle: Cody-Waite reduction by pi/2 (two FMAs, exact to ~1e-32 |k|) + the fdlibm
+// minimax kernels on [-pi/4, pi/4]; ~1 ulp for |t| < 1e5 rad.  The libm versions carry a Payne-Hanek path for
+// huge arguments that costs private-memory scratch and registers in every kernel that calls them.
+__device__ __forceinline__ void fast_sincos(double t, double &sn, double &cs) {
+  const double k = rint(t * 0.63661977236758134308);  // 2 / pi
+  double r = fma(-k, 1.5707963267948966, t);
+  r = fma(-k, 6.123233995736766e-17, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double s0 = fma(r * z, ps, r);
+  const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = static_cast<int>(k) & 3;
+  const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
+  sn = (q & 2) ? -s1 : s1;
+  cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
 // One Newton step (~2e-14 relative): for quantities that only steer the active-set iteration or are

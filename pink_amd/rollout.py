@@ -5,11 +5,13 @@ robot at a time (``examples/inverse_kinematics_ur10.py:75-91``, ``tests/test_sol
 :160-210``).  ``DeviceRollout`` keeps ``B`` robots resident in HBM and runs every stage of a
 step as a HIP kernel, with no host round trip between steps:
 
-    forward kinematics + FrameTask e, J      pinkhip_fk_frame_tasks_device (one fused launch; ``fused=False``:
-                                             pinkhip_fk_device + one pinkhip_frame_task_strided_device per task)
-    box limits + PostureTask error           pinkhip_limits_posture_device
+    q <- q (+) dq of the previous step, forward kinematics, FrameTask e and J,
+    box limits, PostureTask error            pinkhip_step_device (ONE launch)
     stack + QP solve                         pinkhip_solve_device
-    q <- q (+) dq                            pinkhip_integrate_device
+
+i.e. two launches per control step (``fused=False`` keeps the five separate ones: pinkhip_fk_device, one
+pinkhip_frame_task_strided_device per task, pinkhip_limits_posture_device, pinkhip_solve_device,
+pinkhip_integrate_checked_device -- kept for A/B runs and as a cross-check of the fusion).
 
 The task stack is the one of Pink's humanoid / arm examples: any number of FrameTasks plus an
 optional PostureTask, the model's configuration and velocity limits.
@@ -22,7 +24,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import Desc, Problem, Result, c_double_p, c_int32_p
+from ._lib import Desc, Problem, Result, Step, c_double_p, c_int32_p
 from .configuration import Model
 from .exceptions import NoSolutionFound, NotWithinConfigurationLimits
 from .utils import get_root_joint_dim
@@ -177,6 +179,7 @@ class DeviceRollout:
         r.dq, r.status, r.iters = self.d_dq, self.d_status, self.d_iters
         self.result = r
         self.steps_done = 0
+        self._pending = False  # a solved dq waits to be integrated by the next whole-step launch
 
     def set_targets(self, targets: np.ndarray) -> None:
         """Frame targets, ``[B, n_frame_tasks, 12]`` poses (rotation row-major, translation)."""
@@ -187,25 +190,45 @@ class DeviceRollout:
         """Enqueue one IK step for every robot (asynchronous)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         if self.fused:
-            if nf:
-                a.fk_frame_tasks(self.dmodel, B, self.d_q, self.d_Tt, self.d_T, self.d_e, self.K, self.d_J, self.Kd * nv)
-        else:  # one launch for FK, one per FrameTask (kept for A/B runs and as a cross-check of the fusion)
+            # one launch applies the previous step's dq (status-checked), then FK, frame-task rows, limits, posture
+            st = Step()
+            st.q = self.d_q
+            st.dq_prev = self.d_dq if self._pending else None
+            st.status, st.first_failure, st.step = self.d_status, self.d_fail, max(self.steps_done - 1, 0)
+            st.target_batched = 1
+            st.T_target, st.T_frames = self.d_Tt, self.d_T
+            st.e, st.sE, st.J, st.sJ = self.d_e, self.K, self.d_J, self.Kd * nv
+            st.dt, st.config_limit_gain = self.dt, self.config_limit_gain
+            st.q_target = self.d_qt if self.n_post else None
+            st.lb, st.ub, st.e_off = self.d_lb, self.d_ub, self.Kd
+            a.step_kernel(self.dmodel, B, st)
+            a.solve_raw(self.desc, self.problem, self.result)
+            self._pending = True
+        else:  # one launch for FK, one per FrameTask, limits + posture, solve, integrate
             a.fk(self.dmodel, B, self.d_q, self.d_T, self.d_Jb)
             for t in range(nf):
                 a.frame_task_strided(B, nv, self.d_T + 8 * 12 * t, 12 * nf, self.d_Tt + 8 * 12 * t, 12 * nf,
                                      self.d_Jb + 8 * 6 * nv * t, 6 * nv * nf, self.d_e + 8 * 6 * t, self.K,
                                      self.d_J + 8 * 6 * nv * t, self.Kd * nv)
-        a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
-                         self.d_e if self.n_post else None, self.K, self.Kd)
-        a.solve_raw(self.desc, self.problem, self.result)
-        a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
+            a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
+                             self.d_e if self.n_post else None, self.K, self.Kd)
+            a.solve_raw(self.desc, self.problem, self.result)
+            a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
         self.steps_done += 1
+
+    def flush(self) -> None:
+        """Apply the displacement of the last enqueued step (the whole-step kernel integrates lazily, at the
+        start of the next step); called by everything that reads the configurations."""
+        if self._pending:
+            self.api.integrate_checked(self.dmodel, self.B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done - 1)
+            self._pending = False
 
     def run(self, steps: int, raise_on_failure: bool = True) -> None:
         """``steps`` IK steps for every robot, then one synchronisation.  Raises :class:`NoSolutionFound`
         listing the robots whose QP failed at some step (they stopped moving at that step)."""
         for _ in range(steps):
             self.step()
+        self.flush()
         self.api.sync()
         if raise_on_failure:
             idx, status, step = self.failures()
@@ -216,6 +239,7 @@ class DeviceRollout:
 
     def failures(self):
         """``(indices, status, step)`` of the robots whose solve has failed so far (first failure of each)."""
+        self.flush()
         f = np.zeros(self.B, np.int32)
         self.api.get(f, self.d_fail)
         idx = np.nonzero(f)[0]
@@ -238,6 +262,7 @@ class DeviceRollout:
             logging.warning("Value %f at index %d of instance %d is out of limits: [%f, %f]", q0[b, i], i, b, lo[i], up[i])
 
     def configurations(self) -> np.ndarray:
+        self.flush()
         q = np.zeros((self.B, self.nq))
         self.api.get(q, self.d_q)
         return q

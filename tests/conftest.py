@@ -117,6 +117,12 @@ class EmuSolver:
         self.lib.pinkhip_emu_fk_frame_tasks.argtypes = [vp, ll, vp, vp, vp, vp, ll, vp, ll]
         self.lib.pinkhip_emu_fk_frame_tasks(model, B, q, T_target, T_frames, e, sE, J, sJ)
 
+    def step_kernel(self, model, B, args):
+        from pink_amd._lib import Step
+
+        self.lib.pinkhip_emu_step.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(Step)]
+        self.lib.pinkhip_emu_step(model, B, ctypes.byref(args))
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ):
         vp, ll = ctypes.c_void_p, ctypes.c_longlong
         self.lib.pinkhip_emu_frame_task_strided.argtypes = [ll, ctypes.c_int, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll]

@@ -122,6 +122,11 @@ void lane_main_fk_fused(void *p) {
   pinkhip::ik_fk_instance<W, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
 }
 
+template <int W>
+void lane_main_step(void *p) {
+  pinkhip::ik_fk_instance<W, true, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
+}
+
 struct EmuModel {
   pinkhip::ModelImage image;
   pinkhip::ModelDev dev;
@@ -173,6 +178,36 @@ int pinkhip_emu_fk_frame_tasks(void *mp, long long B, const double *q, const dou
     for (long long b = 0; b < (B + 1) / 2; ++b) pinkhip::emu_run_block(b, lane_main_fk_fused<32>, &a);
   } else {
     for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_fk_fused<64>, &a);
+  }
+  return PINKHIP_OK;
+}
+int pinkhip_emu_step(void *mp, long long B, const pinkhip_step *st) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::FkArgs a{m->dev, B, st->q, st->T_frames, nullptr};
+  a.T_target = st->T_target;
+  a.e_out = st->e;
+  a.J_out = st->J;
+  a.sE = st->sE;
+  a.sJo = st->sJ;
+  a.q_rw = st->q;
+  a.dq_prev = st->dq_prev;
+  a.status = st->status;
+  a.first_failure = st->first_failure;
+  a.step = st->step;
+  a.dt = st->dt;
+  a.config_limit_gain = st->config_limit_gain;
+  a.q_target = st->q_target;
+  a.target_batched = st->target_batched;
+  a.lb = st->lb;
+  a.ub = st->ub;
+  a.e_off = st->e_off;
+  const int width = m->dev.nv > m->dev.nj ? m->dev.nv : m->dev.nj;
+  if (width <= 8) {
+    for (long long b = 0; b < (B + 7) / 8; ++b) pinkhip::emu_run_block(b, lane_main_step<8>, &a);
+  } else if (width <= 32) {
+    for (long long b = 0; b < (B + 1) / 2; ++b) pinkhip::emu_run_block(b, lane_main_step<32>, &a);
+  } else {
+    for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_step<64>, &a);
   }
   return PINKHIP_OK;
 }

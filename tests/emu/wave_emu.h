@@ -25,6 +25,7 @@
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV)
+#define PINKHIP_OCCUPANCY_FK
 
 // element-wise kernels use blockIdx / threadIdx directly; the emulator calls their per-thread
 // bodies in a plain loop and only needs the names to exist
@@ -165,6 +166,10 @@ inline int key_payload(double k) {
   long long b;
   std::memcpy(&b, &k, 8);
   return (int)(b & 0xFF);
+}
+inline void fast_sincos(double t, double &sn, double &cs) {
+  sn = std::sin(t);
+  cs = std::cos(t);
 }
 inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
