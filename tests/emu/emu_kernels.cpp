@@ -28,6 +28,11 @@ void lane_main_packed(void *p) {
     pinkhip::ik_packed_instance<NV, W, true>(*a, pinkhip::block_id());
 }
 
+template <int TP>
+void lane_main_stack_small(void *p) {
+  pinkhip::ik_stack_small_instance<TP>(*static_cast<const KernelArgs *>(p), pinkhip::block_id());
+}
+
 template <int NT>
 void lane_main_stack_mfma(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
@@ -78,7 +83,12 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   a.c_out = c_out;
   pinkhip::LaneFn fn = nullptr;
   long long blocks = d->B;
-  if (!solve) {
+  if (!solve && a.nv <= 8 && a.n_barriers == 0) {  // same rule as pinkhip.hip
+    // (the library switches to four tiles per wave at B >= 65536; the emulator exercises both on small batches)
+    const bool four = (d->B % 2) == 1;
+    fn = four ? lane_main_stack_small<4> : lane_main_stack_small<1>;
+    blocks = four ? (d->B + 7) / 8 : (d->B + 1) / 2;
+  } else if (!solve) {
     switch ((a.nv + 15) / 16) {
       case 1: fn = lane_main_stack_mfma<1>; break;
       case 2: fn = lane_main_stack_mfma<2>; break;

@@ -26,6 +26,7 @@
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV)
 #define PINKHIP_OCCUPANCY_FK
+#define PINKHIP_OCCUPANCY_SMALL_STACK
 
 // element-wise kernels use blockIdx / threadIdx directly; the emulator calls their per-thread
 // bodies in a plain loop and only needs the names to exist

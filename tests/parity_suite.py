@@ -359,3 +359,27 @@ def kkt_certificate(solver, seeds):
             assert stat <= 1e-9 * scale and viol <= 1e-10, (sd, b, stat, viol)
             n_checked += 1
     return n_checked
+
+
+def small_stack_packing(solver):
+    """nv <= 8 without barriers takes the stack kernel that packs eight instances per wavefront (two per MFMA
+    tile): every batch size around the packing boundaries, LM damping, per-instance costs, a diagonal task that
+    does not start at column 0."""
+    rng = np.random.default_rng(21)
+    for nv in (1, 3, 6, 8):
+        for B in (1, 7, 8, 9, 17):
+            k = int(rng.integers(1, 9))
+            J = rng.normal(0, 0.5, size=(B, k, nv))
+            e = 0.1 * rng.normal(size=(B, k))
+            cost = rng.uniform(0.5, 2.0, size=(B, k)) if B % 2 else rng.uniform(0.5, 2.0, size=k)
+            root = int(rng.integers(0, nv))
+            ep = rng.uniform(-0.5, 0.5, size=(B, nv - root))
+            tasks = [DenseTaskTerm(J=J, e=e, cost=cost, gain=0.8, lm_damping=0.3),
+                     DiagonalTaskTerm(col0=root, e=ep, cost=0.2, gain=0.9, lm_damping=0.1)]
+            batch = pack_terms(nv, tasks, 0.01, 1e-9, batch_size=B)
+            H, c = solver.stack(batch)
+            for b in range(B):
+                cb = cost[b] if cost.ndim == 2 else cost
+                Hr, cr = po.qp_objective(nv, [(J[b], e[b], cb, 0.8, 0.3), (np.eye(nv)[root:], ep[b], 0.2, 0.9, 0.1)], 1e-9)
+                assert np.abs(H[b] - Hr).max() <= 1e-13 * max(1.0, np.abs(Hr).max()), (nv, B, b)
+                assert np.abs(c[b] - cr).max() <= 1e-13 * max(1.0, np.abs(cr).max()), (nv, B, b)

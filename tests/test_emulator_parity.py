@@ -93,3 +93,7 @@ def test_fuzz(emu):
 
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):
     assert ps.kkt_certificate(emu, range(9000, 9060)) > 80
+
+
+def test_small_stack_packing(emu):
+    ps.small_stack_packing(emu)

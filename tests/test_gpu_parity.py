@@ -153,9 +153,43 @@ def test_rccl_gather_single_rank(gpu_solver):
         s._d2h(got, recv)
         assert np.array_equal(got, out.dq)
         s._free(recv)
+        # byte gather / all-gather of the int32 status and iteration counts (what solve_sharded moves)
+        for fn in (lambda d: s.comm_gather_bytes(dev.d_iters, d, 4 * 256, 0), lambda d: s.comm_allgather_bytes(dev.d_iters, d, 4 * 256)):
+            recv = s._malloc(4 * 256)
+            fn(recv)
+            s.sync()
+            it = np.zeros(256, np.int32)
+            s._d2h(it, recv)
+            assert np.array_equal(it, out.iters)
+            s._free(recv)
+        # RcclComm-shaped device gather helper used by pink_amd.sharding (one rank: the gather is a copy)
+        from pink_amd.comm import HostRendezvous, RcclComm
+
+        class OneRank(RcclComm):
+            def __init__(self, solver):  # communicator already initialised above
+                self.solver, self.rdzv, self.rank, self.world = solver, HostRendezvous(0, 1), 0, 1
+
+        d = OneRank(s).gather_device(dev.d_dq, 8 * n, None)
+        s.sync()
+        got2 = np.zeros((256, 6))
+        s.get(got2, d)
+        assert np.array_equal(got2, out.dq)
+        s.release(d)
     finally:
         s.comm_destroy()
         dev.free()
+
+
+def test_pinned_host_path_equals_pageable(gpu_solver):
+    """pinkhip_solve_host from page-locked buffers (chunked, overlapped H2D) returns bit for bit what the pageable
+    single-copy path returns, across several chunks and with dense rows / equalities in the batch."""
+    s = gpu_solver
+    batch, _ = config_case("jvrc", "tight", "dense", 6000)  # ~13.8 kB per instance: three chunks of 32 MB
+    ref = s.solve(batch)
+    pb, pr = s.pin(batch), s.pinned_result(batch.B, batch.nv)
+    out = s.solve(pb, out=pr)
+    assert out.dq is pr.dq and np.array_equal(pr.dq, ref.dq) and np.array_equal(pr.status, ref.status) and np.array_equal(pr.iters, ref.iters)
+    assert (ref.status == 0).all()
 
 
 def test_api_errors(gpu_solver):
@@ -169,3 +203,7 @@ def test_api_errors(gpu_solver):
 
 def test_kkt_certificate_independent_of_the_oracle_solver(gpu_solver):
     assert ps.kkt_certificate(gpu_solver, range(9000, 9400)) > 500
+
+
+def test_small_stack_packing(gpu_solver):
+    ps.small_stack_packing(gpu_solver)
