@@ -176,14 +176,19 @@ def reference_build_ik_rate(terms):
         return {"available": False, "reason": f"failed: {exc!r}"}
 
 
-def kernel_ms_of(solver, dev, steps: int, stack: bool = False) -> float:
+def kernel_ms_of(solver, dev, steps: int, stack: bool = False, repeats: int = 3) -> float:
+    """Median over `repeats` of the HIP-event time of `steps` back-to-back launches (auxiliary figures only: the
+    headline is timed once, over exactly K steps, in main())."""
     run = solver.stack_device if stack else solver.solve_device
     run(dev)
     solver.sync()
-    solver.timer_start()  # HIP events on the stream the kernel runs on
-    for _ in range(steps):
-        run(dev)
-    return solver.timer_stop() / max(steps, 1)
+    out = []
+    for _ in range(repeats):
+        solver.timer_start()  # HIP events on the stream the kernel runs on
+        for _ in range(steps):
+            run(dev)
+        out.append(solver.timer_stop() / max(steps, 1))
+    return statistics.median(out)
 
 
 def measure_config(solver, name: str, B: int, steps: int, parity_sample: int, seed=None, **kw) -> dict:

@@ -106,6 +106,7 @@ class HostRendezvous:
                     continue
                 _send(c, hello)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(None)  # collectives block for as long as the slowest rank takes
                 self._peers[r] = c
                 joined += 1
             srv.close()
@@ -121,6 +122,7 @@ class HostRendezvous:
                         _send(s, hello + struct.pack("<q", self.rank))
                         if _recv(s) == hello:
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            s.settimeout(None)
                             self._root = s
                             break
                     except (OSError, ConnectionError, struct.error):

@@ -29,7 +29,7 @@
 // Profiling builds only (scripts/section_clock.py compiles with -DPINKHIP_SECTION_CLOCK): every 64th
 // wave adds the s_memtime cycles it spends in each section of the kernel to pinkhip_clock[].
 #ifdef PINKHIP_SECTION_CLOCK
-__device__ unsigned long long pinkhip_clock[16];
+static __device__ unsigned long long pinkhip_clock[16];  // one copy per translation unit
 #define PINKHIP_TICK(k)                                                        \
   do {                                                                         \
     if (clock_on) {                                                            \

@@ -918,18 +918,6 @@ int pinkhip_timer_start(pinkhip_handle *h) {
   return PINKHIP_OK;
 }
 
-#ifdef PINKHIP_SECTION_CLOCK
-// profiling builds only (scripts/section_clock.py): read and clear the per-section cycle counters
-int pinkhip_debug_section_clock(pinkhip_handle *h, unsigned long long *out16) {
-  if (!h || !out16) return PINKHIP_E_INVALID;
-  if (hipStreamSynchronize(h->stream) != hipSuccess) return PINKHIP_E_HIP;
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pinkhip_clock), 16 * sizeof(unsigned long long)) != hipSuccess)
-    return PINKHIP_E_HIP;
-  unsigned long long zero[16] = {0};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(pinkhip_clock), zero, sizeof(zero)) != hipSuccess) return PINKHIP_E_HIP;
-  return PINKHIP_OK;
-}
-#endif
 
 int pinkhip_timer_stop(pinkhip_handle *h, float *elapsed_ms) {
   if (!h || !elapsed_ms) return fail(h, PINKHIP_E_INVALID, "bad argument");

@@ -26,3 +26,17 @@ hipError_t PINKHIP_LAUNCH_PACKED_NAME(PINKHIP_TU_NV, PINKHIP_TU_W, PINKHIP_TU_DE
 }
 
 }  // namespace pinkhip
+
+#if defined(PINKHIP_SECTION_CLOCK) && PINKHIP_TU_DENSE == 0
+// profiling builds only (scripts/section_clock.py, make DEV=1 SECTION_CLOCK=1): read and clear the per-section
+// cycle counters of this translation unit's kernel
+extern "C" int pinkhip_debug_section_clock(void *handle_unused, unsigned long long *out16) {
+  (void)handle_unused;
+  if (!out16) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pinkhip_clock), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pinkhip_clock), zero, sizeof(zero)) != hipSuccess) return -2;
+  return 0;
+}
+#endif

@@ -21,9 +21,8 @@ SECTIONS = ["stacking", "Cholesky", "J = L^-T, x0", "selection", "d = J^T n (row
 
 
 def build():
-    cmd = ["hipcc"] + ge.HIPCC_FLAGS + ["-DPINKHIP_SECTION_CLOCK"] + \
-        [os.path.join(ge.CSRC, s) for s in ge.HIP_SOURCES] + ["-o", LIB]
-    subprocess.run(cmd, check=True)
+    """One-kernel profiling library: make DEV=1 SECTION_CLOCK=1 (the headline instantiation only)."""
+    subprocess.run(["make", "-j4", "DEV=1", "SECTION_CLOCK=1", "OBJDIR=build_clock", "OUT=libpinkhip_clock.so"], cwd=ge.CSRC, check=True)
 
 
 def main():
