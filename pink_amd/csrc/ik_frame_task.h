@@ -93,10 +93,8 @@ __device__ inline void alpha_beta(double th, double &alpha, double &beta) {
   }
 }
 
-// twist [v; w] with exp6 = (R, p)
-__device__ inline void log6(const double *R, const double *p, double *xi) {
-  double w[3], th;
-  log3(R, w, th);
+// twist [v; w] with exp6 = (R, p), given w = log3(R) and its norm
+__device__ inline void log6_from_log3(const double *w, double th, const double *p, double *xi) {
   double alpha, beta;
   alpha_beta(th, alpha, beta);
   const double wp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
@@ -107,11 +105,14 @@ __device__ inline void log6(const double *R, const double *p, double *xi) {
   xi[4] = w[1];
   xi[5] = w[2];
 }
-
-// right Jacobian of log6 at (R, p), row-major 6 x 6: [[A, C A], [0, A]]
-__device__ inline void jlog6(const double *R, const double *p, double *Jl) {
+__device__ inline void log6(const double *R, const double *p, double *xi) {
   double w[3], th;
   log3(R, w, th);
+  log6_from_log3(w, th, p, xi);
+}
+
+// right Jacobian of log6 at (R, p), row-major 6 x 6: [[A, C A], [0, A]], given w = log3(R) and its norm
+__device__ inline void jlog6_from_log3(const double *w, double th, const double *p, double *Jl) {
   double a, d, beta, beta_dot;
   if (th < 1e-4) {
     a = 1.0 / 12.0 + th * th / 720.0;
@@ -149,6 +150,11 @@ __device__ inline void jlog6(const double *R, const double *p, double *Jl) {
       Jl[6 * (i + 3) + j] = 0.0;
       Jl[6 * (i + 3) + 3 + j] = A[3 * i + j];
     }
+}
+__device__ inline void jlog6(const double *R, const double *p, double *Jl) {
+  double w[3], th;
+  log3(R, w, th);
+  jlog6_from_log3(w, th, p, Jl);
 }
 
 template <int W>

@@ -227,6 +227,29 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   double *qs = Jls + 36 * m.nf;  // scalar configuration of every joint (STEP)
   const double *q = a.q + b * (long long)m.nq;
 
+  // The tables the later steps need for THIS lane's first frame / tangent column are requested now: the
+  // barriers of steps 1-2 would otherwise keep these loads (model tables in L2, targets in HBM) from starting
+  // before the poses are composed, and the kernel is bound by exactly such dependent round trips.
+  int pf_fj = -1, pf_jt = 0, pf_sub = 0, pf_ty = 0;
+  double pf_FP[12], pf_Tt[12], pf_ax[3];
+  unsigned pf_anc = 0;  // bit f: joint of column li is an ancestor of frame f (first 32 frames)
+  if constexpr (FUSED) {
+    const int f0 = li < m.nf ? li : 0;
+    pf_fj = m.frame_joint[f0];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      pf_FP[i] = m.frame_placement[12 * f0 + i];
+      pf_Tt[i] = a.T_target[(b * m.nf + f0) * 12 + i];
+    }
+    const int j0 = li < m.nv ? li : 0;
+    pf_jt = m.dof_joint[j0];
+    pf_sub = m.dof_sub[j0];
+    pf_ty = m.jtype[pf_jt];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pf_ax[i] = m.axis[3 * pf_jt + i];
+    for (int f = 0; f < m.nf && f < 32; ++f) pf_anc |= (m.anc[f * m.nj + pf_jt] != 0 ? 1u : 0u) << f;
+  }
+
   // 1. pose of joint li in its parent's frame
   const bool isj = li < m.nj;
   const int jl = isj ? li : 0;
@@ -292,6 +315,129 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
     }
     wave_sync();
   }
+  if constexpr (FUSED) {
+    // 3. lane = frame: pose, FrameTask error, and the two 3 x 3 blocks that turn a WORLD twist [lin; ang] of a
+    //    joint into the six rows of the task Jacobian:  J_task = -Jlog6(T_t^-1 T_f) X_f^-1 [lin; ang]  with
+    //    X_f^-1 = [[R_f^T, -R_f^T [p_f]x], [0, R_f^T]] and Jlog6 = [[A, C A], [0, A]]  gives
+    //    rows 0..2 = -(U lin + V ang), rows 3..5 = -U ang,  U = A R_f^T,  V = (C A) R_f^T - U [p_f]x.
+    //    log3 is evaluated once: log(T_t^-1 T_f) has the rotation vector of log(T_f^-1 T_t) negated.
+    for (int f = li; f < m.nf; f += W) {
+      double F[12], FP[12], Tt[12];
+      const bool first = f == li;  // prefetched above
+      const int fj = first ? pf_fj : m.frame_joint[f];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        FP[i] = first ? pf_FP[i] : m.frame_placement[12 * f + i];
+        Tt[i] = first ? pf_Tt[i] : a.T_target[(b * m.nf + f) * 12 + i];
+      }
+      if (fj >= 0) {
+        se3_mul(oM + 12 * fj, FP, F);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) F[i] = FP[i];
+      }
+      if (valid && a.T_frames) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a.T_frames[(b * m.nf + f) * 12 + i] = F[i];
+      }
+      double R1[9], p1[3], w[3], th;
+      se3_act_inv(F, Tt, R1, p1);  // T_f^-1 T_t
+      log3(R1, w, th);
+      {
+        double xi[6];
+        log6_from_log3(w, th, p1, xi);  // e = log6(T_frame^-1 T_target), frame_task.py:181-193
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) a.e_out[b * a.sE + 6 * f + i] = xi[i];
+        }
+      }
+      // T_t^-1 T_f = (R1^T, -R1^T p1), rotation vector -w
+      double p2[3], w2[3], Jl[36];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        p2[i] = -(R1[i] * p1[0] + R1[3 + i] * p1[1] + R1[6 + i] * p1[2]);
+        w2[i] = -w[i];
+      }
+      jlog6_from_log3(w2, th, p2, Jl);  // frame_task.py:222-227
+      double *UV = Jls + 36 * f;  // U (9) then V (9)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double U[3], CR[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // times R_f^T: column k of R_f^T is row k of R_f
+          U[k] = Jl[6 * i] * F[3 * k] + Jl[6 * i + 1] * F[3 * k + 1] + Jl[6 * i + 2] * F[3 * k + 2];
+          CR[k] = Jl[6 * i + 3] * F[3 * k] + Jl[6 * i + 4] * F[3 * k + 1] + Jl[6 * i + 5] * F[3 * k + 2];
+        }
+        // (U [p]x)[k] = sum_l U[l] P[l][k],  [p]x = [[0, -pz, py], [pz, 0, -px], [-py, px, 0]]
+        UV[3 * i] = U[0];
+        UV[3 * i + 1] = U[1];
+        UV[3 * i + 2] = U[2];
+        UV[9 + 3 * i] = CR[0] - (U[1] * F[11] - U[2] * F[10]);
+        UV[9 + 3 * i + 1] = CR[1] - (U[2] * F[9] - U[0] * F[11]);
+        UV[9 + 3 * i + 2] = CR[2] - (U[0] * F[10] - U[1] * F[9]);
+      }
+    }
+    wave_sync();
+    // 4. lane = tangent column: world twist of the column's joint axis, then 27 FMAs per ancestor frame
+    for (int j = li; j < m.nv; j += W) {
+      const bool first = j == li;  // prefetched above
+      const int jt = first ? pf_jt : m.dof_joint[j], sub = first ? pf_sub : m.dof_sub[j], ty = first ? pf_ty : m.jtype[jt];
+      const double *Xj = oM + 12 * jt;  // world pose of the joint
+      double ax[3], u[3];
+      if (ty == JOINT_FREE_FLYER) {
+        const int k = sub % 3;
+        ax[0] = k == 0 ? 1.0 : 0.0;
+        ax[1] = k == 1 ? 1.0 : 0.0;
+        ax[2] = k == 2 ? 1.0 : 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ax[i] = first ? pf_ax[i] : m.axis[3 * jt + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) u[i] = Xj[3 * i] * ax[0] + Xj[3 * i + 1] * ax[1] + Xj[3 * i + 2] * ax[2];
+      const bool angular = (ty == JOINT_REVOLUTE) || (ty == JOINT_FREE_FLYER && sub >= 3);
+      double lin[3], ang[3];
+      if (angular) {  // axis through the joint origin: [p x u; u]
+        lin[0] = Xj[10] * u[2] - Xj[11] * u[1];
+        lin[1] = Xj[11] * u[0] - Xj[9] * u[2];
+        lin[2] = Xj[9] * u[1] - Xj[10] * u[0];
+        ang[0] = u[0], ang[1] = u[1], ang[2] = u[2];
+      } else {
+        lin[0] = u[0], lin[1] = u[1], lin[2] = u[2];
+        ang[0] = ang[1] = ang[2] = 0.0;
+      }
+      for (int f = 0; f < m.nf; ++f) {
+        const bool on = (first && f < 32) ? ((pf_anc >> f) & 1u) != 0 : m.anc[f * m.nj + jt] != 0;
+        const double *UV = Jls + 36 * f;
+        double *Jo = a.J_out + b * a.sJo + (long long)(6 * f) * m.nv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double top = UV[3 * i] * lin[0] + UV[3 * i + 1] * lin[1] + UV[3 * i + 2] * lin[2] +
+                             UV[9 + 3 * i] * ang[0] + UV[9 + 3 * i + 1] * ang[1] + UV[9 + 3 * i + 2] * ang[2];
+          const double bot = UV[3 * i] * ang[0] + UV[3 * i + 1] * ang[1] + UV[3 * i + 2] * ang[2];
+          if (valid) {
+            Jo[i * m.nv + j] = on ? -top : 0.0;
+            Jo[(i + 3) * m.nv + j] = on ? -bot : 0.0;
+          }
+        }
+      }
+    if constexpr (STEP) {
+      // 5. merged box limits and the posture error of tangent coordinate j (qs was published before step 2's barriers)
+      const double qi = qs[jt];
+      double lo, hi;
+      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
+      if (valid) {
+        a.lb[b * m.nv + j] = lo;
+        a.ub[b * m.nv + j] = hi;
+        if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q*
+          const int iq = m.idx_q[jt];
+          const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
+          a.e_out[b * a.sE + a.e_off + (j - m.root_nv)] = qi - qt;
+        }
+      }
+    }
+    }
+  } else {
   // 3. frames
   for (int f = li; f < m.nf; f += W) {
     double F[12];
@@ -380,20 +526,6 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
         }
       }
     }
-    if constexpr (STEP) {
-      // 5. merged box limits and the posture error of tangent coordinate j (qs was published before step 2's barriers)
-      const double qi = qs[jt];
-      double lo, hi;
-      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
-      if (valid) {
-        a.lb[b * m.nv + j] = lo;
-        a.ub[b * m.nv + j] = hi;
-        if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q*
-          const int iq = m.idx_q[jt];
-          const double qt = a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq];
-          a.e_out[b * a.sE + a.e_off + (j - m.root_nv)] = qi - qt;
-        }
-      }
     }
   }
 }

@@ -32,9 +32,10 @@
 #define PINKHIP_OCCUPANCY_PACKED(NV) \
   __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
 
-// fused forward-kinematics kernels: ~210 live registers in the log6 / Jlog6 section
+// fused forward-kinematics kernels: latency bound (dependent table / LDS round trips), three waves per SIMD
+// measured best (0.576 -> 0.548 ms per nv = 30 step; four waves spill)
 #ifndef PINKHIP_FK_WAVES
-#define PINKHIP_FK_WAVES 2
+#define PINKHIP_FK_WAVES 3
 #endif
 #define PINKHIP_OCCUPANCY_FK __attribute__((amdgpu_waves_per_eu(PINKHIP_FK_WAVES, PINKHIP_FK_WAVES)))
 
@@ -50,7 +51,21 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x); }
 __device__ __forceinline__ long long block_id() { return static_cast<long long>(blockIdx.x); }
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// Hand-off through LDS between the lanes of the ONE wavefront of the workgroup.  __syncthreads() would be
+// correct but also waits for every outstanding global load and store (s_waitcnt vmcnt(0)): it stalls on the
+// prefetches that are deliberately in flight and on the kernels' output stores (the kinematics step kernel spent
+// 62 % of its wave time there, rocprofv3 SQ_WAIT_ANY).  LDS operations of one wave execute in order, so all that
+// is needed is that the compiler does not move LDS accesses across this point: wavefront-scope fences around a
+// wave barrier (which emits no instruction).
+__device__ __forceinline__ void wave_sync() {
+#ifdef PINKHIP_HEAVY_SYNC
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // Base of the workgroup's dynamic LDS allocation (16-byte aligned, no static
 // __shared__ in front of it: cdna guide, guideline 17).

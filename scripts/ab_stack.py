@@ -9,6 +9,8 @@ from pink_amd import _lib, synthetic  # noqa: E402
 from pink_amd.batch_solver import BatchSolver  # noqa: E402
 
 cases = [("draco3", 65536), ("jvrc", 65536), ("ur5", 65536), ("ur5", 4096), ("ur5", 1 << 20)]
+if os.environ.get("AB_STACK_ONLY"):
+    cases = [c for c in cases if c[0] in os.environ["AB_STACK_ONLY"].split(",")]
 batches = {c: synthetic.pack(synthetic.make_terms(c[0], c[1], bounds="tight")) for c in cases}
 for path in sys.argv[1:]:
     s = BatchSolver(0, library=_lib.load_library(os.path.abspath(path)))
