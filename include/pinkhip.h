@@ -244,6 +244,28 @@ typedef struct pinkhip_step {
   int32_t e_off;
 } pinkhip_step;
 int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const pinkhip_step *args);
+/* The whole control step in ONE kernel: forward kinematics, FrameTask rows, limits, posture error, stacking,
+ * QP solve and q <- q (+) dq -- the task Jacobians never reach memory (they are formed from the joints' world
+ * twists while the objective is stacked).  `desc` describes the task stack of the model: one 6-row dense task per
+ * model frame (in frame order: Kd = 6 nf), optionally followed by one diagonal task on the actuated coordinates
+ * (the PostureTask: col0 = root_nv, nv - root_nv rows); box limits only (md = 0).  Returns
+ * PINKHIP_E_UNSUPPORTED when no instantiation fits the model (nv > 56, or a group of lanes cannot hold the
+ * joints / the kinematics scratch): use pinkhip_step_device + pinkhip_solve_device then. */
+typedef struct pinkhip_rollout_step {
+  double *q;                 /* [B,nq] in / out */
+  const double *cost;        /* [K] (or [B,K] with desc.cost_is_batched) row weights, device memory */
+  const double *T_target;    /* [B,nf,12] */
+  double *T_frames;          /* [B,nf,12] out, may be NULL */
+  const double *q_target;    /* [nq] / [B,nq] posture target; required iff desc has the diagonal task */
+  double *dq;                /* [B,nv] out */
+  int32_t *status;           /* [B] out */
+  int32_t *iters;            /* [B] out, may be NULL */
+  int32_t *first_failure;    /* [B] sticky `status | (step << 8)`, may be NULL */
+  double config_limit_gain;
+  int32_t target_batched, step, integrate;
+} pinkhip_rollout_step;
+int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
+                                const pinkhip_rollout_step *args);
 /* q [B,nq], q_target [nq] or [B,nq] -> lb, ub [B,nv]; posture error written into e [B,K] at columns
  * e_off .. e_off + nv - root_nv (e may be NULL) */
 int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double dt,

@@ -96,13 +96,24 @@ class Step(ctypes.Structure):
     ]
 
 
+class RolloutStep(ctypes.Structure):
+    """``pinkhip_rollout_step``."""
+
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("cost", ctypes.c_void_p), ("T_target", ctypes.c_void_p), ("T_frames", ctypes.c_void_p),
+        ("q_target", ctypes.c_void_p), ("dq", ctypes.c_void_p), ("status", ctypes.c_void_p), ("iters", ctypes.c_void_p),
+        ("first_failure", ctypes.c_void_p), ("config_limit_gain", ctypes.c_double),
+        ("target_batched", ctypes.c_int32), ("step", ctypes.c_int32), ("integrate", ctypes.c_int32),
+    ]
+
+
 # every symbol include/pinkhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
     "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
-    "pinkhip_fk_frame_tasks_device", "pinkhip_step_device",
+    "pinkhip_fk_frame_tasks_device", "pinkhip_step_device", "pinkhip_rollout_step_device",
     "pinkhip_limits_posture_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
@@ -146,6 +157,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_fk_device.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.pinkhip_fk_frame_tasks_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64]
     lib.pinkhip_step_device.argtypes = [vp, vp, i64, ctypes.POINTER(Step)]
+    lib.pinkhip_rollout_step_device.argtypes = [vp, ctypes.POINTER(Desc), vp, ctypes.POINTER(RolloutStep)]
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
     lib.pinkhip_integrate_checked_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32]

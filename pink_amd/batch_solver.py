@@ -289,6 +289,15 @@ class BatchSolver:
         """Whole control step around the solve in one launch (``pinkhip_step_device``)."""
         self._check(self._lib.pinkhip_step_device(self._h, ctypes.c_void_p(model), B, ctypes.byref(args)))
 
+    def rollout_step(self, desc, model: int, args) -> bool:
+        """The whole control step in one kernel (``pinkhip_rollout_step_device``).  Returns ``False`` when no
+        instantiation fits the model (the caller then uses ``step_kernel`` + ``solve_raw``)."""
+        rc = self._lib.pinkhip_rollout_step_device(self._h, ctypes.byref(desc), ctypes.c_void_p(model), ctypes.byref(args))
+        if rc == -5:  # PINKHIP_E_UNSUPPORTED
+            return False
+        self._check(rc)
+        return True
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ) -> None:
         self._check(self._lib.pinkhip_frame_task_strided_device(self._h, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ))
 

@@ -8,7 +8,10 @@
 // W = lanes per QP (64 / W QPs per wavefront).  Every pair is built with and without the dense-row machinery.
 #ifdef PINKHIP_DEV_NV  // kernel-development builds: one instantiation only (make DEV=1 [DEVNV=50 DEVW=64], ~20 s)
 #define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
+#define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
 #else
+// the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
+#define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
   X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
 #endif
@@ -25,6 +28,18 @@ inline PackedChoice select_packed(int nv, int md) {
 #define PINKHIP_PICK(NV_, W_) \
   if (nv <= NV_ && md <= W_) return PackedChoice{NV_, W_};
   PINKHIP_PACKED_TABLE(PINKHIP_PICK)
+#undef PINKHIP_PICK
+  return PackedChoice{0, 0};
+}
+
+// Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
+// kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the scratch
+// must fit the solve kernel's own LDS share (doubles per QP of LdsP<NV>::stride(0) = NV (NV + 3) / 2 + 4 NV, even).
+inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
+#define PINKHIP_PICK(NV_, W_)                                                                       \
+  if (nv <= NV_ && nj <= W_ && fk_doubles <= ((((NV_ * (NV_ + 3) / 2 + 1) & ~1) + 4 * NV_ + 1) & ~1)) \
+    return PackedChoice{NV_, W_};
+  PINKHIP_ROLLOUT_TABLE(PINKHIP_PICK)
 #undef PINKHIP_PICK
   return PackedChoice{0, 0};
 }

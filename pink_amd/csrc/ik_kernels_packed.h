@@ -70,11 +70,24 @@ struct LdsP {
   static __host__ __device__ constexpr int prow(int r) { return -((r * (2 * NV - 1 + r)) / 2); }
 };
 
+// Where the per-instance terms come from.  HbmTerms (default): the packed streams J / e / lb / ub in HBM.  A policy
+// with kOnTheFly = true (ik_rollout.h: the whole-control-step kernel) produces the task rows, errors and bounds
+// itself -- frame_rows(f, dst) fills this lane's entries of the six rows of FrameTask f, error(k) / diag_error(r)
+// return task errors, lb / ub are members -- and receives the result back in x / status.
+struct HbmTerms {
+  static constexpr bool kOnTheFly = false;
+  double lb = 0.0, ub = 0.0, x = 0.0;
+  int status = 0;
+  __device__ __forceinline__ void frame_rows(int, double (&)[6]) const {}
+  __device__ __forceinline__ double error(int) const { return 0.0; }
+  __device__ __forceinline__ double diag_error(int) const { return 0.0; }
+};
+
 // DENSE = false is the instantiation for problems without dense inequality / equality rows (box limits
 // only, md = 0): every dense-row branch and its state (row slacks, row norms, equality bookkeeping)
 // folds away at compile time.
-template <int NV, int W, bool DENSE = true>
-__device__ inline void ik_packed_instance(const KernelArgs &a, long long block) {
+template <int NV, int W, bool DENSE = true, class Src = HbmTerms>
+__device__ inline void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
   static_assert(W >= NV && NV % 2 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
@@ -131,17 +144,27 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
     // next chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters
     // every lane's H row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j]
     // taken from lane j and w_k^2 from lane k.
-    constexpr int RC = S::RC < 8 ? S::RC : 8;  // (two chunks of eight rows in registers: twelve spill at NV = 30)
+    // (two chunks of eight rows in registers: twelve spill at NV = 30; an on-the-fly source delivers one
+    // FrameTask = six rows per chunk)
+    constexpr int RC = Src::kOnTheFly ? 6 : (S::RC < 8 ? S::RC : 8);
     static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
     double cur[RC], nxt[RC];
     double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
     auto request = [&](double (&dst)[RC], int r0, int rc) {
+      if constexpr (Src::kOnTheFly) {
+        double six[6];
+        terms->frame_rows(r0 / 6, six);
 #pragma unroll
-      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
+        for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? six[kk] : 0.0;
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
+      }
       if (li < rc) {
         const int k = r0 + li;
         pw = costb[k];
-        pe = eb[k];
+        if constexpr (Src::kOnTheFly) pe = terms->error(k);
+        else pe = eb[k];
         pg = a.row_gain[k];
         pl = a.row_lm[k];
       }
@@ -256,7 +279,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
       const int off = li - a.dtask_col0[t];
       if (off >= 0 && off < a.dtask_k[t]) {
         const int r = a.dtask_row0[t] + off;
-        const double w = costb[r], ev = eb[r], gn = a.row_gain[r], l = a.row_lm[r];
+        const double w = costb[r], gn = a.row_gain[r], l = a.row_lm[r];
+        double ev;
+        if constexpr (Src::kOnTheFly) ev = terms->diag_error(r);
+        else ev = eb[r];
         const double wa = w * w;
         dadd += wa;
         ci += gn * wa * ev;
@@ -450,8 +476,14 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   }
 
   // ------------------------------------------------------------------ Goldfarb-Idnani, flat
-  const double lbv = in ? a.lb[b * (long long)nv + li] : -INF;
-  const double ubv = in ? a.ub[b * (long long)nv + li] : INF;
+  double lbv, ubv;
+  if constexpr (Src::kOnTheFly) {
+    lbv = in ? terms->lb : -INF;
+    ubv = in ? terms->ub : INF;
+  } else {
+    lbv = in ? a.lb[b * (long long)nv + li] : -INF;
+    ubv = in ? a.ub[b * (long long)nv + li] : INF;
+  }
   // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension (nv dot
   // products of length nv per step) and so does the threshold; same rule as oracle/gi_oracle.c
   const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
@@ -838,6 +870,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block) 
   PINKHIP_TICK(11);  // exit
 
   // ------------------------------------------------------------------ write-out
+  if constexpr (Src::kOnTheFly) {
+    terms->x = in ? x : 0.0;
+    terms->status = status;
+  }
   if (valid) {
     if (in) a.dq[b * (long long)nv + li] = x;
     if (li == 0) {

@@ -211,8 +211,18 @@ __device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj 
 //      by -Jlog6 and written straight into the rows of the packed task Jacobian.
 // FUSED = true moves 8 (nq + 12 nf + nf (6 + 6 nv)) bytes per instance instead of 8 (nq + 12 nf + 6 nf nv)
 // written by the FK launch and 8 nf (24 + 12 nv + 6) re-read and written by nf frame-task launches.
-template <int W, bool FUSED = false, bool STEP = false>
-__device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
+// Where the fused results go.  HbmSink (default): e / J rows / lb / ub into the packed streams in HBM.  A sink
+// with kKeep = true (ik_rollout.h) keeps them on chip for the solve that follows in the same kernel: the frame
+// errors in LDS (es), the column's world twist + ancestor bits + box + posture error in its members.
+struct HbmSink {
+  static constexpr bool kKeep = false;
+  double *es = nullptr;
+  double lin[3], ang[3], lb, ub, post_e;
+  unsigned anc;
+};
+
+template <int W, bool FUSED = false, bool STEP = false, class Sink = HbmSink>
+__device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *sink = nullptr, double *lds = nullptr) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.m;
   const int lane = lane_id();
@@ -220,7 +230,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
   long long b = block * G + g;
   const bool valid = b < a.B;
   if (!valid) b = a.B - 1;
-  double *oM = shared_base() + (long long)g * fk_lds_doubles(m.nj, m.nf);
+  double *oM = lds ? lds : shared_base() + (long long)g * fk_lds_doubles(m.nj, m.nf);
   double *fMo = oM + 12 * m.nj;  // frame-from-world transforms
   int *anc = reinterpret_cast<int *>(fMo + 12 * m.nf);
   double *Jls = fMo + 12 * m.nf + ((m.nj + 1) & ~1);
@@ -346,7 +356,10 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
       {
         double xi[6];
         log6_from_log3(w, th, p1, xi);  // e = log6(T_frame^-1 T_target), frame_task.py:181-193
-        if (valid) {
+        if constexpr (Sink::kKeep) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) sink->es[6 * f + i] = xi[i];
+        } else if (valid) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) a.e_out[b * a.sE + 6 * f + i] = xi[i];
         }
@@ -406,7 +419,15 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
         lin[0] = u[0], lin[1] = u[1], lin[2] = u[2];
         ang[0] = ang[1] = ang[2] = 0.0;
       }
-      for (int f = 0; f < m.nf; ++f) {
+      if constexpr (Sink::kKeep) {  // the rows are formed during the stacking of the solve (W >= nv: one column per lane)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          sink->lin[i] = lin[i];
+          sink->ang[i] = ang[i];
+        }
+        sink->anc = pf_anc;
+      }
+      for (int f = 0; f < (Sink::kKeep ? 0 : m.nf); ++f) {
         const bool on = (first && f < 32) ? ((pf_anc >> f) & 1u) != 0 : m.anc[f * m.nj + jt] != 0;
         const double *UV = Jls + 36 * f;
         double *Jo = a.J_out + b * a.sJo + (long long)(6 * f) * m.nv;
@@ -426,7 +447,15 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block) {
       const double qi = qs[jt];
       double lo, hi;
       coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
-      if (valid) {
+      if constexpr (Sink::kKeep) {
+        sink->lb = lo;
+        sink->ub = hi;
+        sink->post_e = 0.0;
+        if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {
+          const int iq = m.idx_q[jt];
+          sink->post_e = qi - (a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq]);
+        }
+      } else if (valid) {
         a.lb[b * m.nv + j] = lo;
         a.ub[b * m.nv + j] = hi;
         if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {  // posture_task.py:100-107: q (-) q*
@@ -576,9 +605,11 @@ __device__ inline void ik_limits_posture_thread(const LimitsPostureArgs &a, long
   a.ub[b * m.nv + j] = hi;
 }
 
+#ifndef PINKHIP_NO_ELEMENTWISE_KERNELS  // (non-template kernels: defined by the host translation unit only)
 __global__ void __launch_bounds__(256) ik_limits_posture_kernel(LimitsPostureArgs a) {
   ik_limits_posture_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
+#endif
 
 struct IntegrateArgs {
   ModelDev m;
@@ -606,8 +637,10 @@ __device__ inline void ik_integrate_thread(const IntegrateArgs &a, long long t) 
   integrate_joint(m, j, a.q + b * m.nq + m.idx_q[j], a.dq + b * m.nv + m.idx_v[j]);
 }
 
+#ifndef PINKHIP_NO_ELEMENTWISE_KERNELS
 __global__ void __launch_bounds__(256) ik_integrate_kernel(IntegrateArgs a) {
   ik_integrate_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
+#endif
 
 }  // namespace pinkhip

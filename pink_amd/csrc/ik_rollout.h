@@ -1,0 +1,107 @@
+// One kernel per control step: forward kinematics, FrameTask rows, limits, posture error, stacking, QP solve and
+// integration for 64/W robots per wavefront -- what the reference does per robot and per step with Pinocchio +
+// NumPy + quadprog (pink/solve_ik.py:206-275 followed by configuration.integrate_inplace,
+// examples/inverse_kinematics_ur10.py:75-91).
+//
+// The task Jacobians never exist in memory: the kinematics phase (ik_kinematics.h) leaves, per robot, the world
+// twist of each tangent column in that column's lane and two 3 x 3 blocks per FrameTask in LDS; the stacking of
+// the solve kernel (ik_kernels_packed.h, source policy FkTerms) forms its six rows per task from them with 27
+// FMAs per lane.  Against the two-launch loop (ik_step_kernel writes J, e, lb, ub; ik_solve_packed_kernel reads
+// them back) a step moves ~0.3 kB per robot through HBM instead of ~14 kB.  The kinematics scratch overlays the
+// LDS region of the active-set iteration (dead until stacking is done), so the footprint is the solve kernel's.
+#pragma once
+
+#include "ik_kernels_packed.h"
+#include "ik_kinematics.h"
+
+namespace pinkhip {
+
+struct RolloutArgs {
+  KernelArgs k;  // task tables, cost, damping, dt, B, nv, Kd = 6 nf, K; outputs dq / status / iters; J, e, lb, ub unused
+  FkArgs fk;     // model, q, targets, limit gain, posture target; T_frames optional; e / J / lb / ub outputs unused
+  int integrate;       // apply dq to q at the end of the step (instances whose solve failed keep their q)
+  int *first_failure;  // [B] sticky status | (step << 8), may be NULL
+  int step;
+};
+
+// doubles of kinematics scratch per robot: joint poses, ancestor pointers, U / V blocks, frame errors, joint scalars
+__device__ __host__ inline int rollout_fk_doubles(int nj, int nf) { return fk_lds_doubles(nj, nf) + 6 * nf; }
+
+template <int W>
+struct FkTerms {
+  static constexpr bool kOnTheFly = true;
+  static constexpr bool kKeep = true;
+  double lb = 0.0, ub = 0.0, x = 0.0;
+  int status = 0;
+  double lin[3], ang[3], post_e = 0.0;
+  unsigned anc = 0;
+  double *es = nullptr;        // LDS: frame-task errors [6 nf]
+  const double *UV = nullptr;  // LDS: U (9), V (9) per frame, pitch 36
+  // this lane's entries (tangent column li) of the six rows of FrameTask f
+  __device__ __forceinline__ void frame_rows(int f, double (&six)[6]) const {
+    const double *u = UV + 36 * f;
+    const bool on = ((anc >> f) & 1u) != 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double top = u[3 * i] * lin[0] + u[3 * i + 1] * lin[1] + u[3 * i + 2] * lin[2] + u[9 + 3 * i] * ang[0] +
+                         u[9 + 3 * i + 1] * ang[1] + u[9 + 3 * i + 2] * ang[2];
+      const double bot = u[3 * i] * ang[0] + u[3 * i + 1] * ang[1] + u[3 * i + 2] * ang[2];
+      six[i] = on ? -top : 0.0;
+      six[i + 3] = on ? -bot : 0.0;
+    }
+  }
+  __device__ __forceinline__ double error(int k) const { return es[k]; }
+  __device__ __forceinline__ double diag_error(int) const { return post_e; }
+};
+
+template <int NV, int W>
+__device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block) {
+  using S = LdsP<NV>;
+  constexpr int G = kWave / W;
+  const ModelDev &m = a.fk.m;
+  const int lane = lane_id();
+  const int g = lane / W, li = lane & (W - 1);
+  long long b = block * G + g;
+  const bool valid = b < a.k.B;
+  if (!valid) b = a.k.B - 1;
+  // kinematics scratch inside this robot's share of the solve kernel's LDS (host checks that it fits)
+  double *sm = shared_base() + (long long)g * S::stride(0);
+  FkTerms<W> t;
+  t.es = sm + fk_lds_doubles(m.nj, m.nf);
+  t.UV = sm + 12 * (m.nj + m.nf) + ((m.nj + 1) & ~1);  // = Jls of ik_fk_instance
+  ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
+  wave_sync();
+  ik_packed_instance<NV, W, false, FkTerms<W>>(a.k, block, &t);
+  // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
+  const int st = t.status;  // group-uniform
+  const bool isj = li < m.nj;
+  const int jl = isj ? li : 0;
+  const int iv = m.idx_v[jl], iq = m.idx_q[jl];
+  const bool ff = m.jtype[jl] == JOINT_FREE_FLYER;
+  double v[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[i] = lane_shfl(t.x, g * W + ((i == 0 || ff) ? (iv + i) & (W - 1) : iv & (W - 1)));
+  if (a.integrate) {
+    if (st == 0) {
+      if (valid && isj) {
+        double *qw = a.fk.q_rw + b * (long long)m.nq + iq;
+        double qj[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) qj[i] = (i == 0 || ff) ? qw[i] : 0.0;
+        integrate_joint(m, jl, qj, v);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+          if (i == 0 || ff) qw[i] = qj[i];
+      }
+    } else if (valid && li == 0 && a.first_failure && a.first_failure[b] == 0) {
+      a.first_failure[b] = st | (a.step << 8);
+    }
+  }
+}
+
+template <int NV, int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV) ik_rollout_kernel(RolloutArgs a) {
+  ik_rollout_instance<NV, W>(a, block_id());
+}
+
+}  // namespace pinkhip

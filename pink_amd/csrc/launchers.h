@@ -7,6 +7,8 @@
 
 #define PINKHIP_PASTE5(a, b, c, d, e) a##b##_##c##_##d##e
 #define PINKHIP_LAUNCH_PACKED_NAME(NV, W, D) PINKHIP_PASTE5(launch_packed_, NV, W, D, )
+#define PINKHIP_PASTE4(a, b, c) a##b##_##c
+#define PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W) PINKHIP_PASTE4(launch_rollout_, NV, W)
 
 namespace pinkhip {
 
@@ -14,6 +16,12 @@ namespace pinkhip {
   hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(hipStream_t stream, const KernelArgs &a);     \
   hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 1)(hipStream_t stream, const KernelArgs &a);
 PINKHIP_PACKED_TABLE(PINKHIP_DECLARE)
+#undef PINKHIP_DECLARE
+
+// tu_rollout.hip: the whole-control-step kernel, one launcher per entry of PINKHIP_ROLLOUT_TABLE
+struct RolloutArgs;
+#define PINKHIP_DECLARE(NV, W) hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W)(hipStream_t stream, const RolloutArgs &a);
+PINKHIP_ROLLOUT_TABLE(PINKHIP_DECLARE)
 #undef PINKHIP_DECLARE
 
 

@@ -20,6 +20,7 @@
 #include "ik_stack_mfma.h"
 #include "ik_frame_task.h"
 #include "ik_kinematics.h"
+#include "ik_rollout.h"
 #include "host_tables.h"
 #include "model_tables.h"
 // clang-format on
@@ -686,6 +687,58 @@ int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, co
     hipLaunchKernelGGL(pinkhip::ik_step_kernel<64>, dim3((unsigned)B), block, 8 * per + 16, h->stream, a);
   }
   PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *m,
+                                const pinkhip_rollout_step *st) {
+  if (!h || !m || !st) return fail(h, PINKHIP_E_INVALID, "null handle / model / args");
+  pinkhip::RolloutArgs ra{};
+  int rc = prepare(h, desc, ra.k);
+  if (rc) return rc;
+  const pinkhip::ModelDev &md = m->dev;
+  if (desc->B == 0) return PINKHIP_OK;
+  if (desc->nv != md.nv || desc->Kd != 6 * md.nf || desc->md != 0 || desc->n_eq != 0)
+    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, Kd = 6 nf, md = 0)");
+  const int n_post = desc->K - desc->Kd;
+  if (desc->T != md.nf + (n_post ? 1 : 0)) return fail(h, PINKHIP_E_INVALID, "expected one dense task per frame (+ one diagonal task)");
+  for (int t = 0; t < md.nf; ++t)
+    if (desc->task_kind[t] != PINKHIP_TASK_DENSE || desc->task_rows[t + 1] - desc->task_rows[t] != 6)
+      return fail(h, PINKHIP_E_INVALID, "frame tasks must be dense with six rows each");
+  if (n_post && (desc->task_kind[md.nf] != PINKHIP_TASK_DIAGONAL || desc->task_col0[md.nf] != md.root_nv || n_post != md.nv - md.root_nv))
+    return fail(h, PINKHIP_E_INVALID, "the diagonal task must cover the actuated coordinates");
+  if (!st->q || !st->cost || !st->dq || !st->status || (md.nf > 0 && !st->T_target) || (n_post && !st->q_target))
+    return fail(h, PINKHIP_E_INVALID, "null pointer");
+  if (!(st->config_limit_gain > 0.0 && st->config_limit_gain <= 1.0) || st->step < 0 || st->step >= (1 << 23))
+    return fail(h, PINKHIP_E_INVALID, "bad limit gain / step");
+  const pinkhip::PackedChoice pc = pinkhip::select_rollout(md.nv, md.nj, pinkhip::rollout_fk_doubles(md.nj, md.nf));
+  if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
+  ra.k.cost = st->cost;
+  ra.k.dq = st->dq;
+  ra.k.status = st->status;
+  ra.k.iters = st->iters;
+  pinkhip::FkArgs &f = ra.fk;
+  f.m = md;
+  f.B = desc->B;
+  f.q = st->q;
+  f.q_rw = st->q;
+  f.T_frames = st->T_frames;
+  f.T_target = st->T_target;
+  f.dt = desc->dt;
+  f.config_limit_gain = st->config_limit_gain;
+  f.q_target = n_post ? st->q_target : nullptr;
+  f.target_batched = st->target_batched;
+  ra.integrate = st->integrate;
+  ra.first_failure = st->first_failure;
+  ra.step = st->step;
+  hipError_t e = hipErrorInvalidValue;
+  switch (pc.NV) {
+#define PINKHIP_CASE(NV, W) \
+  case NV: e = pinkhip::PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W)(h->stream, ra); break;
+    PINKHIP_ROLLOUT_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+  }
+  PH_HIP(h, e);
   return PINKHIP_OK;
 }
 

@@ -1,0 +1,26 @@
+// One translation unit per instantiation of the whole-control-step kernel (ik_rollout.h): compiled with
+//   -DPINKHIP_TU_NV=<NV> -DPINKHIP_TU_W=<W>       (Makefile, ROLLOUT list)
+#include <hip/hip_runtime.h>
+
+// clang-format off
+#define PINKHIP_NO_ELEMENTWISE_KERNELS
+#include "wave.h"
+#include "ik_rollout.h"
+#include "launchers.h"
+// clang-format on
+
+#if !defined(PINKHIP_TU_NV) || !defined(PINKHIP_TU_W)
+#error "tu_rollout.hip is compiled once per (NV, W): see the Makefile"
+#endif
+
+namespace pinkhip {
+
+hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(PINKHIP_TU_NV, PINKHIP_TU_W)(hipStream_t stream, const RolloutArgs &a) {
+  constexpr int NV = PINKHIP_TU_NV, W = PINKHIP_TU_W, G = kWave / W;
+  const size_t lds = static_cast<size_t>(LdsP<NV>::bytes(0, G));
+  const dim3 grid(static_cast<unsigned>((a.k.B + G - 1) / G)), block(kWave);
+  hipLaunchKernelGGL((ik_rollout_kernel<NV, W>), grid, block, lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace pinkhip

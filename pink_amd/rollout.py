@@ -9,7 +9,9 @@ step as a HIP kernel, with no host round trip between steps:
     box limits, PostureTask error            pinkhip_step_device (ONE launch)
     stack + QP solve                         pinkhip_solve_device
 
-i.e. two launches per control step (``fused=False`` keeps the five separate ones: pinkhip_fk_device, one
+i.e. two launches per control step; with ``fused="kernel"`` the two become ONE
+(``pinkhip_rollout_step_device``: the task Jacobians are formed on chip while the objective is stacked and never
+reach HBM; the integration closes the same launch).  ``fused=False`` keeps the five separate launches: pinkhip_fk_device, one
 pinkhip_frame_task_strided_device per task, pinkhip_limits_posture_device, pinkhip_solve_device,
 pinkhip_integrate_checked_device -- kept for A/B runs and as a cross-check of the fusion).
 
@@ -24,7 +26,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import Desc, Problem, Result, Step, c_double_p, c_int32_p
+from ._lib import Desc, Problem, Result, RolloutStep, Step, c_double_p, c_int32_p
 from .configuration import Model
 from .exceptions import NoSolutionFound, NotWithinConfigurationLimits
 from .utils import get_root_joint_dim
@@ -113,7 +115,8 @@ class DeviceRollout:
                  fused: bool = True, safety_break: bool = True):
         self.api, self.model, self.dt = api, model, float(dt)
         self._check_limits(model, np.asarray(q0, dtype=np.float64), safety_break)
-        self.fused = bool(fused)  # FK + FrameTask rows in one launch (False: FK, then one launch per task)
+        # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
+        self.fused = fused if fused == "kernel" else bool(fused)
         self.B = B = int(q0.shape[0])
         self.nv, self.nq = model.nv, model.nq
         self.frames = [ft[0] for ft in frame_tasks]
@@ -189,7 +192,11 @@ class DeviceRollout:
     def step(self) -> None:
         """Enqueue one IK step for every robot (asynchronous)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
-        if self.fused:
+        if self.fused == "kernel" and not self._one_kernel_step():
+            self.fused = True  # no instantiation for this model: two launches from now on
+        if self.fused == "kernel":
+            pass
+        elif self.fused:
             # one launch applies the previous step's dq (status-checked), then FK, frame-task rows, limits, posture
             st = Step()
             st.q = self.d_q
@@ -215,6 +222,16 @@ class DeviceRollout:
             a.solve_raw(self.desc, self.problem, self.result)
             a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
         self.steps_done += 1
+
+    def _one_kernel_step(self) -> bool:
+        """FK + FrameTask rows + limits + posture + stack + solve + integrate in one launch."""
+        st = RolloutStep()
+        st.q, st.cost, st.T_target, st.T_frames = self.d_q, self.d_cost, self.d_Tt, self.d_T
+        st.q_target = self.d_qt if self.n_post else None
+        st.dq, st.status, st.iters, st.first_failure = self.d_dq, self.d_status, self.d_iters, self.d_fail
+        st.config_limit_gain = self.config_limit_gain
+        st.target_batched, st.step, st.integrate = 1, self.steps_done, 1
+        return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def flush(self) -> None:
         """Apply the displacement of the last enqueued step (the whole-step kernel integrates lazily, at the

@@ -22,22 +22,25 @@ for label, model, frames in [c for c in cases if not only or c[0] == only]:
             q0[:, j.idx_q] = rng.uniform(-0.8, 0.8, size=B)
     cfg = Configuration(model, q0[0])
     specs = [(f, 1.0, 1.0 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
-    ro = DeviceRollout(s, model, q0, specs, 5e-3, posture_cost=1e-1)
-    # targets: each robot's own initial frame poses displaced by a few centimetres
-    ro.step(); s.sync()
-    T = ro.frame_poses()
-    T[:, :, 9:12] += 0.05 * rng.normal(size=(B, len(frames), 3))
-    ro.set_targets(T)
-    ro.run(5)
-    steps = 50
-    s.timer_start()
-    for _ in range(steps):
-        ro.step()
-    ms = s.timer_stop() / steps
-    _, st, it = ro.last_step()
-    print(f"{label}: nv={model.nv} B={B}: {ms:.3f} ms per closed-loop step -> {B/ms/1e3:.1f} M robot-steps/s; failed={(st!=0).sum()} qp iters mean {it.mean():.2f}")
-    out[label] = dict(nv=model.nv, B=B, ms_per_step=ms, robot_steps_per_s=B / (ms * 1e-3), qp_iters_mean=float(it.mean()), failed=int((st != 0).sum()),
-                      frame_tasks=len(frames))
-    ro.free()
+    T = None
+    for mode in ("kernel", True):  # the whole step in one kernel / step kernel + solve
+        ro = DeviceRollout(s, model, q0, specs, 5e-3, posture_cost=1e-1, fused=mode)
+        if T is None:  # targets: each robot's own initial frame poses displaced by a few centimetres
+            ro.step(); s.sync()
+            T = ro.frame_poses()
+            T[:, :, 9:12] += 0.05 * rng.normal(size=(B, len(frames), 3))
+        ro.set_targets(T)
+        ro.run(5)
+        steps = 50
+        s.timer_start()
+        for _ in range(steps):
+            ro.step()
+        ms = s.timer_stop() / steps
+        _, st, it = ro.last_step()
+        name = label + ("_one_kernel" if ro.fused == "kernel" else "_two_launches")
+        print(f"{name}: nv={model.nv} B={B}: {ms:.3f} ms per closed-loop step -> {B/ms/1e3:.1f} M robot-steps/s; failed={(st!=0).sum()} qp iters mean {it.mean():.2f}")
+        out[name] = dict(nv=model.nv, B=B, ms_per_step=ms, robot_steps_per_s=B / (ms * 1e-3), qp_iters_mean=float(it.mean()),
+                         failed=int((st != 0).sum()), frame_tasks=len(frames), launches_per_step=1 if ro.fused == "kernel" else 2)
+        ro.free()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "rollout_bench.json"), "w"), indent=1)

@@ -123,6 +123,17 @@ class EmuSolver:
         self.lib.pinkhip_emu_step.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(Step)]
         self.lib.pinkhip_emu_step(model, B, ctypes.byref(args))
 
+    def rollout_step(self, desc, model, args):
+        from pink_amd._lib import Desc, RolloutStep
+
+        self.lib.pinkhip_emu_rollout_step.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.POINTER(RolloutStep)]
+        rc = self.lib.pinkhip_emu_rollout_step(ctypes.byref(desc), model, ctypes.byref(args))
+        if rc == -5:
+            return False
+        if rc != 0:
+            raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
+        return True
+
     def frame_task_strided(self, B, nv, Tf, sTf, Tt, sTt, Jb, sJb, e, sE, J, sJ):
         vp, ll = ctypes.c_void_p, ctypes.c_longlong
         self.lib.pinkhip_emu_frame_task_strided.argtypes = [ll, ctypes.c_int, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll]

@@ -9,6 +9,7 @@
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/ik_frame_task.h"
 #include "../../pink_amd/csrc/ik_kinematics.h"
+#include "../../pink_amd/csrc/ik_rollout.h"
 #include "../../pink_amd/csrc/model_tables.h"
 #include "../../pink_amd/csrc/host_tables.h"
 // clang-format on
@@ -137,6 +138,11 @@ void lane_main_step(void *p) {
   pinkhip::ik_fk_instance<W, true, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
 }
 
+template <int NV, int W>
+void lane_main_rollout(void *p) {
+  pinkhip::ik_rollout_instance<NV, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
+}
+
 struct EmuModel {
   pinkhip::ModelImage image;
   pinkhip::ModelDev dev;
@@ -219,6 +225,67 @@ int pinkhip_emu_step(void *mp, long long B, const pinkhip_step *st) {
   } else {
     for (long long b = 0; b < B; ++b) pinkhip::emu_run_block(b, lane_main_step<64>, &a);
   }
+  return PINKHIP_OK;
+}
+int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_rollout_step *st) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  pinkhip::HostTables t;
+  g_err = pinkhip::build_tables(*d, t);
+  if (!g_err.empty()) return PINKHIP_E_INVALID;
+  pinkhip::RolloutArgs ra{};
+  KernelArgs &a = ra.k;
+  a.B = d->B;
+  a.nv = d->nv;
+  a.Kd = d->Kd;
+  a.K = d->K;
+  a.md = 0;
+  a.n_dtasks = static_cast<int>(t.dtask_k.size());
+  a.cost_batched = d->cost_is_batched;
+  a.max_iter = d->max_iter;
+  a.damping = d->damping;
+  a.dt = d->dt;
+  a.cost = st->cost;
+  a.row_gain = t.row_gain.data();
+  a.row_lm = t.row_lm.data();
+  a.dtask_col0 = t.dtask_col0.data();
+  a.dtask_row0 = t.dtask_row0.data();
+  a.dtask_k = t.dtask_k.data();
+  a.barrier_rows = t.barrier_rows.data();
+  a.barrier_safe_gain = t.barrier_safe_gain.data();
+  a.dq = st->dq;
+  a.status = st->status;
+  a.iters = st->iters;
+  pinkhip::FkArgs &f = ra.fk;
+  f.m = m->dev;
+  f.B = d->B;
+  f.q = st->q;
+  f.q_rw = st->q;
+  f.T_frames = st->T_frames;
+  f.T_target = st->T_target;
+  f.dt = d->dt;
+  f.config_limit_gain = st->config_limit_gain;
+  f.q_target = (d->K > d->Kd) ? st->q_target : nullptr;
+  f.target_batched = st->target_batched;
+  ra.integrate = st->integrate;
+  ra.first_failure = st->first_failure;
+  ra.step = st->step;
+  const pinkhip::PackedChoice pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
+  pinkhip::LaneFn fn = nullptr;
+  long long blocks = 0;
+  switch (pc.NV) {
+#define PINKHIP_CASE(NV, W)                  \
+  case NV:                                   \
+    fn = lane_main_rollout<NV, W>;           \
+    blocks = (d->B + 64 / W - 1) / (64 / W); \
+    break;
+    PINKHIP_ROLLOUT_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+  }
+  if (!fn || m->dev.nf > 32) {
+    g_err = "no whole-step instantiation fits this model";
+    return PINKHIP_E_UNSUPPORTED;
+  }
+  for (long long b = 0; b < blocks; ++b) pinkhip::emu_run_block(b, fn, &ra);
   return PINKHIP_OK;
 }
 int pinkhip_emu_limits_posture(void *mp, long long B, double dt, double gain, const double *q,

@@ -77,9 +77,14 @@ def test_makefile_builds_every_instantiation_of_the_dispatch_table():
     import re
 
     csrc = os.path.join(ROOT, "pink_amd", "csrc")
-    table = re.search(r"#else\n#define PINKHIP_PACKED_TABLE\(X\)(.*?)#endif", open(os.path.join(csrc, "dispatch.h")).read(), re.S).group(1)
+    table = re.search(r"#define PINKHIP_PACKED_TABLE\(X\)\s*\\\n(.*?)#endif", open(os.path.join(csrc, "dispatch.h")).read(), re.S).group(1)
     pairs = re.findall(r"X\((\d+), (\d+)\)", table)
     packed = re.search(r"^PACKED\s*:=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
     assert packed == [f"{nv}_{w}" for nv, w in pairs] and len(pairs) >= 11
     for nv, w in pairs:
         assert int(w) >= int(nv) and int(nv) % 2 == 0 and 64 % int(w) == 0
+    # the whole-control-step kernel: a subset of the table (groups of whole 16-lane rows), one unit each
+    rt = re.search(r"#define PINKHIP_ROLLOUT_TABLE\(X\) (X\(12.*)$", open(os.path.join(csrc, "dispatch.h")).read(), re.M).group(1)
+    rpairs = re.findall(r"X\((\d+), (\d+)\)", rt)
+    rollout = re.search(r"^ROLLOUT\s*:=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
+    assert rollout == [f"{nv}_{w}" for nv, w in rpairs] and set(rpairs) <= set(pairs) and all(int(w) >= 16 for _, w in rpairs)

@@ -133,9 +133,11 @@ def test_fk_and_integrate_against_the_independent_oracle(api):
         api.model_destroy(dm)
 
 
+@pytest.mark.parametrize("fused", [True, "kernel"])
 @pytest.mark.parametrize("which", [0, 1])
-def test_closed_loop_matches_host_loop_and_converges(api, which):
-    """tests/test_solve_ik.py:160-210 / examples/inverse_kinematics_ur10.py:75-91, batched."""
+def test_closed_loop_matches_host_loop_and_converges(api, which, fused):
+    """tests/test_solve_ik.py:160-210 / examples/inverse_kinematics_ur10.py:75-91, batched; with two launches per
+    step (step kernel + solve) and with the whole step in one kernel."""
     model, frames = _models()[which]
     rng = np.random.default_rng(10 + which)
     B, dt, steps = 4, 5e-3, 40
@@ -158,9 +160,10 @@ def test_closed_loop_matches_host_loop_and_converges(api, which):
         p.set_target(q0[b])
         tl.append(p)
         host_tasks.append(tl)
-    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-2)
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-2, fused=fused)
     ro.set_targets(targets)
     ro.run(steps)
+    assert ro.fused == fused  # the one-kernel step exists for both test models
     qd = ro.configurations()
     _, st, _ = ro.last_step()
     assert (st == 0).all()
@@ -219,7 +222,8 @@ def test_fused_fk_frame_tasks_equal_separate_launches(api, which):
             assert np.abs(t.compute_jacobian(cfg) - rows[0][1][b, 6 * i:6 * i + 6]).max() < 1e-9
 
 
-def test_failed_solves_are_not_integrated_and_stay_visible(api):
+@pytest.mark.parametrize("mode", [True, "kernel"])
+def test_failed_solves_are_not_integrated_and_stay_visible(api, mode):
     """A robot whose QP fails (here: iteration cap of one active-set step) must keep its configuration -- the
     reference raises NoSolutionFound before integrating (pink/solve_ik.py:271-275) -- and the failure must
     survive later steps (first failure is sticky); run() raises listing those robots."""
@@ -238,7 +242,7 @@ def test_failed_solves_are_not_integrated_and_stay_visible(api):
             # robots 3..5: target = current pose (no active constraint, solved without any step)
             far = SE3(np.eye(3), (2.0 if b < 3 else 0.0) * np.ones(3))
             targets[b, i] = pose12(cfg.get_transform_frame_to_world(f) * far)
-    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=None, max_iter=1)
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=None, max_iter=1, fused=mode)
     ro.set_targets(targets)
     with pytest.raises(NoSolutionFound) as info:
         ro.run(3)
@@ -257,3 +261,38 @@ def test_failed_solves_are_not_integrated_and_stay_visible(api):
     with pytest.raises(NotWithinConfigurationLimits) as lim:
         DeviceRollout(api, model, bad, specs, dt)
     assert lim.value.instance == 2 and lim.value.joint == j
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_one_kernel_step_equals_two_launch_step(api, which):
+    """pinkhip_rollout_step_device forms the task rows on chip (world twists x per-frame blocks) instead of reading
+    them from HBM: after every step dq, status and the configurations must agree with the step-kernel + solve loop
+    to round-off (the rows are the same numbers computed in a different order)."""
+    model, frames = _models()[which]
+    rng = np.random.default_rng(50 + which)
+    B = 5
+    q0 = _random_q(model, B, rng) * 0.6 + 0.4 * np.tile(model.neutral(), (B, 1))
+    if which == 1:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    specs = [(f, 1.0, 0.5, 0.9, 1e-3) for f in frames]
+    targets = np.zeros((B, len(frames), 12))
+    for b in range(B):
+        cfg = Configuration(model, q0[b])
+        for i, f in enumerate(frames):
+            targets[b, i] = pose12(cfg.get_transform_frame_to_world(f) * SE3(exp3(0.3 * rng.normal(size=3)), 0.08 * rng.normal(size=3)))
+    runs = {}
+    for mode in (True, "kernel"):
+        ro = DeviceRollout(api, model, q0, specs, 5e-3, posture_cost=5e-2, fused=mode)
+        ro.set_targets(targets)
+        hist = []
+        for _ in range(6):
+            ro.step()
+            api.sync()
+            dq, st, it = ro.last_step()
+            hist.append((dq.copy(), st.copy(), ro.configurations().copy()))
+        assert ro.fused == mode
+        runs[mode] = hist
+        ro.free()
+    for (dq_a, st_a, q_a), (dq_b, st_b, q_b) in zip(runs[True], runs["kernel"]):
+        assert np.array_equal(st_a, st_b) and (st_a == 0).all()
+        assert np.abs(dq_a - dq_b).max() < 1e-11 and np.abs(q_a - q_b).max() < 1e-11
