@@ -36,6 +36,9 @@ inline PackedChoice select_packed(int nv, int md) {
 // kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the scratch
 // must fit the solve kernel's own LDS share (doubles per QP of LdsP<NV>::stride(0) = NV (NV + 3) / 2 + 4 NV, even).
 inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
+  // robots that fit an 8-lane group keep the two-launch step: padding them to 16 lanes halves the robots per
+  // wavefront (measured, 6-dof arm: 0.107 ms in one kernel at NV = 12 against 0.068 ms in two launches at NV = 6)
+  if (nv <= 8) return PackedChoice{0, 0};
 #define PINKHIP_PICK(NV_, W_)                                                                       \
   if (nv <= NV_ && nj <= W_ && fk_doubles <= ((((NV_ * (NV_ + 3) / 2 + 1) & ~1) + 4 * NV_ + 1) & ~1)) \
     return PackedChoice{NV_, W_};
