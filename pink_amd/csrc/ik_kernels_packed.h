@@ -517,24 +517,42 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       if (md > 0) {
         if (li < NV) xs[li] = x;
         wave_sync();
-        if (li < md) {
-          // slack of dense row li: eight entries of the row and of x per LDS round trip (columns nv..NV-1 of
-          // the staged rows are zero, x is zero there as well)
-          double s = hv;
-          const double *gr = Gs + li * GP;
+        // slacks h_i - g_i x of the dense rows.  Up to W / 8 rows: eight lanes per row, each sums every eighth
+        // column, three DPP steps fold the eight partial sums and row i's total is handed to lane i (1 + NV / 8
+        // dependent LDS reads per lane instead of NV on md lanes); more rows: one lane per row, eight entries of
+        // the row and of x per LDS round trip.  (Columns nv..NV-1 of the staged rows and of x are zero.)
+        double gx = 0.0;
+        if (md * 8 <= W) {
+          const int row = li >> 3, seg = li & 7;
+          const double *gr = Gs + (row < md ? row : 0) * GP;
+          double part = 0.0;
 #pragma unroll
           for (int j0 = 0; j0 < NV; j0 += 8) {
-            if (j0 < nv) {
-              double gv[8], xv[8];
+            const int j = j0 + seg;  // NV is a multiple of two, not of eight: the last block is partial
+            if (j0 + 8 <= NV || j < NV) part += gr[j < NV ? j : 0] * xs[j < NV ? j : 0];
+          }
+          if (row >= md) part = 0.0;
+          part = group_sum<8>(part);
+          gx = group_bcast<W>(part, (li < md ? li : 0) << 3);
+        }
+        if (li < md) {
+          double s = hv - gx;
+          if (md * 8 > W) {
+            const double *gr = Gs + li * GP;
 #pragma unroll
-              for (int m = 0; m < 8; ++m) {
-                gv[m] = (j0 + m < NV) ? gr[j0 + m] : 0.0;
-                xv[m] = (j0 + m < NV) ? xs[j0 + m] : 0.0;
+            for (int j0 = 0; j0 < NV; j0 += 8) {
+              if (j0 < nv) {
+                double gv[8], xv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                  gv[m] = (j0 + m < NV) ? gr[j0 + m] : 0.0;
+                  xv[m] = (j0 + m < NV) ? xs[j0 + m] : 0.0;
+                }
+                pin16(gv, xv);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) s -= gv[m] * xv[m];
+                pin(s);
               }
-              pin16(gv, xv);
-#pragma unroll
-              for (int m = 0; m < 8; ++m) s -= gv[m] * xv[m];
-              pin(s);
             }
           }
           sd = s;
