@@ -224,6 +224,45 @@ def measure_config(solver, name: str, B: int, steps: int, parity_sample: int, se
     }
 
 
+def api_level(solver, B: int = 4096) -> dict:
+    """`pink_amd.solve_ik_batch(configurations, tasks, dt)` -- the Python API of the drop-in -- on B configurations
+    of a 6-dof arm: with the kinematics evaluated by the device kernels from q (default for B >= 64) and with
+    tasks / limits evaluated per configuration on the host as Pink does (on a 256-configuration sample)."""
+    import pink_amd
+    from pink_amd import Configuration, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.lie import SE3
+    from pink_amd.runtime import set_default_solver
+
+    set_default_solver(solver)
+    try:
+        m = build_chain(6)
+        rng = np.random.default_rng(2)
+        cfgs, tasks = [], []
+        for _ in range(B):
+            q = m.neutral()
+            for j in m.joints:
+                q[j.idx_q] = rng.uniform(-0.9, 0.9)
+            cfg = Configuration(m, q)
+            t = FrameTask("tool0", 1.0, 1.0, lm_damping=1.0)
+            t.set_target(cfg.get_transform_frame_to_world("tool0") * SE3(np.eye(3), 0.05 * rng.normal(size=3)))
+            p = PostureTask(cost=1e-3)
+            p.set_target(m.neutral())
+            cfgs.append(cfg)
+            tasks.append([t, p])
+        dt = 1.0 / 200.0
+        v_dev = solve_ik_batch(cfgs, tasks, dt)
+        t_dev = statistics.median(_timed(lambda: solve_ik_batch(cfgs, tasks, dt), 3))
+        n = 256
+        v_host = solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False)
+        t_host = statistics.median(_timed(lambda: solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False), 3, warmup=0))
+        return {"workload": f"6-dof arm, FrameTask + PostureTask, {B} configurations, pink_amd {pink_amd.__version__}",
+                "device_kinematics": {"ms": t_dev * 1e3, "solves_per_s": B / t_dev},
+                "host_evaluated_tasks": {"ms_for_sample": t_host * 1e3, "sample": n, "solves_per_s": n / t_host},
+                "max_abs_velocity_difference_on_sample": float(np.abs(v_dev[:n] - v_host).max())}
+    finally:
+        set_default_solver(None)
+
+
 def traffic_from_profiles():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC pass -- reported only when that
     pass was collected on exactly these kernel sources (content hash), else null."""
@@ -404,6 +443,13 @@ def main() -> None:
                                       "host_call_median": statistics.median(tl) * 1e6, "host_call_p90": sorted(tl)[int(0.9 * len(tl))] * 1e6,
                                       "kernel_only": kernel_ms_of(solver, d1, 50) * 1e3}
             d1.free()
+
+            # Pink's own calling pattern, batched: solve_ik_batch on Configuration objects (BASELINE config 2's shape:
+            # 6-dof arm, 1 FrameTask + PostureTask, one target per instance)
+            try:
+                extra["api_solve_ik_batch"] = api_level(solver)
+            except Exception as exc:  # noqa: BLE001  never lose the bench line
+                extra["api_solve_ik_batch"] = {"failed": repr(exc)}
 
         total = global_batch * args.steps
         value = total / elapsed

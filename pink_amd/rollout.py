@@ -112,7 +112,7 @@ class DeviceRollout:
     def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
-                 fused: bool = True, safety_break: bool = True):
+                 fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0):
         self.api, self.model, self.dt = api, model, float(dt)
         self._check_limits(model, np.asarray(q0, dtype=np.float64), safety_break)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
@@ -133,7 +133,7 @@ class DeviceRollout:
         self.task_kind = np.ascontiguousarray([0] * nf + ([1] if n_post else []), dtype=np.int32)
         self.task_col0 = np.ascontiguousarray([0] * nf + ([root_nv] if n_post else []), dtype=np.int32)
         self.gain = np.ascontiguousarray([ft[3] for ft in frame_tasks] + ([posture_gain] if n_post else []), dtype=np.float64)
-        self.lm = np.ascontiguousarray([ft[4] for ft in frame_tasks] + ([0.0] if n_post else []), dtype=np.float64)
+        self.lm = np.ascontiguousarray([ft[4] for ft in frame_tasks] + ([posture_lm_damping] if n_post else []), dtype=np.float64)
         cost = []
         for ft in frame_tasks:
             cost += list(np.broadcast_to(np.asarray(ft[1], float), (3,))) + list(np.broadcast_to(np.asarray(ft[2], float), (3,)))
@@ -189,10 +189,11 @@ class DeviceRollout:
         t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, len(self.frames), 12)
         self.api.put(self.d_Tt, t)
 
-    def step(self) -> None:
-        """Enqueue one IK step for every robot (asynchronous)."""
+    def step(self, integrate: bool = True) -> None:
+        """Enqueue one IK step for every robot (asynchronous).  ``integrate=False`` only solves (dq, status and
+        iteration counts of ``last_step`` are those of the current configurations, which stay as they are)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
-        if self.fused == "kernel" and not self._one_kernel_step():
+        if self.fused == "kernel" and not self._one_kernel_step(integrate):
             self.fused = True  # no instantiation for this model: two launches from now on
         if self.fused == "kernel":
             pass
@@ -210,7 +211,7 @@ class DeviceRollout:
             st.lb, st.ub, st.e_off = self.d_lb, self.d_ub, self.Kd
             a.step_kernel(self.dmodel, B, st)
             a.solve_raw(self.desc, self.problem, self.result)
-            self._pending = True
+            self._pending = bool(integrate)
         else:  # one launch for FK, one per FrameTask, limits + posture, solve, integrate
             a.fk(self.dmodel, B, self.d_q, self.d_T, self.d_Jb)
             for t in range(nf):
@@ -220,17 +221,18 @@ class DeviceRollout:
             a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
                              self.d_e if self.n_post else None, self.K, self.Kd)
             a.solve_raw(self.desc, self.problem, self.result)
-            a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
+            if integrate:
+                a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
         self.steps_done += 1
 
-    def _one_kernel_step(self) -> bool:
+    def _one_kernel_step(self, integrate: bool = True) -> bool:
         """FK + FrameTask rows + limits + posture + stack + solve + integrate in one launch."""
         st = RolloutStep()
         st.q, st.cost, st.T_target, st.T_frames = self.d_q, self.d_cost, self.d_Tt, self.d_T
         st.q_target = self.d_qt if self.n_post else None
         st.dq, st.status, st.iters, st.first_failure = self.d_dq, self.d_status, self.d_iters, self.d_fail
         st.config_limit_gain = self.config_limit_gain
-        st.target_batched, st.step, st.integrate = 1, self.steps_done, 1
+        st.target_batched, st.step, st.integrate = 1, self.steps_done, int(integrate)
         return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def flush(self) -> None:

@@ -240,18 +240,100 @@ def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, da
                       dense_rows=dense_rows, barriers=barrier_terms, batch_size=B, equality_rows=equality_rows)
 
 
+def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints):
+    """``(model, frame task specs, target poses [B, nf, 12], posture task)`` when the whole batch can be evaluated on
+    the device from the configurations alone -- every task a FrameTask (one target per instance allowed) or one
+    PostureTask, the model's default limits, no barriers, no equality constraints, one model -- else ``None``."""
+    from .tasks.frame_task import FrameTask
+    from .tasks.posture_task import PostureTask
+
+    B = len(configurations)
+    if B == 0 or barriers or constraints or limits is not None:
+        return None
+    model = configurations[0].model
+    if any(c.model is not model for c in configurations) or getattr(model, "floating_base_velocity_limit", None) is not None:
+        return None
+    per_instance = len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    slots = [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))] if per_instance else [[t] * B for t in tasks]
+    specs, targets, posture = [], [], None
+    for col in slots:
+        t0 = col[0]
+        same = all(type(t) is type(t0) and t.gain == t0.gain and t.lm_damping == t0.lm_damping
+                   and np.array_equal(np.asarray(t.cost, dtype=float), np.asarray(t0.cost, dtype=float)) for t in col)
+        if not same:
+            return None
+        if type(t0) is FrameTask:
+            if any(t.frame != t0.frame or t.transform_target_to_world is None for t in col) or posture is not None:
+                return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
+            specs.append((t0.frame, np.asarray(t0.position_cost, float), np.asarray(t0.orientation_cost, float), t0.gain, t0.lm_damping))
+            targets.append(np.array([_pose12(t.transform_target_to_world) for t in col]))
+        elif type(t0) is PostureTask:
+            if posture is not None or any(t.target_q is None for t in col) or np.ndim(t0.cost) != 0:
+                return None
+            posture = col
+        else:
+            return None
+    if not specs:
+        return None
+    T = np.stack(targets, axis=1) if targets else np.zeros((B, 0, 12))
+    return model, specs, T, posture
+
+
+def _solve_on_device(plan, configurations, dt, damping, safety_break, solver_handle, max_iter):
+    """FK, task rows, limits and the QP for the whole batch in device kernels (one launch where the whole-step
+    kernel covers the model): the host only hands over ``q`` and the targets."""
+    from .rollout import DeviceRollout
+    from .runtime import default_solver
+
+    model, specs, T, posture = plan
+    api = solver_handle or default_solver()
+    q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
+    kw = {}
+    if posture is not None:
+        p0 = posture[0]
+        kw = dict(posture_cost=float(p0.cost), posture_gain=p0.gain, posture_lm_damping=p0.lm_damping,
+                  q_posture=np.stack([t.target_q for t in posture]))
+    ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
+                       max_iter=max_iter, fused="kernel", safety_break=safety_break, **kw)
+    try:
+        ro.set_targets(T)
+        ro.step(integrate=False)
+        api.sync()
+        return ro.last_step()
+    finally:
+        ro.free()
+
+
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
                    limits=None, barriers=None, constraints=None, safety_break: bool = True, solver_handle=None,
-                   **kwargs) -> np.ndarray:
+                   device_kinematics: Optional[bool] = None, **kwargs) -> np.ndarray:
     """Batched ``solve_ik``: velocities ``[B, nv]`` for ``B`` configurations.
 
     Raises :class:`NoSolutionFound` listing the failing instances (the batched
     analogue of ``pink/solve_ik.py:271-273``).
+
+    ``device_kinematics``: when the task stack is FrameTasks (+ one PostureTask) under the model's default limits,
+    forward kinematics, task errors / Jacobians and limits can be evaluated by the device kernels from ``q`` alone
+    instead of per configuration on the host (``None``: do so for batches of 64 and more; ``True``: require it).
     """
     if solver not in SOLVER_NAMES:
         raise PinkError(f"solver={solver!r}: this build only provides the MI355X solver {SOLVER_NAMES}")
     from .runtime import default_solver
 
+    plan = None
+    if device_kinematics or (device_kinematics is None and len(configurations) >= 64):
+        plan = _device_kinematics_plan(configurations, tasks, limits, barriers, constraints)
+        if plan is None and device_kinematics:
+            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask), default limits, no barriers / constraints")
+    if plan is not None:
+        from .batch_solver import BatchResult
+
+        dq, status, iters = _solve_on_device(plan, configurations, dt, damping, safety_break, solver_handle,
+                                             int(kwargs.get("max_iter", 0)))
+        if (status != 0).any():
+            result = BatchResult(dq, status, iters)
+            raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
+        return dq / dt
     for cfg in configurations:
         cfg.check_limits(safety_break=safety_break)
     batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, solver_handle,

@@ -403,3 +403,37 @@ def test_solve_ik_batch_ragged_dense_rows_safe_displacement_and_constraints(back
         J, e = hold.compute_jacobian(cfg), hold.compute_error(cfg)
         assert np.abs(J @ (Vc[b] * 5e-3) + hold.gain * e).max() < 1e-12
     assert np.abs(Vc).max() > 1e-3
+
+
+def test_solve_ik_batch_device_kinematics_equals_host_path(backend):
+    """FrameTasks + PostureTask under the default limits: FK, task rows and limits evaluated by the device kernels
+    from q alone must give the velocities of the host-evaluated path (same QP, rows computed in another order)."""
+    for m, frames in ((build_chain(6), ["tool0"]), (build_chain(9, free_flyer=True, seed=3), ["tool0", "joint_4"])):
+        rng = np.random.default_rng(31)
+        B = 7
+        cfgs = []
+        for _ in range(B):
+            q = m.neutral()
+            for j in m.joints:
+                if j.kind != "free_flyer":
+                    q[j.idx_q] = rng.uniform(-0.9, 0.9)
+            cfgs.append(Configuration(m, q))
+        per_instance = []
+        for cfg in cfgs:
+            tl = []
+            for k, f in enumerate(frames):
+                t = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+                t.set_target(cfg.get_transform_frame_to_world(f) * SE3(np.eye(3), 0.03 * rng.normal(size=3)))
+                tl.append(t)
+            p = PostureTask(cost=1e-2, gain=0.7)
+            p.set_target(m.neutral())
+            tl.append(p)
+            per_instance.append(tl)
+        V_host = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=False, gpu_frame_tasks=False)
+        V_dev = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=True)
+        assert np.abs(V_dev - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
+        assert np.abs(V_host).max() > 1e-3
+    # not eligible: a barrier in the stack
+    bar = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
+    with pytest.raises(pink_amd.PinkError):
+        solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
