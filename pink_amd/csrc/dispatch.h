@@ -11,9 +11,9 @@
 #define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
 #else
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
-#define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
+#define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
-  X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
+  X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
 #endif
 
 namespace pinkhip {

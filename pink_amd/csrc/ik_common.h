@@ -34,6 +34,31 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for<I + 1, N>(f);
   }
 }
+// "Transpose-reduce": every lane of a group holds N <= W partial values v(0..N-1); afterwards lane j of the group
+// holds sum over the group's lanes of v(j) (lanes >= N: 0).  Recursive halving: at level b the lanes whose bit b
+// is set keep the odd entries and hand the even ones to their partner (lane ^ 2^b), and vice versa, so the number
+// of values halves with every exchange -- N + N/2 + ... moves instead of N full reductions (N log W).
+template <int W, int N, int BIT, class F>
+__device__ __forceinline__ double transpose_reduce(F v) {
+  const int lane = lane_id();
+  if constexpr ((1 << BIT) >= W) {
+    static_assert(N == 1, "N <= W values fold to one per lane");
+    return v(std::integral_constant<int, 0>{});
+  } else {
+    constexpr int H = (N + 1) / 2;
+    double nx[H];
+    const bool up = ((lane >> BIT) & 1) != 0;
+    static_for<0, H>([&](auto M) {
+      constexpr int m = decltype(M)::value;
+      const double a = v(std::integral_constant<int, 2 * m>{});
+      double b = 0.0;
+      if constexpr (2 * m + 1 < N) b = v(std::integral_constant<int, 2 * m + 1>{});
+      nx[m] = (up ? b : a) + lane_shfl(up ? a : b, lane ^ (1 << BIT));
+    });
+    return transpose_reduce<W, H, BIT + 1>([&](auto K) { return nx[decltype(K)::value]; });
+  }
+}
+
 constexpr int STATUS_OPTIMAL = 0;
 constexpr int STATUS_MAX_ITER = 1;
 constexpr int STATUS_INFEASIBLE = 2;

@@ -623,11 +623,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
       const bool dn = act && (DENSE && kind >= 2);
       const double gi = (in && dn) ? ((kind == 3) ? Gs[(src & 31) * GP + li] : -Gs[(src & 31) * GP + li]) : 0.0;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const double s = group_sum<W>(Jr[j] * gi);
-        if (dn && li == j) dl = s;
-      }
+      // d_j = sum over the lanes i of J[i][j] g_i for every j at once (one group reduction per j before)
+      const double dj = transpose_reduce<W, NV, 0>([&](auto Jc) { return Jr[decltype(Jc)::value] * gi; });
+      if (dn) dl = dj;
     }
     PINKHIP_TICK(4);  // d = J^T n
     double dd = group_bcast<W>(rown2, src & (W - 1));
