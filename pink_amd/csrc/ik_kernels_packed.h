@@ -313,11 +313,27 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     // (columns nv .. NV of the staged rows: read by the eight-wide slack products, must be zero)
     for (int idx = li; idx < md * (GP - nv); idx += W) Gs[(idx / (GP - nv)) * GP + nv + idx % (GP - nv)] = 0.0;
     wave_sync();
-    if (li < md) {  // dispatch.h guarantees md <= W: one lane per dense row
-      hv = a.hd[b * (long long)md + li];
-      double s = 0.0;
-      for (int j = 0; j < nv; ++j) s += Gs[li * GP + j] * Gs[li * GP + j];
-      ginv = (s > 0.0) ? 1.0 / sqrt(s) : 1.0;
+    {  // Euclidean norms of the dense rows, eight lanes per row like the slacks of the selection (up to W / 8 rows)
+      double n2 = 0.0;
+      if (md * 8 <= W) {
+        const int row = li >> 3, seg = li & 7;
+        const double *gr = Gs + (row < md ? row : 0) * GP;
+        double part = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < NV; j0 += 8) {
+          const int j = j0 + seg;
+          if (j0 + 8 <= NV || j < NV) part += gr[j < NV ? j : 0] * gr[j < NV ? j : 0];
+        }
+        if (row >= md) part = 0.0;
+        part = group_sum<8>(part);
+        n2 = group_bcast<W>(part, (li < md ? li : 0) << 3);
+      }
+      if (li < md) {  // dispatch.h guarantees md <= W: one lane per dense row
+        hv = a.hd[b * (long long)md + li];
+        if (md * 8 > W)
+          for (int j = 0; j < nv; ++j) n2 += Gs[li * GP + j] * Gs[li * GP + j];
+        ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
+      }
     }
     for (int t = 0; t < a.n_barriers; ++t) {
       const double r = a.barrier_safe_gain[t];
