@@ -437,3 +437,69 @@ def test_solve_ik_batch_device_kinematics_equals_host_path(backend):
     bar = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
     with pytest.raises(pink_amd.PinkError):
         solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
+
+
+def _biped():
+    """Floating base with two 6-joint legs (a tree, not a chain) and frames at the pelvis and the ankles: the
+    smallest model with the structure of the reference's JVRC / Upkie fixtures."""
+    m = pink_amd.Model()
+    root = m.add_joint("root_joint", "free_flyer")
+    m.add_frame("pelvis", root, SE3(np.eye(3), [0.0, 0.0, 0.05]))
+    axes = [[0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 1, 0], [0, 1, 0], [1, 0, 0]]
+    for side, y in (("l", 0.1), ("r", -0.1)):
+        parent = root
+        for i, ax in enumerate(axes):
+            off = SE3(np.eye(3), [0.0, y if i == 0 else 0.0, -0.05 if i < 3 else -0.35 if i in (3, 4) else -0.05])
+            parent = m.add_joint(f"{side}_leg_{i}", "revolute", parent, off, ax, -2.0, 2.0, 10.0)
+        m.add_frame(f"{side}_ankle", parent, SE3(np.eye(3), [0.0, 0.0, -0.05]))
+    m.finalize() if hasattr(m, "finalize") else None
+    return m
+
+
+def test_single_task_translation_gives_pure_linear_velocity(backend):
+    """tests/test_solve_ik.py:212-247: translating the target of a frame yields a linear velocity of that frame
+    along the translation and no angular velocity."""
+    m = _biped()
+    q = m.neutral()
+    q[7 + 3] = 0.4  # bend the knees a little, away from the singular straight leg
+    q[7 + 4] = -0.2
+    q[7 + 9] = 0.4
+    q[7 + 10] = -0.2
+    cfg = Configuration(m, q)
+    task = FrameTask("r_ankle", position_cost=1.0, orientation_cost=1.0)
+    tgt = cfg.get_transform_frame_to_world("r_ankle").copy()
+    tgt.translation[1] -= 0.1
+    task.set_target(tgt)
+    task.lm_damping = 0.0  # only Tikhonov damping for this test
+    v = solve_ik(cfg, [task], dt=1e-3, damping=1e-12)
+    twist = cfg.get_frame_jacobian("r_ankle") @ v  # body twist of the frame, [linear; angular]
+    R = cfg.get_transform_frame_to_world("r_ankle").rotation
+    lin_world = R @ twist[:3]
+    assert np.allclose(twist[3:], 0.0, atol=1e-7)
+    assert abs(lin_world[0]) < 1e-6 and abs(lin_world[2]) < 1e-6 and lin_world[1] < 0.0
+
+
+def test_three_tasks_convergence(backend):
+    """tests/test_solve_ik.py:279-339: three simultaneously feasible FrameTasks on a floating-base biped converge in
+    fewer than 42 closed-loop steps (velocity norm below 1e-6, small residual errors)."""
+    m = _biped()
+    q = m.neutral()
+    for k in (3, 9):
+        q[7 + k] = 0.5
+        q[7 + k + 1] = -0.25
+    cfg = Configuration(m, q)
+    l_task = FrameTask("l_ankle", position_cost=1.0, orientation_cost=3.0)
+    r_task = FrameTask("r_ankle", position_cost=1.0, orientation_cost=3.0)
+    p_task = FrameTask("pelvis", position_cost=1.0, orientation_cost=0.0)
+    tasks = [p_task, l_task, r_task]
+    l_task.set_target(cfg.get_transform_frame_to_world("l_ankle") * SE3(np.eye(3), [0.1, 0.0, 0.0]))
+    r_task.set_target(cfg.get_transform_frame_to_world("r_ankle") * SE3(np.eye(3), [-0.1, 0.0, 0.0]))
+    p_task.set_target(cfg.get_transform_frame_to_world("pelvis"))
+    dt, max_iter = 4e-3, 42
+    for nb_iter in range(max_iter):
+        v = solve_ik(cfg, tasks, dt)
+        if np.linalg.norm(v) < 1e-6:
+            break
+        cfg = Configuration(m, cfg.integrate(v, dt))
+    assert nb_iter < max_iter and np.linalg.norm(v) < 1e-6
+    assert max(np.linalg.norm(t.compute_error(cfg)) for t in tasks) < 0.5
