@@ -32,16 +32,26 @@ inline PackedChoice select_packed(int nv, int md) {
   return PackedChoice{0, 0};
 }
 
+// Doubles of LDS per QP of the stack + solve kernel without dense rows (= LdsP<NV>::stride(0), checked at compile
+// time in tu_rollout.hip).
+constexpr int solve_lds_doubles(int NV) { return ((((NV * (NV + 3) / 2 + 1) & ~1) + 5 * NV) + 1) & ~1; }
+
+// Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
+// LDS, whichever is larger.
+constexpr int rollout_lds_doubles(int NV, int fk_doubles) {
+  return ((fk_doubles + 1) & ~1) > solve_lds_doubles(NV) ? ((fk_doubles + 1) & ~1) : solve_lds_doubles(NV);
+}
+
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
-// kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the scratch
-// must fit the solve kernel's own LDS share (doubles per QP of LdsP<NV>::stride(0) = NV (NV + 3) / 2 + 4 NV, even).
+// kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the 64 / W
+// robots of a wavefront must fit the 64 KiB of LDS a workgroup may ask for.
 inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
   // robots that fit an 8-lane group keep the two-launch step: padding them to 16 lanes halves the robots per
   // wavefront (measured, 6-dof arm: 0.107 ms in one kernel at NV = 12 against 0.068 ms in two launches at NV = 6)
   if (nv <= 8) return PackedChoice{0, 0};
-#define PINKHIP_PICK(NV_, W_)                                                                       \
-  if (nv <= NV_ && nj <= W_ && fk_doubles <= ((((NV_ * (NV_ + 3) / 2 + 1) & ~1) + 4 * NV_ + 1) & ~1)) \
-    return PackedChoice{NV_, W_};
+#define PINKHIP_PICK(NV_, W_)                                                                              \
+  if (nv <= NV_ && nj <= W_)                                                                               \
+    return 8 * rollout_lds_doubles(NV_, fk_doubles) * (64 / W_) + 16 <= 65536 ? PackedChoice{NV_, W_} : PackedChoice{0, 0};
   PINKHIP_ROLLOUT_TABLE(PINKHIP_PICK)
 #undef PINKHIP_PICK
   return PackedChoice{0, 0};

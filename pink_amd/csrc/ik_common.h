@@ -73,6 +73,7 @@ struct KernelArgs {
   int n_barriers;
   int cost_batched;
   int max_iter;
+  int lds_pitch;     // doubles of LDS per QP (0: LdsP<NV>::stride(md)); the whole-step kernel may need more for its kinematics
   double damping, dt;
   // per-instance streams
   const double *J, *e, *cost, *lb, *ub, *Gd, *hd, *c_extra;

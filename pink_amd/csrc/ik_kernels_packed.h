@@ -60,8 +60,9 @@ struct LdsP {
   static constexpr int oY = oV;
   static constexpr int oWa = oD;                  // RC <= NV: stacking weights, dead before oD is used
   static constexpr int oGs = oD2;
-  static constexpr int oGd = oV + NV;             // md*GP
-  static __host__ __device__ inline int stride(int md) { return (oGd + md * GP + 1) & ~1; }  // doubles per QP
+  static constexpr int oRn = oV + NV;             // NV   (H^-1)_ii = |row i of J|^2: read at the entering row
+  static constexpr int oGd = oRn + NV;            // md*GP
+  static __host__ __device__ constexpr int stride(int md) { return (oGd + md * GP + 1) & ~1; }  // doubles per QP
   static __host__ __device__ inline long long bytes(int md, int groups) { return 8LL * stride(md) * groups + 16; }
   // L: row i, entries 0..i at i(i+1)/2
   static __host__ __device__ constexpr int lrow(int i) { return i * (i + 1) / 2; }
@@ -99,6 +100,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   // pass from 2 minutes at NV = 56 to 8 minutes per translation unit)
   constexpr bool kBc = W >= 16 && NV <= 56;
   using BcT = Bcast<(W >= 16 ? W : 16)>;
+  // the instantiations with dense rows of the two- and four-QPs-per-wave sizes carry ~16 more registers through the loop
+  // than fit next to eight-wide operand batches at three waves per SIMD: they use narrower batches instead of spilling
+  constexpr bool kTight = DENSE && (W == 32 || W == 16);
 
   const int lane = lane_id();
   const int g = lane / W, li = lane & (W - 1);
@@ -111,7 +115,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   const bool valid = b < a.B;
   if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
 
-  double *sm = shared_base() + (long long)g * S::stride(md);
+  double *sm = shared_base() + (long long)g * (a.lds_pitch ? a.lds_pitch : S::stride(md));
   double *Ts = sm + S::oT;
   double *xs = sm + S::oX;
   double *ys = sm + S::oY;
@@ -293,7 +297,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   }
   double diag = a.damping + group_sum<W>(mu_l);
 
-  double hv = 0.0, ginv = 1.0;
+  double hv = 0.0, ginv = 1.0, gr0 = 0.0, gr1 = 0.0;
+#ifndef PINKHIP_GR
+#define PINKHIP_GR 2
+#endif
+  constexpr int kGR = PINKHIP_GR;  // dense rows kept in registers
   if (md > 0) {
     wave_sync();
     {
@@ -334,6 +342,12 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
           for (int j = 0; j < nv; ++j) n2 += Gs[li * GP + j] * Gs[li * GP + j];
         ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
       }
+    }
+    // one or two dense rows (a pair of barriers is the common case, examples/humanoid_jvrc.py) also stay in the lanes,
+    // entry li with lane li: their slacks are then two group sums per selection -- no LDS round trip, no barrier
+    if (md <= kGR) {
+      gr0 = (li < NV) ? Gs[li] : 0.0;
+      gr1 = (md > 1 && li < NV) ? Gs[GP + li] : 0.0;
     }
     for (int t = 0; t < a.n_barriers; ++t) {
       const double r = a.barrier_safe_gain[t];
@@ -460,6 +474,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   for (int j = 0; j < NV; ++j) rown2 += Jr[j] * Jr[j];
   // metric weight of the box constraints on coordinate li in the selection rule: 1 / sqrt((H^-1)_ii)
   const double rsc = in ? fast_rsqrt1(rown2) : 0.0;
+  if (li < NV) sm[S::oRn + li] = rown2;
   double rsc_mean = 0.0;
   if (md > 0) rsc_mean = group_sum<W>(rsc) / (double)nv;
   double x = 0.0;
@@ -503,8 +518,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension (nv dot
   // products of length nv per step) and so does the threshold; same rule as oracle/gi_oracle.c
   const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
-  const double thr_lo = (in && lbv > -INF) ? -tol * (1.0 + fabs(lbv)) : -INF;
-  const double thr_up = (in && ubv < INF) ? -tol * (1.0 + fabs(ubv)) : -INF;
+  // (an infinite bound gives an infinite slack and threshold: never violated.  The instantiation with dense rows is
+  // short of registers: it rebuilds the two thresholds at every selection instead of keeping them)
+  const double thr_lo0 = -tol * (1.0 + fabs(lbv)), thr_up0 = -tol * (1.0 + fabs(ubv));
   const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
   int q = 0, it = 0, eq_next = 0;  // group-uniform
   int bstate = 0, dactive = 0, A = 0;
@@ -528,9 +544,27 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       // configurations, the minimiser being the same.
       int bestid = 0;
       const double klo = slo * rsc, kup = sup * rsc;
+      double thr_lo = thr_lo0, thr_up = thr_up0;
+      if constexpr (DENSE) {
+        double lbk = lbv, ubk = ubv;
+        pin(lbk);
+        pin(ubk);
+        thr_lo = -tol * (1.0 + fabs(lbk));
+        thr_up = -tol * (1.0 + fabs(ubk));
+      }
       if (bstate != 1 && slo < thr_lo) best = klo, bestid = li;
       if (bstate != 2 && sup < thr_up && kup < best) best = kup, bestid = 64 + li;
-      if (md > 0) {
+      if (md > 0 && md <= kGR) {
+        const double g0 = group_sum<W>(gr0 * x);
+        const double g1 = (md > 1) ? group_sum<W>(gr1 * x) : 0.0;
+        if (li < md) {
+          const double s = hv - (li == 0 ? g0 : g1);
+          sd = s;
+          const double sc = s * ginv;
+          const double kd = sc * rsc_mean;
+          if (li >= n_eq && !dactive && sc < -tol * (1.0 + fabs(hv) * ginv) && kd < best) best = kd, bestid = 128 + li;
+        }
+      } else if (md > 0) {
         if (li < NV) xs[li] = x;
         wave_sync();
         // slacks h_i - g_i x of the dense rows.  Up to W / 8 rows: eight lanes per row, each sums every eighth
@@ -539,7 +573,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
         // the row and of x per LDS round trip.  (Columns nv..NV-1 of the staged rows and of x are zero.)
         double gx = 0.0;
         if (md * 8 <= W) {
-          const int row = li >> 3, seg = li & 7;
+          int lik = li;  // pinned: the addresses below are rebuilt here instead of living in registers across the loop
+          pin(lik);
+          const int row = lik >> 3, seg = lik & 7;
           const double *gr = Gs + (row < md ? row : 0) * GP;
           double part = 0.0;
 #pragma unroll
@@ -644,7 +680,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       if (dn) dl = dj;
     }
     PINKHIP_TICK(4);  // d = J^T n
-    double dd = group_bcast<W>(rown2, src & (W - 1));
+    double dd = sm[S::oRn + (src & (W - 1))];  // (a dense row's index may point past the NV entries: replaced below)
     if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
       const double dds = group_sum<W>(dl * dl);
       if ((DENSE && kind >= 2)) dd = dds;
@@ -707,16 +743,33 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
 #pragma unroll
       for (int m0 = 0; m0 < NV; m0 += 8) {
         if (m0 < qmax) {
-          double pv[8], dv[8];
+          if constexpr (!kTight) {
+            double pv[8], dv[8];
 #pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            pv[m] = (m0 + m < NV) ? Pl[S::doff(m0 + m)] : 0.0;
-            dv[m] = (m0 + m < NV) ? d1l[m0 + m] : 0.0;
+            for (int m = 0; m < 8; ++m) {
+              pv[m] = (m0 + m < NV) ? Pl[S::doff(m0 + m)] : 0.0;
+              dv[m] = (m0 + m < NV) ? d1l[m0 + m] : 0.0;
+            }
+            pin16(pv, dv);  // all 16 operands in flight before the first FMA
+#pragma unroll
+            for (int m = 0; m < 8; ++m) rv += pv[m] * dv[m];
+            pin(rv);
+          } else {
+            // (register-tight instantiations: four operand pairs in flight at a time)
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {
+              double pv[4], dv[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                pv[m] = (m0 + h + m < NV) ? Pl[S::doff(m0 + h + m < NV ? m0 + h + m : 0)] : 0.0;
+                dv[m] = (m0 + h + m < NV) ? d1l[m0 + h + m] : 0.0;
+              }
+              pin8(pv, dv);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) rv += pv[m] * dv[m];
+              pin(rv);
+            }
           }
-          pin16(pv, dv);  // all 16 operands in flight before the first FMA
-#pragma unroll
-          for (int m = 0; m < 8; ++m) rv += pv[m] * dv[m];
-          pin(rv);
         }
       }
     }
@@ -835,7 +888,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       wave_sync();
       // rotation indices any group needs: two wave-uniform bounds, tested per l on the scalar unit;
       // inside them a group that does not rotate at l reads the identity
-      constexpr int kRB = 4;  // rotations per batch (reads of a batch in flight together)
+      constexpr int kRB = kTight ? 2 : 4;  // rotations per batch (reads of a batch in flight together)
       const int l0 = groups_min<W>(do_drop ? kd : NV);
       const int l1 = groups_max<W>(do_drop ? q - 1 : 0);
       const int ro = (li < kd) ? lv : (lv + 1 < NV ? lv + 1 : 0);  // lane li builds NEW row li from old row ro
@@ -848,9 +901,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
         if (lb + kRB > l0 && lb < l1) {
           // old entries P[ro][l + 1] are read one column ahead of the writes of new P[li][l]
           double pb[kRB], cc[kRB], ss[kRB];
-          int lik = lv, rok = ro;  // pinned: keeps the per-column lane addresses from being hoisted out of
-          pin(lik);                // the active-set loop, where they would live in (spilled) registers
-          pin(rok);
+          int lik = lv, rok = prow ? ro : NV, wlo = (lv > kd) ? lv : kd, whi = prow ? q - 1 : 0;
+          pin(lik);  // pinned: keeps the per-column lane addresses and masks from being hoisted out of the
+          pin(rok);  // active-set loop, where they would live in (spilled) registers
+          pin(wlo);
+          pin(whi);
 #pragma unroll
           for (int k = 0; k < kRB; ++k) {
             const int l = lb + k;
@@ -858,7 +913,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
             cc[k] = 1.0;
             ss[k] = 0.0;
             if (l < NV - 1) {
-              if (prow && ro <= l + 1) pb[k] = Po[S::doff(l + 1) + (l + 1) * rok];
+              if (rok <= l + 1) pb[k] = Po[S::doff(l + 1) + (l + 1) * rok];
               cc[k] = d2s[2 * l];
               ss[k] = d2s[2 * l + 1];
             }
@@ -868,12 +923,12 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
           for (int k = 0; k < kRB; ++k) {
             const int l = lb + k;
             if (l < NV - 1) {
-              const bool rot = prow && l >= kd && l < q - 1;
+              // outside [kd, q - 1) the rotation read back is the identity: carry just moves on to the next old
+              // entry, so that only the store is conditional (one exec region per column; the lane's window of
+              // columns is two registers -- thirty loop-invariant lane masks would live in spilled SGPRs)
               const double pn_ = cc[k] * carry + ss[k] * pb[k];
-              if (rot) {
-                carry = cc[k] * pb[k] - ss[k] * carry;
-                if (li <= l) Pk[S::doff(l) + l * lik] = pn_;
-              }
+              carry = cc[k] * pb[k] - ss[k] * carry;
+              if ((l >= wlo) & (l < whi)) Pk[S::doff(l) + l * lik] = pn_;
               const double ja = Jr[l], jb = Jr[l + 1];
               Jr[l] = cc[k] * ja + ss[k] * jb;
               Jr[l + 1] = cc[k] * jb - ss[k] * ja;

@@ -64,8 +64,9 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
   long long b = block * G + g;
   const bool valid = b < a.k.B;
   if (!valid) b = a.k.B - 1;
-  // kinematics scratch inside this robot's share of the solve kernel's LDS (host checks that it fits)
-  double *sm = shared_base() + (long long)g * S::stride(0);
+  // kinematics scratch at the start of this robot's share of LDS: the solve (which keeps stacking and the
+  // factorisation in registers) first writes there after its last read of it; the share is the larger of the two
+  double *sm = shared_base() + (long long)g * a.k.lds_pitch;
   FkTerms<W> t;
   t.es = sm + fk_lds_doubles(m.nj, m.nf);
   t.UV = sm + 12 * (m.nj + m.nf) + ((m.nj + 1) & ~1);  // = Jls of ik_fk_instance
@@ -100,7 +101,7 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
 }
 
 template <int NV, int W>
-__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV) ik_rollout_kernel(RolloutArgs a) {
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_ROLLOUT(NV) ik_rollout_kernel(RolloutArgs a) {
   ik_rollout_instance<NV, W>(a, block_id());
 }
 

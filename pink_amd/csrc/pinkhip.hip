@@ -50,6 +50,7 @@ struct pinkhip_handle {
   std::vector<char> h_tables;        // what d_tables currently holds
   char *arena = nullptr;             // grow-only scratch of the *_host entry points
   size_t arena_bytes = 0;
+  char *stage = nullptr;             // page-locked, device-visible staging of the small-batch *_host path
   hipDeviceProp_t prop;
   void *comm = nullptr;              // ncclComm_t once pinkhip_comm_init succeeded
   int comm_rank = 0, comm_size = 0;
@@ -112,11 +113,12 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   }
   // stack + solve: the instantiation chosen by dispatch.h, each one its own translation unit (tu_packed.hip)
   const pinkhip::PackedChoice pc = pinkhip::select_packed(a.nv, a.md);
+  static const bool force_dense = std::getenv("PINKHIP_FORCE_DENSE") != nullptr;  // development: time the dense-row instantiation on a batch without dense rows
   hipError_t e = hipErrorInvalidValue;
   switch (pc.NV) {
 #define PINKHIP_CASE(NV, W)                                                                   \
   case NV:                                                                                    \
-    e = a.md == 0 ? pinkhip::PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(h->stream, a)               \
+    e = (a.md == 0 && !force_dense) ? pinkhip::PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(h->stream, a) \
                   : pinkhip::PINKHIP_LAUNCH_PACKED_NAME(NV, W, 1)(h->stream, a);              \
     break;
     PINKHIP_PACKED_TABLE(PINKHIP_CASE)
@@ -313,6 +315,7 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm) pinkhip_comm_destroy(h);
   if (h->arena) (void)hipFree(h->arena);
+  if (h->stage) (void)hipHostFree(h->stage);
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -371,6 +374,7 @@ int pinkhip_stack_device(pinkhip_handle *h, const pinkhip_desc *desc, const pink
 
 // Device layout of one uploaded batch inside the arena (offsets of the eight input streams + outputs).
 namespace {
+constexpr size_t kStageBytes = size_t(256) << 10;  // *_host batches up to this size go through the staging buffer
 struct ArenaPlan {
   size_t n[8], off[8], stride[8];  // bytes, offset, bytes per instance (0: broadcast stream)
   size_t out_off, total;
@@ -406,8 +410,33 @@ int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
   const size_t B = static_cast<size_t>(desc->B), nv = desc->nv;
   const size_t n_dq = align256(8 * B * nv), n_st = align256(4 * B);
   const ArenaPlan p = plan_arena(desc, host_in, n_dq + 2 * n_st);
-  if ((rc = ensure_arena(h, p.total))) return rc;
   const void *src[8] = {host_in->J, host_in->e, host_in->cost, host_in->lb, host_in->ub, host_in->Gd, host_in->hd, host_in->c_extra};
+  if (p.total <= kStageBytes) {
+    // Small batch (a single robot at its control rate is the reference's own use, examples/arm_ur5.py:62-86): what
+    // the call costs is API round trips, not bytes.  Inputs are copied by the CPU into one page-locked buffer that
+    // the kernel reads -- and writes its results to -- across PCIe: one launch and one synchronisation instead of
+    // eight asynchronous copies, two events and two synchronisations.
+    if (!h->stage) PH_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->stage), kStageBytes, hipHostMallocDefault));
+    char *dbase = nullptr;
+    PH_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&dbase), h->stage, 0));
+    auto at = [&](int i) -> const double * {
+      if (!(p.n[i] && src[i])) return nullptr;
+      std::memcpy(h->stage + p.off[i], src[i], p.n[i]);
+      return reinterpret_cast<const double *>(dbase + p.off[i]);
+    };
+    a.J = at(0), a.e = at(1), a.cost = at(2), a.lb = at(3), a.ub = at(4), a.Gd = at(5), a.hd = at(6), a.c_extra = at(7);
+    a.dq = reinterpret_cast<double *>(dbase + p.out_off);
+    a.status = reinterpret_cast<int *>(dbase + p.out_off + n_dq);
+    a.iters = reinterpret_cast<int *>(dbase + p.out_off + n_dq + n_st);
+    if ((rc = launch(h, a, true))) return rc;
+    PH_HIP(h, hipStreamSynchronize(h->stream));
+    const char *o = h->stage + p.out_off;
+    std::memcpy(host_out->dq, o, 8 * B * nv);
+    std::memcpy(host_out->status, o + n_dq, 4 * B);
+    if (host_out->iters) std::memcpy(host_out->iters, o + n_dq + n_st, 4 * B);
+    return PINKHIP_OK;
+  }
+  if ((rc = ensure_arena(h, p.total))) return rc;
   char *dev[8];
   for (int i = 0; i < 8; ++i) dev[i] = (p.n[i] && src[i]) ? h->arena + p.off[i] : nullptr;
   char *out = h->arena + p.out_off;
@@ -713,6 +742,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     return fail(h, PINKHIP_E_INVALID, "bad limit gain / step");
   const pinkhip::PackedChoice pc = pinkhip::select_rollout(md.nv, md.nj, pinkhip::rollout_fk_doubles(md.nj, md.nf));
   if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
+  ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pinkhip::rollout_fk_doubles(md.nj, md.nf));
   ra.k.cost = st->cost;
   ra.k.dq = st->dq;
   ra.k.status = st->status;

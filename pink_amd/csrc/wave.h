@@ -32,6 +32,15 @@
 #define PINKHIP_OCCUPANCY_PACKED(NV) \
   __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
 
+// whole-control-step kernel: the kinematics part needs more registers than the solve of the small sizes (12-dof
+// arm, 65 536 robots: 0.136 ms per step at four waves per SIMD with 57 spilled registers, 0.120 ms at three)
+#ifndef PINKHIP_ROLLOUT_WAVES_SMALL
+#define PINKHIP_ROLLOUT_WAVES_SMALL 3
+#endif
+#define PINKHIP_ROLLOUT_WAVES(NV) ((NV) <= 16 ? PINKHIP_ROLLOUT_WAVES_SMALL : PINKHIP_PACKED_WAVES(NV))
+#define PINKHIP_OCCUPANCY_ROLLOUT(NV) \
+  __attribute__((amdgpu_waves_per_eu(PINKHIP_ROLLOUT_WAVES(NV), PINKHIP_ROLLOUT_WAVES(NV))))
+
 // fused forward-kinematics kernels: latency bound (dependent table / LDS round trips), three waves per SIMD
 // measured best (0.576 -> 0.548 ms per nv = 30 step; four waves spill)
 #ifndef PINKHIP_FK_WAVES
@@ -100,6 +109,10 @@ __device__ __forceinline__ void pin16(const double (&a)[8], const double (&b)[8]
                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]),
                  "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
                : "memory");
+}
+
+__device__ __forceinline__ void pin8(const double (&a)[4], const double (&b)[4]) {
+  asm volatile("" : : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
 }
 
 // Broadcast `v` of lane `src` (wave-uniform) to every lane: 2 x v_readlane_b32.

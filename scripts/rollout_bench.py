@@ -11,6 +11,7 @@ from pink_amd.rollout import DeviceRollout, pose12
 s = BatchSolver(0)
 out = {}
 cases = (("arm6", build_chain(6), ["tool0"]),
+         ("arm12", build_chain(12, seed=3), ["tool0", "joint_6"]),
          ("floating_base_nv30", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"]))
 only = os.environ.get("ROLLOUT_ONLY")
 for label, model, frames in [c for c in cases if not only or c[0] == only]:

@@ -36,6 +36,8 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "draco3"
     bounds = sys.argv[2] if len(sys.argv) > 2 else "tight"
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    if name == "draco3b":  # the headline robot with two barrier rows (DENSE instantiation; build with EXTRA=-DPINKHIP_CLOCK_DENSE=1)
+        synthetic.CONFIGS["draco3b"] = dict(synthetic.CONFIGS["draco3"], n_barriers=2, config_id=13)
     s = BatchSolver(0)
     lib = _lib.load_library()
     lib.pinkhip_debug_section_clock.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -53,7 +55,7 @@ def main():
     c = np.array(list(out), dtype=np.float64)[:len(SECTIONS)]
     print(f"{name} {bounds} B={B}: {ms:.3f} ms (instrumented), mean iterations {r.iters.mean():.1f}")
     for n, v in zip(SECTIONS, c):
-        print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / (B / 128):10.0f} cycles per sampled wave")
+        print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / c.sum() * ms * 1e3 :8.1f} us of the launch")
 
 
 if __name__ == "__main__":

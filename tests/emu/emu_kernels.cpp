@@ -270,6 +270,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   ra.first_failure = st->first_failure;
   ra.step = st->step;
   const pinkhip::PackedChoice pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
+  a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
   pinkhip::LaneFn fn = nullptr;
   long long blocks = 0;
   switch (pc.NV) {

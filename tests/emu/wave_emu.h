@@ -25,6 +25,7 @@
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV)
+#define PINKHIP_OCCUPANCY_ROLLOUT(NV)
 #define PINKHIP_OCCUPANCY_FK
 #define PINKHIP_OCCUPANCY_SMALL_STACK
 
@@ -97,6 +98,7 @@ inline void emu_rendezvous(int tag) {
 inline void wave_sync() { emu_rendezvous(1); }
 inline void sched_fence() {}
 inline void pin16(const double (&)[8], const double (&)[8]) {}
+inline void pin8(const double (&)[4], const double (&)[4]) {}
 template <typename T>
 inline void pin(T &) {}
 
