@@ -59,6 +59,11 @@ __device__ __forceinline__ double transpose_reduce(F v) {
   }
 }
 
+// two doubles written / read as one 16-byte LDS access
+struct alignas(16) Pair {
+  double a, b;
+};
+
 constexpr int STATUS_OPTIMAL = 0;
 constexpr int STATUS_MAX_ITER = 1;
 constexpr int STATUS_INFEASIBLE = 2;

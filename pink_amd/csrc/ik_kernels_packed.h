@@ -442,7 +442,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       Jr[j] *= rinv;
       if constexpr (j + 1 < NV) {
         // only lanes jj > j are ever read from this vector (source lane of Jr[jj]'s update): no mask needed
-        const BcT lb = bcast_prepare<W>(lij);
+        const BcT lb = bcast_scale<W>(xb, rinv);  // = bcast_prepare(lij): rinv is group-uniform
         const double nyj = -Jr[j];
         static_for<j + 1, NV>([&](auto Jn) {
           constexpr int jj = decltype(Jn)::value;
@@ -665,8 +665,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     double dl = 0.0;
     if (wave_any(act && (!DENSE || kind < 2))) {
       if (act && (!DENSE || kind < 2) && li == src) {
+        // (the per-QP LDS regions are 16-byte aligned: NV / 2 ds_write_b128 at immediate offsets)
+        Pair *dst = reinterpret_cast<Pair *>(__builtin_assume_aligned(ds, 16));
 #pragma unroll
-        for (int j = 0; j < NV; ++j) ds[j] = Jr[j];
+        for (int j = 0; j < NV; j += 2) dst[j >> 1] = Pair{Jr[j], Jr[j + 1]};
       }
       wave_sync();
       const double rowv = (li < NV) ? ds[lv] : 0.0;

@@ -15,11 +15,19 @@
 
 namespace pinkhip {
 
-template <int NT>
+// STAGED = true (NT >= 3 with even nv, Kd <= 32 and 16-byte aligned J: the JVRC-shaped configuration): the
+// instance's J block (Kd nv contiguous doubles) is requested as ONE flat stream, 16 bytes per lane and 1 KiB per wave
+// instruction, and reaches the MFMA operand layout through LDS.  The direct path requests 128-byte pieces of 8 nv-byte
+// rows per tile column; at nv = 50 the fourth tile column holds two of sixteen lanes.  Measured (MI355X, B = 65 536):
+// nv = 50: 653 -> 546 us; nv = 30 (NT = 2): 186 us either way, so NT <= 2 stays direct.  Staging H on the way out the
+// same way (16 nv contiguous doubles per row of tiles) or pairing neighbouring columns into 16-byte stores measured
+// slower (nv = 30: 209 / 189 us; nv = 50 with both stagings: 789 us, LDS-bound occupancy).
+template <int NT, bool STAGED = false>
 __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) {
   double *sm = shared_base();
   double *was = sm;        // [128] w_k^2 of the current pass
   double *gws = sm + 128;  // [128] gain_k w_k^2 e_k
+  double *Js = sm + 256;   // STAGED: [Kd nv] the J block
   const int lane = lane_id();
   const int nv = a.nv, Kd = a.Kd, K = a.K;
   const int col = lane & 15, rq = lane >> 4;
@@ -36,9 +44,39 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
   // request (Kd <= 32: every BASELINE configuration) J stays in registers for all tile rows; larger task
   // stacks re-request it per tile row and are served by L2.
   constexpr int kSteps = 8;
-  const bool one_pass = Kd <= 4 * kSteps;
+  const bool one_pass = STAGED || Kd <= 4 * kSteps;
   double Jp[kSteps][NT];
+  const int nJ = Kd * nv;
+  constexpr int TL = STAGED ? 4 * NT : 1;  // 32 rows of 16 NT doubles = 4 NT wave-wide 16-byte requests
+  Pair jflat[TL];
+  auto stage_flat = [&]() {  // registers -> LDS (flat) -> this lane's MFMA operands
+    Pair *Jsp = reinterpret_cast<Pair *>(__builtin_assume_aligned(Js, 16));
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int idx = lane + kWave * t;
+      if (2 * idx < nJ) Jsp[idx] = jflat[t];
+    }
+    wave_sync();
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const int kk = 4 * st + rq;
+#pragma unroll
+      for (int tc = 0; tc < NT; ++tc) {
+        const int j = 16 * tc + col;
+        Jp[st][tc] = (kk < Kd && j < nv) ? Js[kk * nv + j] : 0.0;
+      }
+    }
+  };
   auto request = [&](int r0) {
+    if constexpr (STAGED) {
+      const Pair *Jg = reinterpret_cast<const Pair *>(__builtin_assume_aligned(Jb, 16));
+#pragma unroll
+      for (int t = 0; t < TL; ++t) {
+        const int idx = lane + kWave * t;
+        jflat[t] = (2 * idx < nJ) ? Jg[idx] : Pair{0.0, 0.0};
+      }
+      return;
+    }
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {
       const int kk = r0 + 4 * st + rq;  // this lane's task row
@@ -98,6 +136,7 @@ __device__ inline void ik_stack_mfma_instance(const KernelArgs &a, long long b) 
     }
   }
   if (one_pass && Kd > 0) build_table(0);
+  if constexpr (STAGED) stage_flat();
 
   double cpart[NT];
 #pragma unroll
@@ -308,6 +347,18 @@ __global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_SMALL_STACK ik_stack_
 template <int NT>
 __global__ void __launch_bounds__(kWave) ik_stack_mfma_kernel(KernelArgs a) {
   ik_stack_mfma_instance<NT>(a, block_id());
+}
+
+// LDS of the staged variant, in doubles: coefficient tables and the J block
+__host__ __device__ inline int stack_staged_lds_doubles(int nv, int Kd) { return 256 + Kd * nv; }
+// the staged variant needs 16-byte aligned per-instance J blocks: Kd nv even, 16-byte aligned base
+__host__ __device__ inline bool stack_staged_ok(int nv, int Kd, const void *J) {
+  return nv > 32 && ((Kd * nv) & 1) == 0 && Kd > 0 && Kd <= 32 && (reinterpret_cast<unsigned long long>(J) & 15) == 0;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kWave) ik_stack_staged_kernel(KernelArgs a) {
+  ik_stack_mfma_instance<NT, true>(a, block_id());
 }
 
 }  // namespace pinkhip

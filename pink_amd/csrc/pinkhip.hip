@@ -82,7 +82,13 @@ struct pinkhip_unique_id_t {
 template <int NT>
 int launch_stack_mfma(pinkhip_handle *h, const KernelArgs &a) {
   const dim3 grid(static_cast<unsigned>(a.B)), block(pinkhip::kWave);
-  hipLaunchKernelGGL(pinkhip::ik_stack_mfma_kernel<NT>, grid, block, 2048, h->stream, a);
+  static const bool direct = std::getenv("PINKHIP_STACK_DIRECT") != nullptr;  // development: time the unstaged variant
+  if (!direct && pinkhip::stack_staged_ok(a.nv, a.Kd, a.J)) {
+    const size_t lds = 8 * static_cast<size_t>(pinkhip::stack_staged_lds_doubles(a.nv, a.Kd));
+    if constexpr (NT >= 3) hipLaunchKernelGGL(pinkhip::ik_stack_staged_kernel<NT>, grid, block, lds, h->stream, a);
+  } else {
+    hipLaunchKernelGGL(pinkhip::ik_stack_mfma_kernel<NT>, grid, block, 2048, h->stream, a);
+  }
   PH_HIP(h, hipGetLastError());
   return PINKHIP_OK;
 }

@@ -4,6 +4,8 @@
 // separate objects they build in parallel and only the host file is touched by an ABI change.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 // clang-format off
 #include "wave.h"
 #include "ik_kernels_packed.h"
@@ -19,7 +21,12 @@ namespace pinkhip {
 hipError_t PINKHIP_LAUNCH_PACKED_NAME(PINKHIP_TU_NV, PINKHIP_TU_W, PINKHIP_TU_DENSE)(hipStream_t stream, const KernelArgs &a) {
   constexpr int NV = PINKHIP_TU_NV, W = PINKHIP_TU_W, G = kWave / W;
   constexpr bool DENSE = PINKHIP_TU_DENSE != 0;
-  const size_t lds = static_cast<size_t>(LdsP<NV>::bytes(DENSE ? a.md : 0, G));
+  size_t lds = static_cast<size_t>(LdsP<NV>::bytes(DENSE ? a.md : 0, G));
+#ifdef PINKHIP_SECTION_CLOCK
+  // profiling builds only: PINKHIP_LDS_TOTAL=<bytes> asks for more LDS per wave to lower the occupancy (40000: one
+  // wave per SIMD, 20000: two) -- per-section cycles of a wave that runs alone vs. among three
+  if (const char *t = std::getenv("PINKHIP_LDS_TOTAL")) lds = static_cast<size_t>(std::atoll(t)) > lds ? static_cast<size_t>(std::atoll(t)) : lds;
+#endif
   const dim3 grid(static_cast<unsigned>((a.B + G - 1) / G)), block(kWave);
   hipLaunchKernelGGL((ik_solve_packed_kernel<NV, W, DENSE>), grid, block, lds, stream, a);
   return hipGetLastError();

@@ -320,6 +320,18 @@ __device__ __forceinline__ Bcast<W> bcast_prepare(double v) {
   }
   return b;
 }
+// bcast_prepare(v * s) for a group-uniform s from bcast_prepare(v): one multiplication per row copy instead of
+// the permlane swaps (the copies of a group's rows all belong to that group)
+template <int W>
+__device__ __forceinline__ Bcast<W> bcast_scale(const Bcast<W> &b, double s) {
+  Bcast<W> o;
+#pragma unroll
+  for (int k = 0; k < W / 16; ++k) o.r[k] = b.r[k] * s;
+  if constexpr (W == 16) asm volatile("s_nop 1" : "+v"(o.r[0]));
+  else if constexpr (W == 32) asm volatile("s_nop 1" : "+v"(o.r[0]), "+v"(o.r[1]));
+  else asm volatile("s_nop 1" : "+v"(o.r[0]), "+v"(o.r[1]), "+v"(o.r[2]), "+v"(o.r[3]));
+  return o;
+}
 template <int W, int J>
 __device__ __forceinline__ double fma_bcast(double acc, const Bcast<W> &b, double x) {
   static_assert(J >= 0 && J < W, "source lane outside the group");

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-LIB = os.path.join(ge.CSRC, "libpinkhip_clock.so")
+LIB = os.environ.get("PINKHIP_CLOCK_LIBRARY", os.path.join(ge.CSRC, "libpinkhip_clock.so"))
 SECTIONS = ["stacking", "Cholesky", "J = L^-T, x0", "selection", "d = J^T n (row)", "norms, v, sync", "z, w",
             "r = P d1", "steps, x/u update", "add (J2, P column)", "drop", "exit"]
 
@@ -54,8 +54,9 @@ def main():
     r = s.download(dev)
     c = np.array(list(out), dtype=np.float64)[:len(SECTIONS)]
     print(f"{name} {bounds} B={B}: {ms:.3f} ms (instrumented), mean iterations {r.iters.mean():.1f}")
+    sampled = (B // 2 + 63) // 64  # every 64th wave of B / 2 adds its cycles
     for n, v in zip(SECTIONS, c):
-        print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / c.sum() * ms * 1e3 :8.1f} us of the launch")
+        print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / c.sum() * ms * 1e3 :8.1f} us of the launch   {v / sampled:9.0f} cycles per sampled wave")
 
 
 if __name__ == "__main__":

@@ -37,6 +37,12 @@ void lane_main_stack_small(void *p) {
 template <int NT>
 void lane_main_stack_mfma(void *p) {
   const KernelArgs *a = static_cast<const KernelArgs *>(p);
+  if constexpr (NT >= 3) {
+    if (pinkhip::stack_staged_ok(a->nv, a->Kd, a->J)) {  // same rule as pinkhip.hip
+      pinkhip::ik_stack_mfma_instance<NT, true>(*a, pinkhip::block_id());
+      return;
+    }
+  }
   pinkhip::ik_stack_mfma_instance<NT>(*a, pinkhip::block_id());
 }
 

@@ -226,6 +226,10 @@ template <int W>
 inline Bcast<W> bcast_prepare(double v) {
   return Bcast<W>{v};
 }
+template <int W>
+inline Bcast<W> bcast_scale(const Bcast<W> &b, double s) {
+  return Bcast<W>{b.v * s};
+}
 template <int W, int J>
 inline double fma_bcast(double acc, const Bcast<W> &b, double x) {
   static_assert(J >= 0 && J < W, "");
