@@ -422,6 +422,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       status = STATUS_NOT_PD;
       p = 1.0;
     }
+    // (the wide instantiations: fold the test into the status register column by column -- left to the compiler it
+    // keeps NV lane masks in scalar registers until the loop is over, 2 NV of ~100 SGPRs, and spills them)
+    if constexpr (NV > 32) pin(status);
     if constexpr (!kBc && j > 0) inverse_row(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, rinv_prev);
     const double rinv = fast_rsqrt(p);
     const double lij = M[j] * rinv;
@@ -507,13 +510,18 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   }
 
   // ------------------------------------------------------------------ Goldfarb-Idnani, flat
+  // The kernel arguments that are only needed from here on (bounds, iteration cap, output pointers): the wide
+  // instantiations re-read them from the kernarg segment through an opaque pointer instead of carrying ~40
+  // scalar registers of arguments (spilled and reloaded) across the factorisation.
+  const KernelArgs *late = &a;
+  if constexpr (NV > 32 && !Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
   double lbv, ubv;
   if constexpr (Src::kOnTheFly) {
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
   } else {
-    lbv = in ? a.lb[b * (long long)nv + li] : -INF;
-    ubv = in ? a.ub[b * (long long)nv + li] : INF;
+    lbv = in ? late->lb[b * (long long)nv + li] : -INF;
+    ubv = in ? late->ub[b * (long long)nv + li] : INF;
   }
   // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension (nv dot
   // products of length nv per step) and so does the threshold; same rule as oracle/gi_oracle.c
@@ -521,7 +529,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   // (an infinite bound gives an infinite slack and threshold: never violated.  The instantiation with dense rows is
   // short of registers: it rebuilds the two thresholds at every selection instead of keeping them)
   const double thr_lo0 = -tol * (1.0 + fabs(lbv)), thr_up0 = -tol * (1.0 + fabs(ubv));
-  const int max_iter = a.max_iter > 0 ? a.max_iter : 20 * (nv + md) + 50;
+  const int max_iter = late->max_iter > 0 ? late->max_iter : 20 * (nv + md) + 50;
   int q = 0, it = 0, eq_next = 0;  // group-uniform
   int bstate = 0, dactive = 0, A = 0;
   double u = 0.0;
@@ -964,10 +972,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     terms->status = status;
   }
   if (valid) {
-    if (in) a.dq[b * (long long)nv + li] = x;
+    if (in) late->dq[b * (long long)nv + li] = x;
     if (li == 0) {
-      a.status[b] = status;
-      if (a.iters) a.iters[b] = it;
+      late->status[b] = status;
+      if (late->iters) late->iters[b] = it;
     }
   }
 }

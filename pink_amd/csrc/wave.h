@@ -83,6 +83,20 @@ __device__ __forceinline__ double *shared_base() {
   return pinkhip_lds;
 }
 
+// The kernel's argument struct (the ONLY kernel parameter, passed by value: offset 0 of the kernarg segment) behind a
+// pointer the compiler cannot see through: fields read through it are loaded where they are used instead of living
+// in scalar registers from the start of the kernel.
+template <class Args>
+__device__ __forceinline__ const Args *kernarg_reload(const Args &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const Args *p = reinterpret_cast<const Args *>(__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(p));
+  return p;
+#else  // the host pass of hipcc only parses device functions
+  return &a;
+#endif
+}
+
 // Scheduling fence: keeps hipcc from hoisting the LDS loads of later unrolled
 // iterations above this point (bounds VGPR pressure in the fully unrolled
 // triangular loops).  Emits no instruction.

@@ -101,6 +101,10 @@ inline void pin16(const double (&)[8], const double (&)[8]) {}
 inline void pin8(const double (&)[4], const double (&)[4]) {}
 template <typename T>
 inline void pin(T &) {}
+template <class Args>
+inline const Args *kernarg_reload(const Args &a) {
+  return &a;
+}
 
 inline double bcast(double v, int src) {
   Emu &e = emu();
