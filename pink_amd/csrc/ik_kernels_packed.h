@@ -670,7 +670,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     PINKHIP_TICK(3);  // selection
 
     // (b) d = J^T n+
-    double dl = 0.0;
+    double dl = 0.0, rowq = 0.0;
     if (wave_any(act && (!DENSE || kind < 2))) {
       if (act && (!DENSE || kind < 2) && li == src) {
         // (the per-QP LDS regions are 16-byte aligned: NV / 2 ds_write_b128 at immediate offsets)
@@ -680,6 +680,9 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       }
       wave_sync();
       const double rowv = (li < NV) ? ds[lv] : 0.0;
+      // entry q of the row (the pivot of the Householder step): read here, group-uniform address, instead of a
+      // broadcast from lane q once d is known (q = NV reads the zero padding behind the row)
+      rowq = ds[q];
       if (act && (!DENSE || kind < 2)) dl = (kind == 0) ? rowv : -rowv;
     }
     if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
@@ -697,7 +700,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     }
     const double d2n = group_sum<W>((li >= q) ? dl * dl : 0.0);
     const bool lin_dep = !(d2n * 1e24 > dd);  // (the product sits on d2n: dd's broadcast is waited for after the reduction)
-    const double dq_ = group_bcast<W>(dl, q < W ? q : W - 1);
+    double dq_ = (kind == 0) ? rowq : -rowq;
+    if constexpr (DENSE) {  // d of a dense row is not in LDS
+      const double dqb = group_bcast<W>(dl, q < W ? q : W - 1);
+      if (kind >= 2) dq_ = dqb;
+    }
     const double rn2 = lin_dep ? 0.0 : fast_rsqrt1(lin_dep ? 1.0 : d2n);
     const double nrm2 = d2n * rn2;
     const double sgq = (dq_ >= 0.0) ? 1.0 : -1.0;
@@ -788,10 +795,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     const bool eq_pos = DENSE && (A >> 6) >= 2 && (A & 63) < n_eq;  // equalities are never dropped
     const bool blocking = act && li < q && rv > 0.0 && !eq_pos;
     const double ratio = blocking ? u * fast_rcp1(rv) : BIG;
-    const double k1 = group_min<W>(blocking ? key_pack(ratio, li) : BIG);
-    const int kd = key_payload(k1) & (W - 1);
-    const double t1b = group_bcast<W>(ratio, kd);  // unconditional: cross-lane ops must not diverge
-    const double t1 = (k1 < BIG) ? t1b : INF;
+    // the exact minimum and the first lane that attains it (a ballot, no LDS-crossbar round trip for the value)
+    const double k1 = group_min<W>(ratio);
+    const int kd = group_first_lane<W>(blocking && ratio == k1) & (W - 1);
+    const double t1 = (k1 < BIG) ? k1 : INF;
     if (sp_take) sp = sp_in;
     sp_take = false;
     const double t2 = lin_dep ? INF : -sp * rn2 * rn2;

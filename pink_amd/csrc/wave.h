@@ -262,6 +262,22 @@ __device__ __forceinline__ double fast_rsqrt1(double x) {
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
 
+// Index inside its group of W lanes of the first lane whose predicate holds (W if none): one ballot, the group's bits
+// shifted down, count of trailing zeros -- no LDS crossbar.
+template <int W>
+__device__ __forceinline__ int group_first_lane(bool p) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+  if constexpr (W == 64) {
+    return m ? __builtin_ctzll(m) : 64;
+  } else {
+    const int lane = static_cast<int>(threadIdx.x);
+    const unsigned half = (lane & 32) ? static_cast<unsigned>(m >> 32) : static_cast<unsigned>(m);
+    unsigned g = half;
+    if constexpr (W < 32) g = (half >> (lane & 31 & ~(W - 1))) & ((1u << W) - 1u);
+    return g ? __builtin_ctz(g) : W;
+  }
+}
+
 // Value of an arbitrary (per-lane) source lane: 2 x ds_bpermute_b32 (LDS crossbar, no LDS memory).
 __device__ __forceinline__ double lane_shfl(double v, int src_lane) {
   const int a = src_lane << 2;

@@ -192,6 +192,18 @@ inline bool wave_any(bool p) {
   emu_rendezvous(15);
   return r;
 }
+template <int W>
+inline int group_first_lane(bool p) {
+  Emu &e = emu();
+  e.slot_i[e.cur] = p ? 1 : 0;
+  emu_rendezvous(40);
+  int r = W;
+  const int base = e.cur & ~(W - 1);
+  for (int l = W - 1; l >= 0; --l)
+    if (e.slot_i[base + l]) r = l;
+  emu_rendezvous(41);
+  return r;
+}
 inline double lane_shfl(double v, int src_lane) {
   if (src_lane < 0 || src_lane >= kWave) {
     std::fprintf(stderr, "wave emulator: lane_shfl from lane %d\n", src_lane);
