@@ -258,15 +258,26 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     specs, targets, posture = [], [], None
     for col in slots:
         t0 = col[0]
-        same = all(type(t) is type(t0) and t.gain == t0.gain and t.lm_damping == t0.lm_damping
-                   and np.array_equal(np.asarray(t.cost, dtype=float), np.asarray(t0.cost, dtype=float)) for t in col)
-        if not same:
-            return None
+        if col[-1] is not t0:  # (one task object for the whole batch: nothing to compare)
+            ty, g0, l0 = type(t0), t0.gain, t0.lm_damping
+            if not all(type(t) is ty and t.gain == g0 and t.lm_damping == l0 for t in col):
+                return None
+            try:  # the costs of the whole column in one comparison
+                costs = np.array([t.cost for t in col], dtype=float)
+            except (TypeError, ValueError):
+                return None
+            if costs.shape[0] != B or (costs != costs[0]).any():
+                return None
         if type(t0) is FrameTask:
             if any(t.frame != t0.frame or t.transform_target_to_world is None for t in col) or posture is not None:
                 return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
             specs.append((t0.frame, np.asarray(t0.position_cost, float), np.asarray(t0.orientation_cost, float), t0.gain, t0.lm_damping))
-            targets.append(np.array([_pose12(t.transform_target_to_world) for t in col]))
+            tg = np.empty((B, 12))
+            for b, t in enumerate(col):
+                T_b = t.transform_target_to_world
+                tg[b, :9] = np.asarray(T_b.rotation, dtype=float).reshape(9)
+                tg[b, 9:] = T_b.translation
+            targets.append(tg)
         elif type(t0) is PostureTask:
             if posture is not None or any(t.target_q is None for t in col) or np.ndim(t0.cost) != 0:
                 return None
