@@ -278,6 +278,29 @@ def traffic_from_profiles():
         return None, "no PMC pass committed for these sources"
 
 
+def _with_timeout(fn, seconds: float, what: str):
+    """`fn()` on a daemon thread; TimeoutError if it is not back after `seconds` (collectives that never return must
+    not cost the bench line; the caller then leaves the process through os._exit)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:  # noqa: BLE001
+            box["error"] = exc
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TimeoutError(f"{what} did not return within {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
 def _device_count() -> int:
     import ctypes
 
@@ -335,15 +358,6 @@ def main() -> None:
     solver = batch_solver.BatchSolver(device_id=local_rank % max(int(os.environ.get("PINKHIP_VISIBLE_DEVICES", "0")) or _device_count(), 1))
     info = solver.device_info()
     comm, comm_note = None, None
-    if world > 1:
-        comm = HostComm(rdzv)
-        if hasattr(solver, "comm_unique_id"):
-            # the communicator is created collectively; if RCCL refuses it (e.g. two ranks placed on one device)
-            # every rank gets the error and the job falls back to gathering over the rendezvous sockets
-            try:
-                comm = RcclComm(solver, rdzv)
-            except Exception as exc:  # noqa: BLE001
-                comm_note = f"RCCL communicator unavailable ({exc}); dq gathered over the TCP rendezvous instead"
     dev = solver.upload(batch)
 
     def barrier():
@@ -372,15 +386,34 @@ def main() -> None:
     n_bad = int(rdzv.allreduce_sum(float((res.status != 0).sum())))
     kernel_ms_ranks = [float(np.frombuffer(b, dtype=np.float64)[0]) for b in rdzv.allgather_bytes(np.float64(kernel_ms).tobytes())]
 
-    # the only inter-GPU traffic of the workload: gather of dq to rank 0 (untimed leg of the job)
+    # the only inter-GPU traffic of the workload: gather of dq to rank 0 (untimed leg of the job, after the timed
+    # region: nothing that happens here can cost the throughput figure).  The communicator is created collectively;
+    # if RCCL refuses it (e.g. two ranks placed on one device) every rank gets the error, if it does not come back
+    # within a minute every rank's watchdog fires, and the job gathers over the rendezvous sockets instead.
     gather = None
+    abandoned = False  # a watchdog fired: a thread may still sit in a collective -> leave through os._exit
     if world > 1:
+        comm = HostComm(rdzv)
+        if hasattr(solver, "comm_unique_id"):
+            try:
+                barrier()
+                comm = _with_timeout(lambda: RcclComm(solver, rdzv), 60.0, "RCCL communicator")
+            except TimeoutError as exc:
+                abandoned = True
+                comm_note = f"{exc}; dq gathered over the TCP rendezvous instead"
+            except Exception as exc:  # noqa: BLE001
+                comm_note = f"RCCL communicator unavailable ({exc}); dq gathered over the TCP rendezvous instead"
         try:
-            barrier()
+            if not abandoned:
+                barrier()
             tg = time.perf_counter()
             if isinstance(comm, RcclComm):
-                d_recv = comm.gather_device(dev.d_dq, 8 * B * nv, 0)
-                solver.sync()
+                def rccl_gather():
+                    d = comm.gather_device(dev.d_dq, 8 * B * nv, 0)
+                    solver.sync()
+                    return d
+
+                d_recv = _with_timeout(rccl_gather, 60.0, "ncclGather")
                 gather_ms = (time.perf_counter() - tg) * 1e3
                 ok = None
                 if rank == 0:  # rank 0's own shard must come back unchanged
@@ -390,10 +423,15 @@ def main() -> None:
                     solver.release(d_recv)
                 gather = {"ms": gather_ms, "bytes_per_rank": 8 * B * nv, "transport": "ncclGather (RCCL over xGMI) via pinkhip_comm_gather_bytes",
                           "rank0_shard_intact": ok}
+            elif abandoned:
+                gather = {"failed": comm_note}
             else:
                 parts = comm.gather_arrays([res.dq], 0)
                 gather = {"ms": (time.perf_counter() - tg) * 1e3, "bytes_per_rank": 8 * B * nv, "transport": "host TCP (no device)",
                           "rank0_shard_intact": None if parts is None else bool(np.array_equal(parts[0][0].reshape(B, nv), res.dq))}
+        except TimeoutError as exc:
+            abandoned = True
+            gather = {"failed": repr(exc)}
         except Exception as exc:  # noqa: BLE001  report, never lose the bench line
             gather = {"failed": repr(exc)}
 
@@ -505,8 +543,14 @@ def main() -> None:
             line["parity"] = {"max_abs_dq_err_vs_oracle": float(np.abs(res.dq[:n] - ref["dq"]).max()),
                               "instances_compared": n, "tolerance": 1e-8,
                               "note": "oracle = restated Goldfarb-Idnani; QP half parity-unpinned against quadprog (DESIGN.md 4)"}
-        print(json.dumps(line))
-    rdzv.barrier()
+        print(json.dumps(line), flush=True)
+    if abandoned:  # a thread of this process may still sit inside an RCCL call: no orderly teardown
+        sys.stdout.flush()
+        os._exit(0)
+    try:
+        rdzv.barrier()
+    except (OSError, ConnectionError):  # a rank that abandoned a collective has left already
+        os._exit(0)
     dev.free()
     if comm is not None:
         comm.close()
