@@ -27,8 +27,10 @@
 #define PINKHIP_OCCUPANCY_ATTR(NV) \
   __attribute__((amdgpu_waves_per_eu((NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE, \
                                      (NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE)))
+// (NV = 34, the 27-joint floating-base humanoids: 168 VGPRs with two spilled dwords at three waves -- 4.20 -> 3.36 ms
+// per 65 536; NV = 40 would spill 228)
 #define PINKHIP_PACKED_WAVES(NV) \
-  ((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : (NV) <= 32 ? PINKHIP_WAVES_PACKED_LARGE : PINKHIP_WAVES_LARGE)
+  ((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : (NV) <= 34 ? PINKHIP_WAVES_PACKED_LARGE : PINKHIP_WAVES_LARGE)
 #define PINKHIP_OCCUPANCY_PACKED(NV) \
   __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
 
