@@ -988,7 +988,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
 }
 
 template <int NV, int W, bool DENSE>
-__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV) ik_solve_packed_kernel(KernelArgs a) {
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_PACKED(NV, DENSE) ik_solve_packed_kernel(KernelArgs a) {
   ik_packed_instance<NV, W, DENSE>(a, block_id());
 }
 

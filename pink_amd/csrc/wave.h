@@ -28,11 +28,14 @@
   __attribute__((amdgpu_waves_per_eu((NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE, \
                                      (NV) <= 32 ? PINKHIP_WAVES_SMALL : PINKHIP_WAVES_LARGE)))
 // (NV = 34, the 27-joint floating-base humanoids: 168 VGPRs with two spilled dwords at three waves -- 4.20 -> 3.36 ms
-// per 65 536; NV = 40 would spill 228)
+// per 65 536.  NV = 40 spills 228 dwords at three waves, most of them in the start-up: the box-only instantiation
+// still gains, 5.49 -> 4.81 ms, the one with dense rows loses, 3.39 -> 3.55 ms, and stays at two; NV = 50 at three
+// waves spills ~1000 dwords and takes twice the time.)
 #define PINKHIP_PACKED_WAVES(NV) \
   ((NV) <= 16 ? PINKHIP_WAVES_PACKED_SMALL : (NV) <= 34 ? PINKHIP_WAVES_PACKED_LARGE : PINKHIP_WAVES_LARGE)
-#define PINKHIP_OCCUPANCY_PACKED(NV) \
-  __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES(NV), PINKHIP_PACKED_WAVES(NV))))
+#define PINKHIP_PACKED_WAVES2(NV, DENSE) (((NV) == 40 && !(DENSE)) ? PINKHIP_WAVES_PACKED_LARGE : PINKHIP_PACKED_WAVES(NV))
+#define PINKHIP_OCCUPANCY_PACKED(NV, DENSE) \
+  __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES2(NV, DENSE), PINKHIP_PACKED_WAVES2(NV, DENSE))))
 
 // whole-control-step kernel: the kinematics part needs more registers than the solve of the small sizes (12-dof
 // arm, 65 536 robots: 0.136 ms per step at four waves per SIMD with 57 spilled registers, 0.120 ms at three)

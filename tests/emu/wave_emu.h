@@ -24,7 +24,7 @@
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
-#define PINKHIP_OCCUPANCY_PACKED(NV)
+#define PINKHIP_OCCUPANCY_PACKED(NV, DENSE)
 #define PINKHIP_OCCUPANCY_ROLLOUT(NV)
 #define PINKHIP_OCCUPANCY_FK
 #define PINKHIP_OCCUPANCY_SMALL_STACK
