@@ -6,10 +6,21 @@
 
 // X(NV, W): NV = nv padded to the next instantiated even size (padded coordinates cost FMAs and LDS traffic),
 // W = lanes per QP (64 / W QPs per wavefront).  Every pair is built with and without the dense-row machinery.
-#ifdef PINKHIP_DEV_NV  // kernel-development builds: one instantiation only (make DEV=1 [DEVNV=50 DEVW=64], ~20 s)
+#ifdef PINKHIP_DEV_NV  // kernel-development builds: one instantiation only (make DEV=1 [DEVNV=50 DEVW=64 DEVMD=6], ~20 s)
+#ifndef PINKHIP_DEV_MD
+#define PINKHIP_DEV_MD 0
+#endif
 #define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
 #define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
+#define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
 #else
+// X(NV, MD, W): the sweep-tableau kernel ik_solve_sweep_kernel<NV, MD, W> (ik_sweep.h): NV coordinates + MD dense rows
+// = NT <= W tableau rows, one per lane.  Ordered by NT within box-only / with dense rows; problems that fit none
+// (8-lane groups, more dense rows than lanes are left) run the Goldfarb-Idnani kernel of PINKHIP_PACKED_TABLE.
+#define PINKHIP_SWEEP_TABLE(X)                                                                                      \
+  X(12, 0, 16) X(16, 0, 16) X(24, 0, 32) X(30, 0, 32) X(32, 0, 32) X(34, 0, 64) X(40, 0, 64) X(48, 0, 64) X(50, 0, 64) \
+  X(56, 0, 64) X(64, 0, 64)                                                                                         \
+  X(12, 4, 16) X(24, 8, 32) X(30, 2, 32) X(30, 8, 64) X(34, 8, 64) X(40, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
 #define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
@@ -30,6 +41,19 @@ inline PackedChoice select_packed(int nv, int md) {
   PINKHIP_PACKED_TABLE(PINKHIP_PICK)
 #undef PINKHIP_PICK
   return PackedChoice{0, 0};
+}
+
+struct SweepChoice {
+  int NV, MD, W;
+};
+
+// Smallest sweep-tableau instantiation that holds nv coordinates and md dense rows ({0, 0, 0}: none).
+inline SweepChoice select_sweep(int nv, int md) {
+#define PINKHIP_PICK(NV_, MD_, W_) \
+  if (nv <= NV_ && md <= MD_ && (md > 0) == (MD_ > 0)) return SweepChoice{NV_, MD_, W_};
+  PINKHIP_SWEEP_TABLE(PINKHIP_PICK)
+#undef PINKHIP_PICK
+  return SweepChoice{0, 0, 0};
 }
 
 // Doubles of LDS per QP of the stack + solve kernel without dense rows (= LdsP<NV>::stride(0), checked at compile

@@ -16,6 +16,7 @@
 #pragma once
 
 #include "ik_common.h"
+#include "ik_stack_rows.h"
 
 // The triangular factor of the active set is kept as P = R^-1 (R itself is never stored): the dual
 // direction r = P d1 is a chain-free matrix-vector product, a new column of P costs one LDS write per
@@ -69,19 +70,6 @@ struct LdsP {
   // P (upper triangular) by diagonals: P[r][c] at doff(c - r) + r = doff(c) + c r + prow(r)
   static __host__ __device__ constexpr int doff(int m) { return m * (2 * NV + 1 - m) / 2; }
   static __host__ __device__ constexpr int prow(int r) { return -((r * (2 * NV - 1 + r)) / 2); }
-};
-
-// Where the per-instance terms come from.  HbmTerms (default): the packed streams J / e / lb / ub in HBM.  A policy
-// with kOnTheFly = true (ik_rollout.h: the whole-control-step kernel) produces the task rows, errors and bounds
-// itself -- frame_rows(f, dst) fills this lane's entries of the six rows of FrameTask f, error(k) / diag_error(r)
-// return task errors, lb / ub are members -- and receives the result back in x / status.
-struct HbmTerms {
-  static constexpr bool kOnTheFly = false;
-  double lb = 0.0, ub = 0.0, x = 0.0;
-  int status = 0;
-  __device__ __forceinline__ void frame_rows(int, double (&)[6]) const {}
-  __device__ __forceinline__ double error(int) const { return 0.0; }
-  __device__ __forceinline__ double diag_error(int) const { return 0.0; }
 };
 
 // DENSE = false is the instantiation for problems without dense inequality / equality rows (box limits
@@ -144,58 +132,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
 
   if constexpr (kBc) {
-    // No LDS at all: lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row; the
-    // next chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters
-    // every lane's H row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j]
-    // taken from lane j and w_k^2 from lane k.
-    // (two chunks of eight rows in registers: twelve spill at NV = 30; an on-the-fly source delivers one
-    // FrameTask = six rows per chunk)
-    constexpr int RC = Src::kOnTheFly ? 6 : (S::RC < 8 ? S::RC : 8);
-    static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
-    double cur[RC], nxt[RC];
-    double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
-    auto request = [&](double (&dst)[RC], int r0, int rc) {
-      if constexpr (Src::kOnTheFly) {
-        double six[6];
-        terms->frame_rows(r0 / 6, six);
-#pragma unroll
-        for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? six[kk] : 0.0;
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
-      }
-      if (li < rc) {
-        const int k = r0 + li;
-        pw = costb[k];
-        if constexpr (Src::kOnTheFly) pe = terms->error(k);
-        else pe = eb[k];
-        pg = a.row_gain[k];
-        pl = a.row_lm[k];
-      }
-    };
-    if (Kd > 0) request(cur, 0, Kd < RC ? Kd : RC);
-    for (int r0 = 0; r0 < Kd; r0 += RC) {
-      const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;
-      const double wa = (li < rc) ? pw * pw : 0.0;
-      const double gw = (li < rc) ? pg * wa * pe : 0.0;
-      if (li < rc) mu_l += pl * (pg * pg) * wa * pe * pe;
-      const BcT wab = bcast_prepare<W>(wa), gwb = bcast_prepare<W>(gw);
-      if (r0 + RC < Kd) request(nxt, r0 + RC, (Kd - r0 - RC < RC) ? Kd - r0 - RC : RC);
-      static_for<0, RC>([&](auto Kc) {
-        constexpr int kk = decltype(Kc)::value;
-        if (kk < rc) {  // wave-uniform
-          const BcT rowb = bcast_prepare<W>(cur[kk]);
-          const double aa = fma_bcast<W, kk>(0.0, wab, cur[kk]);
-          ci = fma_bcast<W, kk>(ci, gwb, cur[kk]);
-          static_for<0, NV>([&](auto Jc) {
-            constexpr int j = decltype(Jc)::value;
-            M[j] = fma_bcast<W, j>(M[j], rowb, aa);
-          });
-        }
-      });
-#pragma unroll
-      for (int kk = 0; kk < RC; ++kk) cur[kk] = nxt[kk];
-    }
+    // no LDS at all: rows requested straight into registers, accumulated through the broadcast-FMA (ik_stack_rows.h)
+    stack_rows_bcast<NV, W, S::RC, Src>(a, b, terms, in, li, M, ci, mu_l);
   } else {
     // Rows are staged chunk by chunk (RC rows) through LDS.  The HBM requests of chunk c+1 (rows and their
     // weights) are issued into registers before chunk c is accumulated, so that only the first chunk pays
@@ -279,20 +217,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     }
   }
   if (in) {
-    for (int t = 0; t < a.n_dtasks; ++t) {
-      const int off = li - a.dtask_col0[t];
-      if (off >= 0 && off < a.dtask_k[t]) {
-        const int r = a.dtask_row0[t] + off;
-        const double w = costb[r], gn = a.row_gain[r], l = a.row_lm[r];
-        double ev;
-        if constexpr (Src::kOnTheFly) ev = terms->diag_error(r);
-        else ev = eb[r];
-        const double wa = w * w;
-        dadd += wa;
-        ci += gn * wa * ev;
-        mu_l += l * (gn * gn) * wa * ev * ev;
-      }
-    }
+    dadd = stack_diag_tasks<Src>(a, b, terms, li, ci, mu_l);
     if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
   }
   double diag = a.damping + group_sum<W>(mu_l);

@@ -1,0 +1,113 @@
+// Stacking of the task rows into H = damping I + sum_t (W_t J_t)^T (W_t J_t) + mu_t I, c = sum_t gain_t J_t^T W_t^2 e_t
+// (pink/tasks/task.py:145-167, pink/solve_ik.py:54-60) for the kernels whose groups are whole rows of 16 lanes: lane li
+// of a group accumulates row li of H in registers, fed by the broadcast-FMA of wave.h -- no LDS, no cross-lane
+// reduction.  Shared by the Goldfarb-Idnani kernel (ik_kernels_packed.h) and the sweep-tableau kernel (ik_sweep.h).
+#pragma once
+
+#include "ik_common.h"
+
+namespace pinkhip {
+
+// Where the per-instance terms come from.  HbmTerms (default): the packed streams J / e / lb / ub in HBM.  A policy
+// with kOnTheFly = true (ik_rollout.h: the whole-control-step kernel) produces the task rows, errors and bounds
+// itself -- frame_rows(f, dst) fills this lane's entries of the six rows of FrameTask f, error(k) / diag_error(r)
+// return task errors, lb / ub are members -- and receives the result back in x / status.
+struct HbmTerms {
+  static constexpr bool kOnTheFly = false;
+  double lb = 0.0, ub = 0.0, x = 0.0;
+  int status = 0;
+  __device__ __forceinline__ void frame_rows(int, double (&)[6]) const {}
+  __device__ __forceinline__ double error(int) const { return 0.0; }
+  __device__ __forceinline__ double diag_error(int) const { return 0.0; }
+};
+
+// Dense task rows.  Lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row; the next
+// chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters every lane's H
+// row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j] taken from lane j and w_k^2
+// from lane k.  M holds at least NV entries (the first NV are used); ci and mu_l accumulate this lane's entry of c
+// and its share of the Levenberg-Marquardt term.
+// (two chunks of eight rows in registers: twelve spill at NV = 30; an on-the-fly source delivers one FrameTask = six
+// rows per chunk)
+template <int NV, int W, int RCMAX, class Src, int NM>
+__device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long b, Src *terms, bool in, int li,
+                                                 double (&M)[NM], double &ci, double &mu_l) {
+  static_assert(NM >= NV && W >= 16, "row-group kernels only");
+  using BcT = Bcast<W>;
+  const int nv = a.nv, Kd = a.Kd, K = a.K;
+  const double *Jb = a.J + b * (long long)Kd * nv;
+  const double *eb = a.e + b * (long long)K;
+  const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
+  constexpr int RC = Src::kOnTheFly ? 6 : (RCMAX < 8 ? RCMAX : 8);
+  static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
+  double cur[RC], nxt[RC];
+  double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
+  auto request = [&](double (&dst)[RC], int r0, int rc) {
+    if constexpr (Src::kOnTheFly) {
+      double six[6];
+      terms->frame_rows(r0 / 6, six);
+#pragma unroll
+      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? six[kk] : 0.0;
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
+    }
+    if (li < rc) {
+      const int k = r0 + li;
+      pw = costb[k];
+      if constexpr (Src::kOnTheFly) pe = terms->error(k);
+      else pe = eb[k];
+      pg = a.row_gain[k];
+      pl = a.row_lm[k];
+    }
+  };
+  if (Kd > 0) request(cur, 0, Kd < RC ? Kd : RC);
+  for (int r0 = 0; r0 < Kd; r0 += RC) {
+    const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;
+    const double wa = (li < rc) ? pw * pw : 0.0;
+    const double gw = (li < rc) ? pg * wa * pe : 0.0;
+    if (li < rc) mu_l += pl * (pg * pg) * wa * pe * pe;
+    const BcT wab = bcast_prepare<W>(wa), gwb = bcast_prepare<W>(gw);
+    if (r0 + RC < Kd) request(nxt, r0 + RC, (Kd - r0 - RC < RC) ? Kd - r0 - RC : RC);
+    static_for<0, RC>([&](auto Kc) {
+      constexpr int kk = decltype(Kc)::value;
+      if (kk < rc) {  // wave-uniform
+        const BcT rowb = bcast_prepare<W>(cur[kk]);
+        const double aa = fma_bcast<W, kk>(0.0, wab, cur[kk]);
+        ci = fma_bcast<W, kk>(ci, gwb, cur[kk]);
+        static_for<0, NV>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          M[j] = fma_bcast<W, j>(M[j], rowb, aa);
+        });
+      }
+    });
+#pragma unroll
+    for (int kk = 0; kk < RC; ++kk) cur[kk] = nxt[kk];
+  }
+}
+
+// Diagonal tasks (J = eye[col0 : col0 + k], PostureTask posture_task.py:128-129, DampingTask ...): their Jacobian is
+// never stored.  Returns what they add to this lane's diagonal entry; c and the LM term accumulate in ci / mu_l.
+template <class Src>
+__device__ __forceinline__ double stack_diag_tasks(const KernelArgs &a, long long b, Src *terms, int li, double &ci,
+                                                   double &mu_l) {
+  const double *eb = a.e + b * (long long)a.K;
+  const double *costb = a.cost_batched ? a.cost + b * (long long)a.K : a.cost;
+  double dadd = 0.0;
+  for (int t = 0; t < a.n_dtasks; ++t) {
+    const int off = li - a.dtask_col0[t];
+    if (off >= 0 && off < a.dtask_k[t]) {
+      const int r = a.dtask_row0[t] + off;
+      const double w = costb[r], gn = a.row_gain[r], l = a.row_lm[r];
+      double ev;
+      if constexpr (Src::kOnTheFly) ev = terms->diag_error(r);
+      else ev = eb[r];
+      const double wa = w * w;
+      dadd += wa;
+      ci += gn * wa * ev;
+      mu_l += l * (gn * gn) * wa * ev * ev;
+    }
+  }
+  return dadd;
+}
+
+}  // namespace pinkhip

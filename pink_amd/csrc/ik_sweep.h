@@ -1,0 +1,451 @@
+// Stack + solve on a register-resident *sweep tableau*: W lanes per QP, 64/W QPs per wavefront, NO LDS.
+//
+// What it computes is the reference's pink/solve_ik.py:206-275 per instance -- H, c stacked as pink/tasks/task.py:145-167
+// and solve_ik.py:54-67 prescribe, then the QP  min 1/2 dq^T H dq + c^T dq  s.t.  lb <= dq <= ub,  Gd dq <= hd  (leading
+// n_eq rows: =) that qpsolvers / quadprog solves at solve_ik.py:270 -- with the same dual active-set logic as
+// Goldfarb-Idnani (start at the unconstrained minimum, add the violated constraint, drop the constraints whose
+// multiplier reaches zero on the way), but on a different representation of the working set.
+//
+// ik_kernels_packed.h keeps J = L^-T Q and the triangular factor of the active normals (quadprog's own data
+// structures): every step costs two matrix-vector products, a Householder update of J, a row of J extracted through LDS,
+// a product with R^-1 read from LDS and, for a drop, a sweep of Givens rotations.  Here the state is ONE symmetric
+// matrix, the KKT matrix  K = [H G^T; G 0]  swept (Beaton's sweep operator = a Gauss-Jordan pivot that keeps the
+// symmetry) on the set B of *basic* indices -- the free coordinates and the active dense rows:
+//     T_BB = -K_BB^-1,   T_NB = K_NB K_BB^-1,   T_NN = K_NN - K_NB K_BB^-1 K_BN.
+// Lane li of a group owns row li of T in NT = NV + MD registers (coordinates 0..NV-1, dense rows NV..NV+MD-1).
+//   * fixing a coordinate at a bound (= adding a box constraint), freeing it (= dropping it), activating or dropping a
+//     dense row are all the same operation: one pivot of T on that index, a rank-one update
+//         T[m][j] -= (T[m][p] / T[p][p]) T[p][j],
+//     i.e. NT broadcast-FMAs per lane (the row T[p][.] = column T[.][p] is a lane-held vector);
+//   * column p of T holds everything a step needs: how the free coordinates move (T_Bp), how the multipliers of the
+//     fixed coordinates and active rows change (T_Np resp. T_Bp), how the slacks of the inactive rows change, and on
+//     the diagonal the curvature n^T Z n along the entering normal (the exact reduced steepest-edge weight of the
+//     entering rule and the step length).  The column is extracted with NT broadcast-FMAs against an indicator vector.
+// A step is therefore 2 NT FMAs (3 NT when a constraint is dropped) plus two group reductions, against ~4 NT FMAs, ~60
+// LDS accesses and five reductions in the Goldfarb-Idnani kernel, and the kernel needs NT + ~20 doubles of registers
+// per lane instead of 2 NV + ~20 and no LDS: more waves per SIMD.  Measured: DESIGN.md section 3.1.
+//
+// The minimiser is the same (strictly convex QP); the path through the active sets follows the same rule as
+// ik_kernels_packed.h (violation weighted by 1 / sqrt(n^T Z n), here with the exact reduced Z).
+#pragma once
+
+#include "ik_common.h"
+#include "ik_stack_rows.h"
+
+#ifdef PINKHIP_SECTION_CLOCK
+#ifndef PINKHIP_TICK
+static __device__ unsigned long long pinkhip_clock[16];  // one copy per translation unit
+#define PINKHIP_TICK(k)                                                        \
+  do {                                                                         \
+    if (clock_on) {                                                            \
+      const unsigned long long now_ = __builtin_readcyclecounter();            \
+      if (lane == 0) atomicAdd(&pinkhip_clock[k], now_ - clock_prev);          \
+      clock_prev = __builtin_readcyclecounter();                               \
+    }                                                                          \
+  } while (0)
+#endif
+#else
+#ifndef PINKHIP_TICK
+#define PINKHIP_TICK(k)
+#endif
+#endif
+
+namespace pinkhip {
+
+template <int NV, int MD, int W, class Src = HbmTerms>
+__device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
+  constexpr int NT = NV + MD;
+  static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
+  constexpr bool DENSE = MD > 0;
+  constexpr int G = kWave / W;
+  constexpr double INF = INFINITY;
+  constexpr double BIG = 1e300;
+  using BcT = Bcast<W>;
+
+  const int lane = lane_id();
+  const int g = lane / W, li = lane & (W - 1);
+  const int nv = a.nv, md = DENSE ? a.md : 0, n_eq = DENSE ? a.n_eq : 0;
+#ifdef PINKHIP_SECTION_CLOCK
+  const bool clock_on = (block & 63) == 0;
+  unsigned long long clock_prev = __builtin_readcyclecounter();
+#endif
+  long long b = block * G + g;
+  const bool valid = b < a.B;
+  if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
+
+  const bool in = li < nv;          // coordinate lane
+  const int dr = li - NV;           // dense row of this lane
+  const bool dlane = DENSE && dr >= 0 && dr < md;
+
+  // ------------------------------------------------------------------ stack (task.py:145-167, solve_ik.py:54-67)
+  double T[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) T[j] = 0.0;
+  double ci = 0.0, mu_l = 0.0, dadd = 0.0;
+  stack_rows_bcast<NV, W, 8, Src>(a, b, terms, in, li, T, ci, mu_l);
+  if (in) {
+    dadd = stack_diag_tasks<Src>(a, b, terms, li, ci, mu_l);
+    if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
+  }
+  double diag = a.damping + group_sum<W>(mu_l);
+
+  double hv = 0.0, ginv = 1.0;
+  if constexpr (DENSE) {
+    if (md > 0) {
+      // K = [H G^T; G 0]: coordinate lane li takes G[d][li] into column NV + d, the lane of dense row d its row
+      const double *Gb = a.Gd + b * (long long)md * nv;
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+      });
+      if (dlane) {
+        const double *gr = Gb + (long long)dr * nv;
+        double n2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          T[j] = (j < nv) ? gr[j] : 0.0;
+          n2 += T[j] * T[j];
+        }
+        hv = a.hd[b * (long long)md + dr];
+        ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
+      }
+      // barrier objective (barrier.py:193-200): rho_b = r_b / ||J_h||_F^2 on the diagonal, J_h = -dt G rows
+      for (int t = 0; t < a.n_barriers; ++t) {
+        const double r = a.barrier_safe_gain[t];
+        if (r > 1e-6) {
+          const int r0 = a.barrier_rows[t], r1 = a.barrier_rows[t + 1];
+          double s = 0.0;
+          static_for<0, MD>([&](auto Dc) {
+            constexpr int d = decltype(Dc)::value;
+            if (in && d >= r0 && d < r1) s += T[NV + d] * T[NV + d];
+          });
+          s = group_sum<W>(s);
+          diag += r / (s * a.dt * a.dt);
+        }
+      }
+    }
+  }
+  diag += dadd;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (j == li) T[j] += in ? diag : 1.0;  // padded coordinates: identity rows, never pivoted
+  PINKHIP_TICK(0);  // stacking
+
+  // ------------------------------------------------------------------ sweep in every coordinate: T = [-H^-1 ...]
+  // Pivot k of the unswept matrix is the Schur complement of H on coordinates 0..k-1 (the square of Cholesky's
+  // pivot): not positive = H is not positive definite (quadprog's "matrix G is not positive definite").
+  // Lane k's own row becomes col / p; written as T[k][j] - (1 - 1/p) col_j it is the same FMA as every other lane's
+  // (T[k][j] and col_j = T[j][k] agree to round-off: the difference enters like a perturbation of H of that size).
+  int status = STATUS_OPTIMAL;
+  static_for<0, NV>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    if (k < nv) {  // wave-uniform
+      const BcT xb = bcast_prepare<W>(T[k]);
+      double p = value_bcast<W, k>(xb);
+      if (!(p > 0.0)) {
+        status = STATUS_NOT_PD;
+        p = 1.0;
+      }
+      if constexpr (NT > 32) pin(status);  // (fold the test column by column: no NV lane masks kept in SGPRs)
+      const double rp = fast_rcp(p);
+      const double t = T[k] * rp;
+      const double nt = (li == k) ? rp - 1.0 : -t;
+      static_for<0, NT>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
+      });
+      T[k] = (li == k) ? -rp : t;
+    }
+  });
+  PINKHIP_TICK(1);  // initial sweeps
+  // The diagonal entry of a lane's own row: kept in a register of its own from here on (a pivot on a run-time index
+  // cannot address "register p of lane p"; the copy inside T is not maintained and never read).
+  double tdiag = 0.0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    if (j == li) tdiag = T[j];
+  // x0 = -H^-1 c = T_BB c; the same product gives the rows of G: slack = h - G x0 = h + (T c)_row
+  double x = 0.0, u = 0.0;
+  {
+    const BcT cb = bcast_prepare<W>(in ? ci : 0.0);
+    double r0 = 0.0, r1 = 0.0;
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      if constexpr (j % 2 == 0) r0 = fma_bcast<W, j>(r0, cb, T[j]);
+      else r1 = fma_bcast<W, j>(r1, cb, T[j]);
+    });
+    x = in ? r0 + r1 : 0.0;
+    if (dlane) u = hv + (r0 + r1);
+  }
+  // n^T H^-1 n (the unreduced curvature along a constraint normal): the reference of the linear-dependence test.
+  // Box-only problems never need it: a free coordinate always has curvature left.
+  const double zd0 = -tdiag;
+  PINKHIP_TICK(2);  // x0
+
+  // ------------------------------------------------------------------ dual active set on the tableau
+  const KernelArgs *late = &a;
+  if constexpr (NT > 32 && !Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
+  double lbv, ubv;
+  if constexpr (Src::kOnTheFly) {
+    lbv = in ? terms->lb : -INF;
+    ubv = in ? terms->ub : INF;
+  } else {
+    lbv = in ? late->lb[b * (long long)nv + li] : -INF;
+    ubv = in ? late->ub[b * (long long)nv + li] : INF;
+  }
+  // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension and so does
+  // the threshold; same rule as oracle/gi_oracle.c and ik_kernels_packed.h
+  const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
+  const double thr_lo = -tol * (1.0 + fabs(lbv)), thr_up = -tol * (1.0 + fabs(ubv));  // infinite bound: never violated
+  const double thr_d = -tol * (1.0 + fabs(hv) * ginv);
+  const int max_iter = late->max_iter > 0 ? late->max_iter : 20 * (nv + md) + 50;
+  // per lane: state 0 = free coordinate / inactive row, 1 = fixed at lb / active row, 2 = fixed at ub;
+  // x = coordinate value; u = multiplier (fixed coordinate, active row) or slack h - g x (inactive row)
+  int state = 0;
+  // group-uniform
+  int it = 0, eq_next = 0, src = 0, kind = 0;  // kind 0: lower bound, 1: upper bound, 2: dense row, 3: equality row
+  double uplus = 0.0;
+  bool running = (status == STATUS_OPTIMAL);
+  bool need_sel = true;
+
+  for (;;) {
+    // (a) entering constraint, for the groups that have none pending: the violated constraint that is farthest away
+    // in the metric of the objective, violation / sqrt(n^T Z n) with Z the reduced inverse Hessian -- n^T Z n is the
+    // diagonal entry -T[i][i] (free coordinate i: Z_ii; inactive row: g Z g^T).
+    if (wave_any(running && need_sel)) {
+      const bool sel = running && need_sel;
+      const double slo = x - lbv, sup = ubv - x;
+      const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
+      // A fixed coordinate sits on its bound: its other bound can only be violated when the box is empty, and so are
+      // both bounds of a free one -- quadprog's "constraints are inconsistent".
+      const bool conflict = (vlo && vup) || (state != 0 && in && (vlo || vup));
+      // (no curvature left along the normal -- it depends on the active ones: the weight is just large; the step
+      // then finds the constraint that has to leave, or that there is none)
+      const double zd = -tdiag;
+      const double wz = (zd > 1e-290) ? approx_rcp(zd) : 1e290;
+      double key = 0.0;
+      int id = li;
+      if (vlo && state == 0) key = -(slo * slo) * wz - 1e-300;
+      if (vup && state == 0) {
+        const double ku = -(sup * sup) * wz - 1e-300;
+        if (ku < key) key = ku, id = 64 + li;
+      }
+      if constexpr (DENSE) {
+        if (dlane && dr >= n_eq && state == 0 && u * ginv < thr_d) key = -(u * u) * wz - 1e-300;
+      }
+      const float best32 = group_min32<W>(key < 0.0 ? key32_pack(key, id) : 3.0e38f);
+      const bool none = !(best32 < 0.0f);
+      const bool bad = group_first_lane<W>(conflict) < W;
+      if (sel) {
+        uplus = 0.0;
+        if (bad) {
+          status = STATUS_INFEASIBLE;
+          running = false;
+        } else if (DENSE && eq_next < n_eq) {
+          // equalities (the first n_eq dense rows; pink/solve_ik.py:140-149) are activated first, in order
+          src = NV + eq_next;
+          kind = 3;
+          need_sel = false;
+        } else if (none) {
+          running = false;  // optimal
+        } else {
+          const int pl = key32_payload(best32);
+          src = pl & 63;
+          kind = (src >= NV) ? 2 : (pl >> 6) & 1;
+          need_sel = false;
+        }
+      }
+    }
+    if (running) {
+      if (++it > max_iter) {
+        status = STATUS_MAX_ITER;
+        running = false;
+      }
+    }
+    if (!wave_any(running)) break;
+    const bool act = running;
+    PINKHIP_TICK(3);  // selection
+
+    // (b) column src of T: col_m = sum_j T[m][j] [j == src]
+    double col;
+    {
+      const BcT eb = bcast_indicator<W>(act ? src : -1);
+      double c0 = 0.0, c1 = 0.0;
+      static_for<0, NT>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
+        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+      });
+      col = c0 + c1;
+    }
+    if (li == src) col = tdiag;
+    // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
+    // entering row; pv = T[src][src] = -n^T Z n
+    const double cand = (li < NV) ? ((kind == 0 ? lbv : ubv) - x) : -u;
+    const double num = group_bcast<W>(cand, src);
+    double pv = group_bcast<W>(tdiag, src);
+    bool lin_dep = false;
+    if constexpr (DENSE) {
+      // an entering normal that depends on the active ones has no curvature left (a coordinate too, once dense rows
+      // are active).  The reduced curvature n^T Z n is what successive pivots leave of n^T H^-1 n: its round-off
+      // floor is ~1e-15 n^T H^-1 n (ik_kernels_packed.h forms it as a sum of squares and can test against 1e-24).
+      const double z0 = group_bcast<W>(zd0, src);
+      lin_dep = !(-pv * 1e10 > z0);
+    }
+    if (!act) pv = -1.0;
+    PINKHIP_TICK(4);  // column
+    // (c) step: the driving parameter nu (multiplier of the entering constraint) moves every quantity along the
+    // column: free coordinates x -= col nu, multipliers of fixed coordinates u -= phi col nu (phi = -1 at lb, +1 at
+    // ub), multipliers of active rows / slacks of inactive rows u -= col nu.  Full step: the entering constraint
+    // becomes tight, nu = num / (-pv); it is cut short where the first multiplier reaches zero.
+    const double rz = lin_dep ? 0.0 : fast_rcp1(-pv);
+    const double sgn = (num >= 0.0) ? 1.0 : -1.0;
+    const double full = lin_dep ? INF : fabs(num) * rz;
+    double phi = 0.0;
+    if (li < NV) phi = (state == 1) ? -1.0 : (state == 2 ? 1.0 : 0.0);
+    else if (DENSE && state == 1) phi = (dr >= n_eq) ? 1.0 : 0.0;  // equalities never leave
+    const double rate = phi * col * sgn;
+    const bool blocking = act && rate > 0.0;
+    const double ratio = blocking ? (u > 0.0 ? u * fast_rcp1(rate) : 0.0) : BIG;
+    const double k1 = group_min<W>(ratio);
+    const int kd = group_first_lane<W>(blocking && ratio == k1) & (W - 1);
+    const double t1 = (k1 < BIG) ? k1 : INF;
+    const double tstep = (t1 < full) ? t1 : full;
+    double hs = 0.0;
+    if constexpr (DENSE) {
+      if (wave_any(act && !(tstep < INF))) hs = group_bcast<W>(hv, src);  // (cross-lane: wave-uniform control flow)
+    }
+    if (act && !(tstep < INF)) {
+      if (DENSE && kind == 3 && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
+        // equality implied by the active ones and already satisfied: nothing to add
+        ++eq_next;
+        need_sel = true;
+      } else {
+        status = STATUS_INFEASIBLE;
+        running = false;
+      }
+    }
+    const bool act2 = act && running && (tstep < INF);
+    const bool do_add = act2 && !(t1 < full);
+    const bool do_drop = act2 && !do_add;
+    if (act2) {
+      const double nu = sgn * tstep;
+      const double d = col * nu;
+      if (li < NV) {
+        if (state == 0) x -= d;
+        else u -= phi * d;
+      } else {
+        u -= d;
+      }
+      uplus += (kind == 3) ? nu : tstep;
+    }
+    PINKHIP_TICK(5);  // step lengths, x / u update
+    // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves; the
+    // entering one stays pending and its column is extracted again from the new tableau)
+    int pi = -1;
+    double pvt = 1.0;
+    if (do_add) {
+      pi = src;
+      pvt = pv;
+      if (li == src) {
+        if (li < NV) {
+          state = kind + 1;
+          x = (kind == 0) ? lbv : ubv;
+        } else {
+          state = 1;
+        }
+        u = uplus;
+      }
+      if (DENSE && kind == 3) ++eq_next;
+      need_sel = true;
+    }
+    if (wave_any(do_drop)) {
+      const BcT eb = bcast_indicator<W>(do_drop ? kd : -1);
+      double c0 = 0.0, c1 = 0.0;
+      static_for<0, NT>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
+        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+      });
+      const double pk = group_bcast<W>(tdiag, kd);
+      if (do_drop) {
+        col = (li == kd) ? tdiag : c0 + c1;
+        pi = kd;
+        pvt = pk;
+        if (li == kd) {
+          state = 0;
+          u = 0.0;
+        }
+      }
+    }
+    PINKHIP_TICK(6);  // column of the leaving constraint
+    {
+      // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
+      // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
+      const bool piv = pi >= 0;
+      const double sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
+      const double rp = fast_rcp(pvt);
+      double t = piv ? col * rp : 0.0;
+      double cp = piv ? col : 0.0;
+      if (li == pi) {
+        // lane pi: its row becomes sg col / p -- as T[pi][j] - (1 - sg / p) col_j -- and the column the other lanes
+        // see at j = pi is p - sg, so that their entry T[m][pi] - t_m (p - sg) becomes sg t_m
+        t = 1.0 - sg * rp;
+        cp = pvt - sg;
+      }
+      const BcT xb = bcast_prepare<W>(cp);
+      const double nt = -t;
+      static_for<0, NT>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        T[j] = fma_bcast<W, j>(T[j], xb, nt);
+      });
+      tdiag = (li == pi) ? -rp : tdiag - t * col;
+    }
+    PINKHIP_TICK(7);  // pivot
+  }
+  PINKHIP_TICK(8);  // exit
+  if constexpr (DENSE) {
+    // The active dense rows hold with equality only as far as the pivots were exact (a row that enters with little
+    // curvature left amplifies round-off by the inverse of what is left).  One correction with the rows as stated:
+    // r = g x - h on the active rows, (x_F, lambda_A) += T_BA r.
+    const bool arow = dlane && state == 1;
+    if (wave_any(arow)) {
+      const BcT xb = bcast_prepare<W>(in ? x : 0.0);
+      const double *gr = a.Gd + (b * (long long)md + (dlane ? dr : 0)) * nv;
+      double r0 = 0.0, r1 = 0.0;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        const double gj = (arow && j < nv) ? gr[j] : 0.0;
+        if constexpr (j % 2 == 0) r0 = fma_bcast<W, j>(r0, xb, gj);
+        else r1 = fma_bcast<W, j>(r1, xb, gj);
+      });
+      const BcT rb = bcast_prepare<W>(arow ? (r0 + r1) - hv : 0.0);
+      double dx = 0.0;
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        dx = fma_bcast<W, NV + d>(dx, rb, T[NV + d]);
+      });
+      if (in && state == 0) x += dx;
+    }
+  }
+
+  // ------------------------------------------------------------------ write-out
+  if constexpr (Src::kOnTheFly) {
+    terms->x = in ? x : 0.0;
+    terms->status = status;
+  }
+  if (valid) {
+    if (in) late->dq[b * (long long)nv + li] = x;
+    if (li == 0) {
+      late->status[b] = status;
+      if (late->iters) late->iters[b] = it;
+    }
+  }
+}
+
+template <int NV, int MD, int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_SWEEP(NV + MD) ik_solve_sweep_kernel(KernelArgs a) {
+  ik_sweep_instance<NV, MD, W>(a, block_id());
+}
+
+}  // namespace pinkhip

@@ -10,7 +10,15 @@
 #define PINKHIP_PASTE4(a, b, c) a##b##_##c
 #define PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W) PINKHIP_PASTE4(launch_rollout_, NV, W)
 
+#define PINKHIP_PASTE6(a, b, c, d) a##b##_##c##_##d
+#define PINKHIP_LAUNCH_SWEEP_NAME(NV, MD, W) PINKHIP_PASTE6(launch_sweep_, NV, MD, W)
+
 namespace pinkhip {
+
+// tu_sweep.hip: the sweep-tableau stack + solve kernel, one launcher per entry of PINKHIP_SWEEP_TABLE
+#define PINKHIP_DECLARE(NV, MD, W) hipError_t PINKHIP_LAUNCH_SWEEP_NAME(NV, MD, W)(hipStream_t stream, const KernelArgs &a);
+PINKHIP_SWEEP_TABLE(PINKHIP_DECLARE)
+#undef PINKHIP_DECLARE
 
 #define PINKHIP_DECLARE(NV, W)                                                                  \
   hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(hipStream_t stream, const KernelArgs &a);     \

@@ -117,7 +117,24 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
     }
     return fail(h, PINKHIP_E_INVALID, "unsupported nv");
   }
-  // stack + solve: the instantiation chosen by dispatch.h, each one its own translation unit (tu_packed.hip)
+  // stack + solve: the instantiation chosen by dispatch.h, each one its own translation unit.  The sweep-tableau
+  // kernel (ik_sweep.h, tu_sweep.hip) serves every problem it is instantiated for; the Goldfarb-Idnani kernel
+  // (ik_kernels_packed.h, tu_packed.hip) the rest: 8-lane groups (nv <= 8), more dense rows than lanes are left.
+  static const char *solver_env = std::getenv("PINKHIP_SOLVER");  // development: "packed" = Goldfarb-Idnani kernel only
+  const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
+  if (sc.NV && !(solver_env && std::strcmp(solver_env, "packed") == 0)) {
+    hipError_t es = hipErrorInvalidValue;
+    switch (sc.NV * 100 + sc.MD) {
+#define PINKHIP_CASE(NV, MD, W)                                            \
+  case NV * 100 + MD:                                                      \
+    es = pinkhip::PINKHIP_LAUNCH_SWEEP_NAME(NV, MD, W)(h->stream, a);      \
+    break;
+      PINKHIP_SWEEP_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    }
+    PH_HIP(h, es);
+    return PINKHIP_OK;
+  }
   const pinkhip::PackedChoice pc = pinkhip::select_packed(a.nv, a.md);
   static const bool force_dense = std::getenv("PINKHIP_FORCE_DENSE") != nullptr;  // development: time the dense-row instantiation on a batch without dense rows
   hipError_t e = hipErrorInvalidValue;

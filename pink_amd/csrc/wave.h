@@ -41,6 +41,12 @@
 #define PINKHIP_OCCUPANCY_PACKED(NV, DENSE) \
   __attribute__((amdgpu_waves_per_eu(PINKHIP_PACKED_WAVES2(NV, DENSE), PINKHIP_PACKED_WAVES2(NV, DENSE))))
 
+// sweep-tableau kernel (ik_sweep.h): NT = NV + MD doubles of tableau per lane + ~20 doubles of state, no LDS
+#ifndef PINKHIP_SWEEP_WAVES
+#define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 6 : (NT) <= 24 ? 5 : (NT) <= 32 ? 4 : (NT) <= 58 ? 3 : 2)
+#endif
+#define PINKHIP_OCCUPANCY_SWEEP(NT) __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEP_WAVES(NT), PINKHIP_SWEEP_WAVES(NT))))
+
 // whole-control-step kernel: the kinematics part needs more registers than the solve of the small sizes (12-dof
 // arm, 65 536 robots: 0.136 ms per step at four waves per SIMD with 57 spilled registers, 0.120 ms at three)
 #ifndef PINKHIP_ROLLOUT_WAVES_SMALL
@@ -268,6 +274,9 @@ __device__ __forceinline__ double fast_rsqrt1(double x) {
   return fma(0.5 * y, e, y);
 }
 
+// hardware reciprocal seed only (~2^-26 relative... v_rcp_f64 gives ~1e-8): for keys that merely rank candidates
+__device__ __forceinline__ double approx_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
 
@@ -371,6 +380,19 @@ __device__ __forceinline__ Bcast<W> bcast_scale(const Bcast<W> &b, double s) {
   else asm volatile("s_nop 1" : "+v"(o.r[0]), "+v"(o.r[1]), "+v"(o.r[2]), "+v"(o.r[3]));
   return o;
 }
+// bcast_prepare(li == src ? 1.0 : 0.0) for a group-uniform src without the permlane swaps: row copy k of a lane is
+// the value of the group's lane 16 k + (lane % 16), which every lane can tell from src alone (src < 0: all zero)
+template <int W>
+__device__ __forceinline__ Bcast<W> bcast_indicator(int src) {
+  Bcast<W> b;
+  const int l16 = lane_id() & 15;
+#pragma unroll
+  for (int k = 0; k < W / 16; ++k) b.r[k] = (l16 + 16 * k == src) ? 1.0 : 0.0;
+  if constexpr (W == 16) asm volatile("s_nop 1" : "+v"(b.r[0]));
+  else if constexpr (W == 32) asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]));
+  else asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]));
+  return b;
+}
 template <int W, int J>
 __device__ __forceinline__ double fma_bcast(double acc, const Bcast<W> &b, double x) {
   static_assert(J >= 0 && J < W, "source lane outside the group");
@@ -418,7 +440,9 @@ __device__ __forceinline__ double group_min(double v) {
 // v_min_f32_dpp per butterfly step.  Only for *choosing* a lane where any candidate is a valid choice (the
 // most violated constraint); exact values are fetched from the winner afterwards.
 __device__ __forceinline__ float key32_pack(double v, int payload) {
-  const float f = static_cast<float>(v);
+  // keys are negative; clamped into the normal floats so that neither -inf | payload (a NaN that v_min_f32 drops)
+  // nor -0.0f (which reads as "none") can come out of the cast
+  const float f = fmaxf(fminf(static_cast<float>(v), -1.17549435e-38f), -3.0e38f);
   return __int_as_float((__float_as_int(f) & ~0xFF) | (payload & 0xFF));
 }
 __device__ __forceinline__ int key32_payload(float k) { return __float_as_int(k) & 0xFF; }

@@ -6,6 +6,7 @@
 #include "../../pink_amd/csrc/ik_common.h"
 #include "../../pink_amd/csrc/dispatch.h"
 #include "../../pink_amd/csrc/ik_kernels_packed.h"
+#include "../../pink_amd/csrc/ik_sweep.h"
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/ik_frame_task.h"
 #include "../../pink_amd/csrc/ik_kinematics.h"
@@ -27,6 +28,11 @@ void lane_main_packed(void *p) {
     pinkhip::ik_packed_instance<NV, W, false>(*a, pinkhip::block_id());
   else
     pinkhip::ik_packed_instance<NV, W, true>(*a, pinkhip::block_id());
+}
+
+template <int NV, int MD, int W>
+void lane_main_sweep(void *p) {
+  pinkhip::ik_sweep_instance<NV, MD, W>(*static_cast<const KernelArgs *>(p), pinkhip::block_id());
 }
 
 template <int TP>
@@ -102,9 +108,22 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
       case 3: fn = lane_main_stack_mfma<3>; break;
       case 4: fn = lane_main_stack_mfma<4>; break;
     }
-  } else {  // the dispatch rule of the library (dispatch.h)
+  } else {  // the dispatch rule of the library (dispatch.h, pinkhip.hip launch())
+    const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
+    const char *force = std::getenv("PINKHIP_SOLVER");  // "packed": the Goldfarb-Idnani kernel for every problem
+    if (sc.NV && !(force && std::string(force) == "packed")) {
+      switch (sc.NV * 100 + sc.MD) {
+#define PINKHIP_CASE(NV, MD, W)                \
+  case NV * 100 + MD:                          \
+    fn = lane_main_sweep<NV, MD, W>;           \
+    blocks = (d->B + 64 / W - 1) / (64 / W);   \
+    break;
+        PINKHIP_SWEEP_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+      }
+    }
     const pinkhip::PackedChoice pc = pinkhip::select_packed(a.nv, a.md);
-    switch (pc.NV) {
+    if (!fn) switch (pc.NV) {
 #define PINKHIP_CASE(NV, W)          \
   case NV:                           \
     fn = lane_main_packed<NV, W>;    \

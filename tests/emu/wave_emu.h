@@ -25,6 +25,7 @@
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV, DENSE)
+#define PINKHIP_OCCUPANCY_SWEEP(NT)
 #define PINKHIP_OCCUPANCY_ROLLOUT(NV)
 #define PINKHIP_OCCUPANCY_FK
 #define PINKHIP_OCCUPANCY_SMALL_STACK
@@ -181,6 +182,7 @@ inline void fast_sincos(double t, double &sn, double &cs) {
 inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline double fast_rcp1(double x) { return 1.0 / x; }
+inline double approx_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt1(double x) { return 1.0 / std::sqrt(x); }
 
 inline bool wave_any(bool p) {
@@ -246,6 +248,10 @@ template <int W>
 inline Bcast<W> bcast_scale(const Bcast<W> &b, double s) {
   return Bcast<W>{b.v * s};
 }
+template <int W>
+inline Bcast<W> bcast_indicator(int src) {
+  return Bcast<W>{((emu().cur & (W - 1)) == src) ? 1.0 : 0.0};
+}
 template <int W, int J>
 inline double fma_bcast(double acc, const Bcast<W> &b, double x) {
   static_assert(J >= 0 && J < W, "");
@@ -277,7 +283,7 @@ inline double group_min(double v) {
 }
 // 32-bit arg-min key (wave.h): float with the payload in its low 8 mantissa bits
 inline float key32_pack(double v, int payload) {
-  const float f = static_cast<float>(v);
+  const float f = std::fmax(std::fmin(static_cast<float>(v), -1.17549435e-38f), -3.0e38f);
   int b;
   std::memcpy(&b, &f, 4);
   b = (b & ~0xFF) | (payload & 0xFF);
