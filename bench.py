@@ -339,7 +339,7 @@ def main() -> None:
     from pink_amd.sharding import shard_bounds
 
     # the library travels prebuilt; if it is stale only rank 0 rebuilds it (hipcc), the others wait
-    if rank == 0:
+    if rank == 0 and "PINKHIP_LIBRARY" not in os.environ:  # (a development library is used as it is)
         g.build_hip()
     rdzv.barrier()
     if args.scaling == "strong":

@@ -52,6 +52,15 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 
 namespace pinkhip {
 
+// LDS of one QP (doubles): the stated problem, parked for the closing refinement step
+template <int NV, int MD, int W>
+struct SweepLds {
+  static __host__ __device__ constexpr int tri(int i) { return i * (i + 1) / 2; }  // H[i][0..i]
+  static constexpr int oC = (NV * (NV + 1) / 2 + 1) & ~1;                            // c, one entry per lane
+  static constexpr int oG = oC + W;                                                  // G[d][li] at d W + li
+  static constexpr int stride = oG + MD * W;
+};
+
 template <int NV, int MD, int W, class Src = HbmTerms>
 __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
   constexpr int NT = NV + MD;
@@ -125,10 +134,28 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       }
     }
   }
-  diag += dadd;
+  diag += dadd;  // (per lane from here on: what H[li][li] holds beyond the dense task rows; kept for the refinement)
 #pragma unroll
   for (int j = 0; j < NV; ++j)
     if (j == li) T[j] += in ? diag : 1.0;  // padded coordinates: identity rows, never pivoted
+  // The QP as stated -- H (lower triangle, packed), c and the columns of G -- is needed once more, by the refinement
+  // step that closes the iteration: parked in LDS (the kernel's only use of it; in the whole-step kernel the region
+  // overlays the kinematics scratch, which is dead by now), not carried through the loop in registers.
+  using SL = SweepLds<NV, MD, W>;
+  double *sm = shared_base() + (long long)g * (a.lds_pitch ? a.lds_pitch : SL::stride);
+  wave_sync();  // (whole-step kernel: every lane is done reading the kinematics scratch)
+  if (li < NV) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (j <= li) sm[SL::tri(li) + j] = T[j];
+  }
+  sm[SL::oC + li] = ci;
+  if constexpr (DENSE) {
+    static_for<0, MD>([&](auto Dc) {
+      constexpr int d = decltype(Dc)::value;
+      sm[SL::oG + d * W + li] = (li < NV) ? T[NV + d] : 0.0;
+    });
+  }
   PINKHIP_TICK(0);  // stacking
 
   // ------------------------------------------------------------------ sweep in every coordinate: T = [-H^-1 ...]
@@ -164,6 +191,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
 #pragma unroll
   for (int j = 0; j < NT; ++j)
     if (j == li) tdiag = T[j];
+
   // x0 = -H^-1 c = T_BB c; the same product gives the rows of G: slack = h - G x0 = h + (T c)_row
   double x = 0.0, u = 0.0;
   {
@@ -183,8 +211,11 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   PINKHIP_TICK(2);  // x0
 
   // ------------------------------------------------------------------ dual active set on the tableau
+  // The kernel arguments that are only needed from here on (bounds, iteration cap, the task rows of the refinement,
+  // output pointers) are re-read from the kernarg segment through an opaque pointer where they are used: carried in
+  // scalar registers across the loop they spill (v_writelane / v_readlane inside every trip).
   const KernelArgs *late = &a;
-  if constexpr (NT > 32 && !Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
+  if constexpr (!Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
   double lbv, ubv;
   if constexpr (Src::kOnTheFly) {
     lbv = in ? terms->lb : -INF;
@@ -207,6 +238,49 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   double uplus = 0.0;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
+  bool refined = false;  // the closing refinement step of this group has been taken
+
+  // ------------------------------------------------------------------ one step of iterative refinement
+  // The tableau is an explicitly updated inverse: after ~60 pivots x carries cond(H) eps times a growth factor
+  // (measured 2e-13 at nv = 30, 4e-10 on the JVRC-shaped batch, against 5e-15 of an orthogonal factorisation).  One
+  // Newton step on the KKT system of the final active set, with the residual formed from the problem AS STATED (H, c,
+  // G as they were stacked, parked in LDS; not the tableau), restores full accuracy: r_F = (H x + G_A^T lambda_A + c)_F on the free
+  // coordinates, r_A = G_A x - h_A on the active rows, (x_F, lambda_A) += T_BB r.  The step is taken INSIDE the loop,
+  // in the trip in which a group finds no violated constraint left: the product with T is the one every trip forms
+  // anyway (with r in the place of the indicator of the entering column), and T never has to outlive the loop (when it
+  // did, the register allocator kept two copies of it and moved one onto the other in every trip).
+  auto residual = [&]() -> double {
+    const double xl = in ? x : 0.0;
+    const BcT xb = bcast_prepare<W>(xl);
+    // row li of the stated KKT matrix times x: a coordinate lane reads H[li][j] = H[j][li] from the packed triangle,
+    // the lane of a dense row its row of G (= column entries the coordinate lanes parked)
+    const int base = (li < NV) ? SL::tri(li) : SL::oG + (dlane ? dr : 0) * W;
+    double h0 = 0.0, h1 = 0.0;
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      const int ad = (li < NV && j > li) ? SL::tri(j) + li : base + j;
+      const double hv_ = sm[ad];
+      if constexpr (j % 2 == 0) h0 = fma_bcast<W, j>(h0, xb, hv_);
+      else h1 = fma_bcast<W, j>(h1, xb, hv_);
+    });
+    double r = in ? (h0 + h1) + sm[SL::oC + li] : 0.0;
+    if (state != 0) r = 0.0;  // fixed coordinates: nonbasic
+    if constexpr (DENSE) {
+      if (md > 0) {
+        const bool arow = dlane && state == 1;
+        // + G_A^T lambda_A on the free coordinates
+        const BcT lamb = bcast_prepare<W>(arow ? u : 0.0);
+        double gl = 0.0;
+        static_for<0, MD>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value;
+          gl = fma_bcast<W, NV + d>(gl, lamb, sm[SL::oG + d * W + li]);
+        });
+        if (in && state == 0) r += gl;
+        if (arow) r = (h0 + h1) - hv;  // residual of an active row
+      }
+    }
+    return r;
+  };
 
   for (;;) {
     // (a) entering constraint, for the groups that have none pending: the violated constraint that is farthest away
@@ -262,14 +336,26 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         running = false;
       }
     }
-    if (!wave_any(running)) break;
+    // once no group of the wave is running any more, one closing trip takes the refinement step of all of them
+    const bool ref = !wave_any(running) && !refined;
+    if (!wave_any(running || ref)) break;
     const bool act = running;
     PINKHIP_TICK(3);  // selection
 
-    // (b) column src of T: col_m = sum_j T[m][j] [j == src]
+    // (b) column src of T: col_m = sum_j T[m][j] [j == src]; for a finishing group the product T r instead
     double col;
     {
-      const BcT eb = bcast_indicator<W>(act ? src : -1);
+      BcT eb = bcast_indicator<W>(act ? src : -1);
+      double rres = 0.0, sdiag = 0.0;
+      if (wave_any(ref)) {
+        rres = residual();
+        if (!ref || status != STATUS_OPTIMAL) rres = 0.0;
+        // (the product below meets the unmaintained copy of the diagonal inside T: replaced by the maintained one)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (j == li) sdiag = T[j];
+        eb = bcast_select<W>(ref, bcast_prepare<W>(rres), eb);
+      }
       double c0 = 0.0, c1 = 0.0;
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
@@ -277,7 +363,12 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         else c1 = fma_bcast<W, j>(c1, eb, T[j]);
       });
       col = c0 + c1;
+      if (ref) {
+        if (in && state == 0) x += col + (tdiag - sdiag) * rres;
+        refined = true;
+      }
     }
+    if (!wave_any(act)) break;  // that was the closing trip
     if (li == src) col = tdiag;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
@@ -404,31 +495,6 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     PINKHIP_TICK(7);  // pivot
   }
   PINKHIP_TICK(8);  // exit
-  if constexpr (DENSE) {
-    // The active dense rows hold with equality only as far as the pivots were exact (a row that enters with little
-    // curvature left amplifies round-off by the inverse of what is left).  One correction with the rows as stated:
-    // r = g x - h on the active rows, (x_F, lambda_A) += T_BA r.
-    const bool arow = dlane && state == 1;
-    if (wave_any(arow)) {
-      const BcT xb = bcast_prepare<W>(in ? x : 0.0);
-      const double *gr = a.Gd + (b * (long long)md + (dlane ? dr : 0)) * nv;
-      double r0 = 0.0, r1 = 0.0;
-      static_for<0, NV>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        const double gj = (arow && j < nv) ? gr[j] : 0.0;
-        if constexpr (j % 2 == 0) r0 = fma_bcast<W, j>(r0, xb, gj);
-        else r1 = fma_bcast<W, j>(r1, xb, gj);
-      });
-      const BcT rb = bcast_prepare<W>(arow ? (r0 + r1) - hv : 0.0);
-      double dx = 0.0;
-      static_for<0, MD>([&](auto Dc) {
-        constexpr int d = decltype(Dc)::value;
-        dx = fma_bcast<W, NV + d>(dx, rb, T[NV + d]);
-      });
-      if (in && state == 0) x += dx;
-    }
-  }
-
   // ------------------------------------------------------------------ write-out
   if constexpr (Src::kOnTheFly) {
     terms->x = in ? x : 0.0;

@@ -17,7 +17,10 @@ namespace pinkhip {
 hipError_t PINKHIP_LAUNCH_SWEEP_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKHIP_TU_W)(hipStream_t stream, const KernelArgs &a) {
   constexpr int NV = PINKHIP_TU_NV, MD = PINKHIP_TU_MD, W = PINKHIP_TU_W, G = kWave / W;
   const dim3 grid(static_cast<unsigned>((a.B + G - 1) / G)), block(kWave);
-  hipLaunchKernelGGL((ik_solve_sweep_kernel<NV, MD, W>), grid, block, 0, stream, a);
+  // LDS: the stated problem (H packed, c, columns of G) parked for the closing refinement step
+  using SL = SweepLds<NV, MD, W>;
+  const size_t lds = 8 * static_cast<size_t>(SL::stride) * G + 16;
+  hipLaunchKernelGGL((ik_solve_sweep_kernel<NV, MD, W>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

@@ -43,7 +43,10 @@
 
 // sweep-tableau kernel (ik_sweep.h): NT = NV + MD doubles of tableau per lane + ~20 doubles of state, no LDS
 #ifndef PINKHIP_SWEEP_WAVES
-#define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 6 : (NT) <= 24 ? 5 : (NT) <= 32 ? 4 : (NT) <= 58 ? 3 : 2)
+// (the kernel is VALU-throughput bound from three waves per SIMD on -- rocprofv3: the waves of a SIMD issue VALU
+// instructions ~100 % of the time -- so the budgets are the largest occupancy without spills: NT = 30 at four waves
+// spills 81 registers and takes 0.77 ms per 65 536 against 0.70 ms at three)
+#define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 4 : (NT) <= 40 ? 3 : 2)
 #endif
 #define PINKHIP_OCCUPANCY_SWEEP(NT) __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEP_WAVES(NT), PINKHIP_SWEEP_WAVES(NT))))
 
@@ -392,6 +395,17 @@ __device__ __forceinline__ Bcast<W> bcast_indicator(int src) {
   else if constexpr (W == 32) asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]));
   else asm volatile("s_nop 1" : "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]));
   return b;
+}
+// per-lane choice between two prepared broadcasts (the condition is uniform over each group)
+template <int W>
+__device__ __forceinline__ Bcast<W> bcast_select(bool c, const Bcast<W> &a, const Bcast<W> &b) {
+  Bcast<W> o;
+#pragma unroll
+  for (int k = 0; k < W / 16; ++k) o.r[k] = c ? a.r[k] : b.r[k];
+  if constexpr (W == 16) asm volatile("s_nop 1" : "+v"(o.r[0]));
+  else if constexpr (W == 32) asm volatile("s_nop 1" : "+v"(o.r[0]), "+v"(o.r[1]));
+  else asm volatile("s_nop 1" : "+v"(o.r[0]), "+v"(o.r[1]), "+v"(o.r[2]), "+v"(o.r[3]));
+  return o;
 }
 template <int W, int J>
 __device__ __forceinline__ double fma_bcast(double acc, const Bcast<W> &b, double x) {

@@ -118,7 +118,7 @@ def pg_guess(H, c, lb, ub, k, precond=True):
     return state
 
 
-def run_gi(H, c, lb, ub, max_iter=500):
+def run_gi(H, c, lb, ub, max_iter=500, want_state=False):
     """Dual active set on the tableau from the unconstrained minimum; entering rule: violation / sqrt(Z_ii)."""
     n = c.size
     tab = Tableau(H)
@@ -138,6 +138,8 @@ def run_gi(H, c, lb, ub, max_iter=500):
             klo = np.where(tab.free & (slo < -tol * (1 + np.abs(lb))), slo / np.sqrt(np.where(zd > 0, zd, 1)), 0.0)
             kup = np.where(tab.free & (sup < -tol * (1 + np.abs(ub))), sup / np.sqrt(np.where(zd > 0, zd, 1)), 0.0)
             if min(klo.min(), kup.min()) >= 0:
+                if want_state:
+                    return x, trips, tab, state
                 return x, trips
             if klo.min() <= kup.min():
                 i, s = int(np.argmin(klo)), -1

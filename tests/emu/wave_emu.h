@@ -252,6 +252,10 @@ template <int W>
 inline Bcast<W> bcast_indicator(int src) {
   return Bcast<W>{((emu().cur & (W - 1)) == src) ? 1.0 : 0.0};
 }
+template <int W>
+inline Bcast<W> bcast_select(bool c, const Bcast<W> &a, const Bcast<W> &b) {
+  return Bcast<W>{c ? a.v : b.v};
+}
 template <int W, int J>
 inline double fma_bcast(double acc, const Bcast<W> &b, double x) {
   static_assert(J >= 0 && J < W, "");
