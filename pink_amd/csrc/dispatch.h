@@ -18,7 +18,7 @@
 // = NT <= W tableau rows, one per lane.  Ordered by NT within box-only / with dense rows; problems that fit none
 // (8-lane groups, more dense rows than lanes are left) run the Goldfarb-Idnani kernel of PINKHIP_PACKED_TABLE.
 #define PINKHIP_SWEEP_TABLE(X)                                                                                      \
-  X(12, 0, 16) X(16, 0, 16) X(24, 0, 32) X(30, 0, 32) X(32, 0, 32) X(34, 0, 64) X(40, 0, 64) X(48, 0, 64) X(50, 0, 64) \
+  X(8, 0, 16) X(12, 0, 16) X(16, 0, 16) X(24, 0, 32) X(30, 0, 32) X(32, 0, 32) X(34, 0, 64) X(40, 0, 64) X(48, 0, 64) X(50, 0, 64) \
   X(56, 0, 64) X(64, 0, 64)                                                                                         \
   X(12, 4, 16) X(24, 8, 32) X(30, 2, 32) X(30, 8, 64) X(34, 8, 64) X(40, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
@@ -56,14 +56,30 @@ inline SweepChoice select_sweep(int nv, int md) {
   return SweepChoice{0, 0, 0};
 }
 
-// Doubles of LDS per QP of the stack + solve kernel without dense rows (= LdsP<NV>::stride(0), checked at compile
-// time in tu_rollout.hip).
-constexpr int solve_lds_doubles(int NV) { return ((((NV * (NV + 3) / 2 + 1) & ~1) + 5 * NV) + 1) & ~1; }
+// Which of the two stack + solve kernels serves a batch of B problems (measured on MI355X, scripts/ab_solvers.sh):
+// the sweep-tableau kernel wherever it is instantiated, except
+//   * when it needs a wider group than the Goldfarb-Idnani kernel (nv = 30 with six dense rows: 36 tableau rows = one QP
+//     per wavefront against two: 1.75 against 1.46 ms per 65 536), and
+//   * for nv <= 8 in large batches: its smallest group is 16 lanes, the Goldfarb-Idnani kernel packs eight QPs per
+//     wavefront (UR5: 71 against 49 us at B = 65 536, but 13.8 against 18.4 us at B = 4 096, where eight per wavefront
+//     leave half of the 1 024 SIMDs without a wave).
+inline bool prefer_sweep(int nv, int md, long long B) {
+  const SweepChoice sc = select_sweep(nv, md);
+  if (!sc.NV) return false;
+  const PackedChoice pc = select_packed(nv, md);
+  if (!pc.NV) return true;
+  if (nv <= 8) return B <= 16384;
+  return sc.W <= pc.W;
+}
+
+// Doubles of LDS per QP of the sweep-tableau kernel (= SweepLds<NV, MD, W>::stride, checked at compile time in
+// tu_sweep.hip): H packed, c, the columns of G.
+constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + W + MD * W; }
 
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger.
-constexpr int rollout_lds_doubles(int NV, int fk_doubles) {
-  return ((fk_doubles + 1) & ~1) > solve_lds_doubles(NV) ? ((fk_doubles + 1) & ~1) : solve_lds_doubles(NV);
+constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles) {
+  return ((fk_doubles + 1) & ~1) > sweep_lds_doubles(NV, 0, W) ? ((fk_doubles + 1) & ~1) : sweep_lds_doubles(NV, 0, W);
 }
 
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
@@ -75,7 +91,7 @@ inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
   if (nv <= 8) return PackedChoice{0, 0};
 #define PINKHIP_PICK(NV_, W_)                                                                              \
   if (nv <= NV_ && nj <= W_)                                                                               \
-    return 8 * rollout_lds_doubles(NV_, fk_doubles) * (64 / W_) + 16 <= 65536 ? PackedChoice{NV_, W_} : PackedChoice{0, 0};
+    return 8 * rollout_lds_doubles(NV_, W_, fk_doubles) * (64 / W_) + 16 <= 65536 ? PackedChoice{NV_, W_} : PackedChoice{0, 0};
   PINKHIP_ROLLOUT_TABLE(PINKHIP_PICK)
 #undef PINKHIP_PICK
   return PackedChoice{0, 0};

@@ -5,14 +5,14 @@
 //
 // The task Jacobians never exist in memory: the kinematics phase (ik_kinematics.h) leaves, per robot, the world
 // twist of each tangent column in that column's lane and two 3 x 3 blocks per FrameTask in LDS; the stacking of
-// the solve kernel (ik_kernels_packed.h, source policy FkTerms) forms its six rows per task from them with 27
-// FMAs per lane.  Against the two-launch loop (ik_step_kernel writes J, e, lb, ub; ik_solve_packed_kernel reads
-// them back) a step moves ~0.3 kB per robot through HBM instead of ~14 kB.  The kinematics scratch overlays the
-// LDS region of the active-set iteration (dead until stacking is done), so the footprint is the solve kernel's.
+// the solve kernel (ik_stack_rows.h / ik_sweep.h, source policy FkTerms) forms its six rows per task from them with
+// 27 FMAs per lane.  Against the two-launch loop (ik_step_kernel writes J, e, lb, ub; ik_solve_packed_kernel reads
+// them back) a step moves ~0.3 kB per robot through HBM instead of ~14 kB.  The kinematics scratch and the solve
+// kernel's LDS (the stated problem parked for its closing refinement step, written after stacking) overlay each other.
 #pragma once
 
-#include "ik_kernels_packed.h"
 #include "ik_kinematics.h"
+#include "ik_sweep.h"
 
 namespace pinkhip {
 
@@ -56,7 +56,6 @@ struct FkTerms {
 
 template <int NV, int W>
 __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block) {
-  using S = LdsP<NV>;
   constexpr int G = kWave / W;
   const ModelDev &m = a.fk.m;
   const int lane = lane_id();
@@ -72,7 +71,7 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
   t.UV = sm + 12 * (m.nj + m.nf) + ((m.nj + 1) & ~1);  // = Jls of ik_fk_instance
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();
-  ik_packed_instance<NV, W, false, FkTerms<W>>(a.k, block, &t);
+  ik_sweep_instance<NV, 0, W, FkTerms<W>>(a.k, block, &t);
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
   const int st = t.status;  // group-uniform
   const bool isj = li < m.nj;

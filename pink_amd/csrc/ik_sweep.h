@@ -238,7 +238,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   double uplus = 0.0;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
-  bool refined = false;  // the closing refinement step of this group has been taken
+  bool refined = false;  // the closing refinement step(s) of this group have been taken
+  int nref = 0;
 
   // ------------------------------------------------------------------ one step of iterative refinement
   // The tableau is an explicitly updated inverse: after ~60 pivots x carries cond(H) eps times a growth factor
@@ -363,12 +364,18 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         else c1 = fma_bcast<W, j>(c1, eb, T[j]);
       });
       col = c0 + c1;
+      // A correction that is not small (a nearly singular H: T is then a poor inverse, accurate to cond(H) eps) calls
+      // for another step, at most three in all: every step shrinks the residual by the relative accuracy of T.
+      const double dxv = (ref && in && state == 0) ? col + (tdiag - sdiag) * rres : 0.0;
+      const bool more = wave_any(ref) && group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
       if (ref) {
-        if (in && state == 0) x += col + (tdiag - sdiag) * rres;
-        refined = true;
+        x += dxv;
+        refined = !(more && ++nref < 3);
       }
     }
-    if (!wave_any(act)) break;  // that was the closing trip
+    // (a closing trip that asks for another one falls through the rest of the body, everything masked off: a second
+    // back edge -- `continue` -- makes the register allocator keep two copies of T and move one onto the other per trip)
+    if (!wave_any(act || !refined)) break;
     if (li == src) col = tdiag;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n

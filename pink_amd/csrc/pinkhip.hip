@@ -120,9 +120,10 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   // stack + solve: the instantiation chosen by dispatch.h, each one its own translation unit.  The sweep-tableau
   // kernel (ik_sweep.h, tu_sweep.hip) serves every problem it is instantiated for; the Goldfarb-Idnani kernel
   // (ik_kernels_packed.h, tu_packed.hip) the rest: 8-lane groups (nv <= 8), more dense rows than lanes are left.
-  static const char *solver_env = std::getenv("PINKHIP_SOLVER");  // development: "packed" = Goldfarb-Idnani kernel only
+  const char *solver_env = std::getenv("PINKHIP_SOLVER");  // development / tests: "packed" / "sweep" force one kernel
   const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
-  if (sc.NV && !(solver_env && std::strcmp(solver_env, "packed") == 0)) {
+  const bool sweep = solver_env ? (std::strcmp(solver_env, "packed") != 0 && sc.NV != 0) : pinkhip::prefer_sweep(a.nv, a.md, a.B);
+  if (sweep) {
     hipError_t es = hipErrorInvalidValue;
     switch (sc.NV * 100 + sc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                                            \
@@ -765,7 +766,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     return fail(h, PINKHIP_E_INVALID, "bad limit gain / step");
   const pinkhip::PackedChoice pc = pinkhip::select_rollout(md.nv, md.nj, pinkhip::rollout_fk_doubles(md.nj, md.nf));
   if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
-  ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pinkhip::rollout_fk_doubles(md.nj, md.nf));
+  ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, pinkhip::rollout_fk_doubles(md.nj, md.nf));
   ra.k.cost = st->cost;
   ra.k.dq = st->dq;
   ra.k.status = st->status;

@@ -17,7 +17,7 @@ namespace pinkhip {
 
 hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(PINKHIP_TU_NV, PINKHIP_TU_W)(hipStream_t stream, const RolloutArgs &a) {
   constexpr int NV = PINKHIP_TU_NV, W = PINKHIP_TU_W, G = kWave / W;
-  static_assert(solve_lds_doubles(NV) == LdsP<NV>::stride(0), "dispatch.h restates the LDS layout");
+  static_assert(sweep_lds_doubles(NV, 0, W) == SweepLds<NV, 0, W>::stride, "dispatch.h restates the LDS layout");
   const size_t lds = 8 * static_cast<size_t>(a.k.lds_pitch) * G + 16;
   const dim3 grid(static_cast<unsigned>((a.k.B + G - 1) / G)), block(kWave);
   hipLaunchKernelGGL((ik_rollout_kernel<NV, W>), grid, block, lds, stream, a);

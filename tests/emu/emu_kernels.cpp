@@ -110,8 +110,9 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
     }
   } else {  // the dispatch rule of the library (dispatch.h, pinkhip.hip launch())
     const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
-    const char *force = std::getenv("PINKHIP_SOLVER");  // "packed": the Goldfarb-Idnani kernel for every problem
-    if (sc.NV && !(force && std::string(force) == "packed")) {
+    const char *force = std::getenv("PINKHIP_SOLVER");  // "packed" / "sweep": one kernel for every problem it serves
+    const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : pinkhip::prefer_sweep(a.nv, a.md, d->B);
+    if (sweep) {
       switch (sc.NV * 100 + sc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \
@@ -295,7 +296,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   ra.first_failure = st->first_failure;
   ra.step = st->step;
   const pinkhip::PackedChoice pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
-  a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
+  a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
   pinkhip::LaneFn fn = nullptr;
   long long blocks = 0;
   switch (pc.NV) {

@@ -88,3 +88,32 @@ def test_makefile_builds_every_instantiation_of_the_dispatch_table():
     rpairs = re.findall(r"X\((\d+), (\d+)\)", rt)
     rollout = re.search(r"^ROLLOUT\s*:=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).split()
     assert rollout == [f"{nv}_{w}" for nv, w in rpairs] and set(rpairs) <= set(pairs) and all(int(w) >= 16 for _, w in rpairs)
+    # the sweep-tableau kernel: one unit per (NV, MD, W) of PINKHIP_SWEEP_TABLE, NV + MD tableau rows on W lanes
+    src = open(os.path.join(csrc, "dispatch.h")).read()
+    st = src[src.index("#define PINKHIP_SWEEP_TABLE(X)  "):]
+    st = st[:st.index("#endif")]
+    triples = re.findall(r"X\((\d+), (\d+), (\d+)\)", st)
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    sweep = re.search(r"^SWEEP\s*:=\s*(.*?)\nifdef", mk.replace("\\\n", " "), re.M | re.S).group(1).split()
+    assert sweep == [f"{nv}_{md}_{w}" for nv, md, w in triples] and len(triples) >= 20
+    for nv, md, w in triples:
+        assert int(nv) + int(md) <= int(w) and int(nv) % 2 == 0 and int(w) in (16, 32, 64)
+
+
+def test_headline_kernel_has_no_register_spills(built):
+    """Code-generation guard: the fully unrolled register-resident tableau is fragile under the register allocator
+    (a second back edge in the active-set loop once cost 145 register moves per trip and 41 spilled registers: 0.74 ->
+    1.12 ms per 65 536).  The headline instantiation must keep its rows in registers."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kernel_meta.py"),
+                          os.path.join(ROOT, "pink_amd", "csrc", "build", "sweep_30_0_32.o")], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump / llvm-readelf not available: " + out.stderr[-200:])
+    row = [ln for ln in out.stdout.splitlines() if "ik_solve_sweep_kernel<30, 0, 32>" in ln]
+    assert row, out.stdout
+    f = row[0].split()
+    vgpr, vspill = int(f[-7]), int(f[-4])
+    assert vspill == 0 and vgpr <= 168, row[0]
+
