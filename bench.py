@@ -191,10 +191,25 @@ def kernel_ms_of(solver, dev, steps: int, stack: bool = False, repeats: int = 3)
     return statistics.median(out)
 
 
-def measure_config(solver, name: str, B: int, steps: int, parity_sample: int, seed=None, **kw) -> dict:
+def full_parity(terms, batch, res) -> dict:
+    """SURVEY.md 8(d) parity procedure over EVERY instance of the batch (oracle/parity_report.py: the C oracle on the
+    host cores, the checker -- never the thing measured)."""
+    from oracle.parity_report import parity_report
+    from pink_amd import synthetic
+
+    t0 = time.perf_counter()
+    rep = parity_report(lambda lo, hi: synthetic.pink_form(terms.slice(lo, hi)), batch, res.dq, res.status,
+                        nthreads=min(usable_cores(), 64))
+    rep["max_abs_dq_err_vs_oracle"] = rep["max_abs_err"]
+    rep["tolerance"] = 1e-8
+    rep["checker_seconds"] = time.perf_counter() - t0
+    rep["note"] = "oracle = restated Goldfarb-Idnani; QP half parity-unpinned against quadprog (DESIGN.md 4)"
+    return rep
+
+
+def measure_config(solver, name: str, B: int, steps: int, seed=None, **kw) -> dict:
     """One BASELINE configuration on the resident-batch path: kernel time, both rooflines, stack-only kernel,
-    parity of a sample against the oracle."""
-    from oracle import c_oracle
+    parity of the whole batch against the oracle."""
     from pink_amd import synthetic
 
     terms = synthetic.make_terms(name, B, seed=seed, **kw)
@@ -204,8 +219,7 @@ def measure_config(solver, name: str, B: int, steps: int, parity_sample: int, se
     res = solver.download(dev)
     stack_ms = kernel_ms_of(solver, dev, steps, stack=True)
     dev.free()
-    n = min(parity_sample, B)
-    ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms.slice(0, n)), nthreads=min(usable_cores(), 32))
+    parity = full_parity(terms, batch, res)
     it = float(res.iters.mean())
     fl = flops_per_qp(batch, it)
     rate = B / (ms * 1e-3)
@@ -218,13 +232,11 @@ def measure_config(solver, name: str, B: int, steps: int, parity_sample: int, se
         "stack_only": {"kernel_ms": stack_ms, "bytes_per_qp": batch.bytes_per_stack(),
                        "achieved_GBs": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9,
                        "frac": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "parity": {"max_abs_dq_err_vs_oracle": float(np.abs(res.dq[:n] - ref["dq"]).max()), "instances_compared": n,
-                   "oracle_failed": int((ref["status"] != 0).sum()), "tolerance": 1e-8,
-                   "note": "oracle = restated Goldfarb-Idnani; QP half parity-unpinned against quadprog (DESIGN.md 4)"},
+        "parity": parity,
     }
 
 
-def api_level(solver, B: int = 4096) -> dict:
+def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
     """`pink_amd.solve_ik_batch(configurations, tasks, dt)` -- the Python API of the drop-in -- on B configurations
     of a 6-dof arm: with the kinematics evaluated by the device kernels from q (default for B >= 64) and with
     tasks / limits evaluated per configuration on the host as Pink does (on a 256-configuration sample)."""
@@ -255,12 +267,67 @@ def api_level(solver, B: int = 4096) -> dict:
         n = 256
         v_host = solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False)
         t_host = statistics.median(_timed(lambda: solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False), 3, warmup=0))
-        return {"workload": f"6-dof arm, FrameTask + PostureTask, {B} configurations, pink_amd {pink_amd.__version__}",
-                "device_kinematics": {"ms": t_dev * 1e3, "solves_per_s": B / t_dev},
-                "host_evaluated_tasks": {"ms_for_sample": t_host * 1e3, "sample": n, "solves_per_s": n / t_host},
-                "max_abs_velocity_difference_on_sample": float(np.abs(v_dev[:n] - v_host).max())}
+        out = {"workload": f"6-dof arm, FrameTask + PostureTask, {B} configurations, pink_amd {pink_amd.__version__}",
+               "device_kinematics": {"ms": t_dev * 1e3, "solves_per_s": B / t_dev},
+               "host_evaluated_tasks": {"ms_for_sample": t_host * 1e3, "sample": n, "solves_per_s": n / t_host},
+               "max_abs_velocity_difference_on_sample": float(np.abs(v_dev[:n] - v_host).max())}
+        out["headline_shape_arrays"] = api_level_arrays(Bh)
+        return out
     finally:
+        pink_amd.clear_device_cache()
         set_default_solver(None)
+
+
+def api_level_arrays(B: int) -> dict:
+    """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
+    with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
+    array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
+    whole-step kernel, D2H and all Python included)."""
+    from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.lie import SE3
+
+    m = build_chain(24, free_flyer=True, seed=2)
+    frames = ["tool0", "joint_8", "joint_16", "joint_20"]
+    rng = np.random.default_rng(1)
+    q = np.tile(m.neutral(), (B, 1))
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[:, j.idx_q] = rng.uniform(-0.8, 0.8, size=B)
+    tasks = []
+    ref = Configuration(m, q[0])
+    for k, f in enumerate(frames):
+        t = FrameTask(f, 1.0, 1.0 if k == 0 else 0.0, lm_damping=1e-3)
+        T0 = ref.get_transform_frame_to_world(f)
+        # every robot's target: the reference robot's frame pose displaced by a few centimetres
+        t.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)))
+        tasks.append(t)
+    post = PostureTask(cost=1e-1)
+    post.set_target(m.neutral())
+    tasks.append(post)
+    cfgs = ConfigurationBatch(m, q)
+    dt = 5e-3
+    v = solve_ik_batch(cfgs, tasks, dt)  # builds the device state
+    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt), 5)
+    t_call = statistics.median(ts)
+    n = min(B, 16)
+    v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False)
+    return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask, default limits, "
+                        f"B = {B} as ConfigurationBatch, targets as arrays",
+            "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,
+            "bytes_in_per_call": int(q.nbytes + B * len(frames) * 12 * 8), "bytes_out_per_call": int(B * m.nv * 8 + 8 * B),
+            "max_abs_velocity_difference_vs_host_evaluated_tasks_on_sample": float(np.abs(v[:n] - v_host).max()), "sample": n}
+
+
+def _slice_task(task, n):
+    """The first n per-instance targets of a task carrying batched targets (for the host-evaluated cross-check)."""
+    import copy
+
+    t = copy.copy(task)
+    if getattr(t, "target_poses", None) is not None:
+        t.target_poses = t.target_poses[:n]
+    if getattr(t, "target_q_batch", None) is not None:
+        t.target_q_batch = t.target_q_batch[:n]
+    return t
 
 
 def traffic_from_profiles():
@@ -311,6 +378,42 @@ def _device_count() -> int:
     return n.value
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` with no launcher around it (WORLD_SIZE unset): start the N ranks from here, one
+    process per GPU, rendezvous on a free port of 127.0.0.1; rank 0 prints the one JSON line to the inherited stdout.
+    Returns the exit code of the job (non-zero as soon as a rank fails; the other ranks are then stopped)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = list(sys.orig_argv) if getattr(sys, "orig_argv", None) else [sys.executable] + sys.argv
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    deadline = time.time() + 10.0
+                    while time.time() < deadline and any(procs[q].poll() is None for q in pending):
+                        time.sleep(0.2)
+                    for q in pending:
+                        if procs[q].poll() is None:
+                            procs[q].kill()  # exactly the processes started above
+        time.sleep(0.05)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,13 +429,20 @@ def main() -> None:
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the launcher of N ranks (one per GPU) instead of silently running one
+        have = _device_count()
+        if have < args.gpus and os.environ.get("PINKHIP_ALLOW_SHARED_DEVICE") != "1":
+            raise SystemExit(f"--gpus {args.gpus} but {have} device(s) visible (PINKHIP_ALLOW_SHARED_DEVICE=1 lets ranks share one)")
+        raise SystemExit(self_launch(args.gpus))
+
     from pink_amd.comm import HostComm, HostRendezvous, RcclComm
 
     rdzv = HostRendezvous.from_env()
     rank, world = rdzv.rank, rdzv.world
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
 
     import __graft_entry__ as g
     from pink_amd import batch_solver, synthetic
@@ -383,6 +493,13 @@ def main() -> None:
     elapsed = rdzv.allreduce_max(time.perf_counter() - t0)
 
     res = solver.download(dev)
+    # what a host-fed job sees per rank: H2D + kernel + D2H through pinkhip_solve_host from pageable buffers, all ranks
+    # at once (they share the host's PCIe / memory bandwidth: SURVEY.md 8(e) "report kernel-only and end-to-end")
+    e2e_ranks = None
+    if not args.headline_only:
+        barrier()
+        e2e_ms = statistics.median(_timed(lambda: solver.solve(batch), 3)) * 1e3
+        e2e_ranks = [float(np.frombuffer(b, dtype=np.float64)[0]) for b in rdzv.allgather_bytes(np.float64(e2e_ms).tobytes())]
     n_bad = int(rdzv.allreduce_sum(float((res.status != 0).sum())))
     kernel_ms_ranks = [float(np.frombuffer(b, dtype=np.float64)[0]) for b in rdzv.allgather_bytes(np.float64(kernel_ms).tobytes())]
 
@@ -453,14 +570,17 @@ def main() -> None:
                 d2 = solver.upload(synthetic.pack(t2))
                 ms2 = kernel_ms_of(solver, d2, 5)
                 r2 = solver.download(d2)
+                b2 = synthetic.pack(t2)
                 regimes[label] = {"kernel_ms": ms2, "solves_per_s": B / (ms2 * 1e-3), "iters_mean": float(r2.iters.mean()),
-                                  "failed": int((r2.status != 0).sum())}
+                                  "failed": int((r2.status != 0).sum()),
+                                  "parity": None if args.no_cpu_baseline else full_parity(t2, b2, r2)}
                 d2.free()
+                del b2
             extra["other_regimes"] = regimes
             # BASELINE configs 2 and 4 in the same line
             extra["configs"] = {
-                "ur5_B4096": measure_config(solver, "ur5", 4096 if B >= 4096 else B, 20, 1024, bounds="tight", jacobians="dense"),
-                "jvrc_B65536": measure_config(solver, "jvrc", 65536 if B >= 4096 else B, 5, 512, bounds="tight", jacobians="dense"),
+                "ur5_B4096": measure_config(solver, "ur5", 4096 if B >= 4096 else B, 20, bounds="tight", jacobians="dense"),
+                "jvrc_B65536": measure_config(solver, "jvrc", 65536 if B >= 4096 else B, 5, bounds="tight", jacobians="dense"),
             }
             # C-ABI call from host buffers: H2D + kernel + D2H (pinkhip_solve_host), and a batch of one (config 1)
             bytes_in = int(sum(a.nbytes for _, a in dev.args.streams()))
@@ -485,7 +605,7 @@ def main() -> None:
             # Pink's own calling pattern, batched: solve_ik_batch on Configuration objects (BASELINE config 2's shape:
             # 6-dof arm, 1 FrameTask + PostureTask, one target per instance)
             try:
-                extra["api_solve_ik_batch"] = api_level(solver)
+                extra["api_solve_ik_batch"] = api_level(solver, Bh=65536 if B >= 4096 else B)
             except Exception as exc:  # noqa: BLE001  never lose the bench line
                 extra["api_solve_ik_batch"] = {"failed": repr(exc)}
 
@@ -515,13 +635,14 @@ def main() -> None:
                             f"box limits, md={batch.md} barrier rows, B={B} per GPU, bounds={args.bounds}, jacobians={args.jacobians}",
                 "batch_per_gpu": B, "global_batch": global_batch, "nv": nv, "Kd": batch.Kd, "K": batch.K, "md": batch.md,
                 "parallelism": f"batch-sharded x{world}",
-                "solver": "Goldfarb-Idnani dual active set, HIP fp64, 64/W QPs per wavefront (W = 32 lanes per QP at nv = 30)",
+                "solver": "dual active set (Goldfarb-Idnani logic) on a register-resident sweep tableau, HIP fp64, 64/W QPs per "
+                          "wavefront (W = 32 lanes per QP at nv = 30), closing iterative-refinement step",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "ik_solve_packed_kernel", "kernel_ms": kernel_ms, "bytes_per_qp": bytes_qp,
-                "note": "fused stack+solve is fp64-VALU-issue bound, not HBM bound (see roofline_fp64; DESIGN.md 3.1); "
+                "kernel": "ik_solve_sweep_kernel", "kernel_ms": kernel_ms, "bytes_per_qp": bytes_qp,
+                "note": "fused stack+solve is VALU-issue bound, not HBM bound (see roofline_fp64; DESIGN.md 3.1); "
                         "stack_only is the HBM-streaming kernel",
             },
             "roofline_fp64": {
@@ -531,18 +652,17 @@ def main() -> None:
             },
             "solver_stats": {"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())},
             "per_rank_kernel_ms": kernel_ms_ranks,
+            "per_rank_end_to_end_ms": e2e_ranks,
+            "end_to_end_solves_per_s_all_ranks": None if not e2e_ranks else global_batch / (max(e2e_ranks) * 1e-3),
             "gather": gather,
             "comm_note": comm_note,
             "device": info.get("gcn_arch"),
         }
         line.update(extra)
         if not args.no_cpu_baseline:
-            base, ref, n = cpu_baseline(terms)
+            base, _, _ = cpu_baseline(terms)
             line["cpu_baseline"] = base
-            # the sample is the head of rank 0's batch: report parity on it
-            line["parity"] = {"max_abs_dq_err_vs_oracle": float(np.abs(res.dq[:n] - ref["dq"]).max()),
-                              "instances_compared": n, "tolerance": 1e-8,
-                              "note": "oracle = restated Goldfarb-Idnani; QP half parity-unpinned against quadprog (DESIGN.md 4)"}
+            line["parity"] = full_parity(terms, batch, res)  # every instance of rank 0's batch
         print(json.dumps(line), flush=True)
     if abandoned:  # a thread of this process may still sit inside an RCCL call: no orderly teardown
         sys.stdout.flush()

@@ -77,11 +77,13 @@ def kkt_residuals(H, c, lb, ub, dq, Gd=None, hd=None, n_eq: int = 0):
     return stat, viol, sign
 
 
-def parity_report(pf: dict, batch, dq: np.ndarray, status: np.ndarray, nthreads: int = 0, chunk: int = 16384,
+def parity_report(pf, batch, dq: np.ndarray, status: np.ndarray, nthreads: int = 0, chunk: int = 8192,
                   H_gpu: Optional[np.ndarray] = None) -> dict:
-    """Compare EVERY instance of ``(dq, status)`` with the C oracle solving ``pf`` (the Pink-form arrays of the same
-    batch, ``synthetic.pink_form`` / ``tests.cases``); ``batch`` is the packed batch (box + dense rows) of the same
-    instances.  Chunked so that the oracle's (H, c) of a big batch need not sit in memory at once."""
+    """Compare EVERY instance of ``(dq, status)`` with the C oracle solving ``pf`` -- the Pink-form arrays of the same
+    batch (``synthetic.pink_form`` / ``tests.cases``), or a callable ``pf(lo, hi)`` that builds them for a slice
+    (the Pink form of 65 536 JVRC-shaped instances is ~7 GB: every limit as dense ``[P; -P]`` rows); ``batch`` is the
+    packed batch (box + dense rows) of the same instances.  Chunked so that neither the Pink form nor the oracle's
+    (H, c) of a big batch sit in memory at once."""
     B = dq.shape[0]
     rep = dict(instances_compared=0, max_abs_err=0.0, max_rel_err=0.0, status_mismatch=0, active_set_equal=0,
                kkt_stationarity_max=0.0, kkt_violation_max=0.0, kkt_multiplier_sign_max=0.0, oracle_iters_mean=0.0)
@@ -91,8 +93,9 @@ def parity_report(pf: dict, batch, dq: np.ndarray, status: np.ndarray, nthreads:
     it_sum = 0
     for lo in range(0, B, chunk):
         hi = min(B, lo + chunk)
-        ref = c_oracle.solve_ik_batch(**_slice(pf, lo, hi, B), want_Hc=True, nthreads=nthreads, meq=n_eq) if n_eq else \
-            c_oracle.solve_ik_batch(**_slice(pf, lo, hi, B), want_Hc=True, nthreads=nthreads)
+        pfc = pf(lo, hi) if callable(pf) else _slice(pf, lo, hi, B)
+        ref = c_oracle.solve_ik_batch(**pfc, want_Hc=True, nthreads=nthreads, meq=n_eq)
+        del pfc
         hist_ref += np.bincount(ref["status"], minlength=4)[:4]
         it_sum += int(ref["iters"].sum())
         x, st = dq[lo:hi], status[lo:hi]

@@ -9,13 +9,14 @@ __version__ = "0.1.0"
 
 from .batch import IKBatch, pack_terms
 from .batch_solver import BatchResult, BatchSolver
-from .configuration import Configuration, Model, build_chain, load_urdf
+from .configuration import Configuration, ConfigurationBatch, Model, build_chain, load_urdf
 from .exceptions import NoSolutionFound, NotWithinConfigurationLimits, PinkError, TargetNotSet
-from .solve_ik import build_ik, pack_configurations, solve_ik, solve_ik_batch
+from .sharding import MultiDeviceSolver
+from .solve_ik import build_ik, clear_device_cache, pack_configurations, solve_ik, solve_ik_batch
 from .tasks import DampingTask, FrameTask, PostureTask, Task
 
 __all__ = [
-    "BatchResult", "BatchSolver", "Configuration", "DampingTask", "FrameTask", "IKBatch", "Model", "NoSolutionFound",
-    "NotWithinConfigurationLimits", "PinkError", "PostureTask", "TargetNotSet", "Task", "build_chain", "build_ik",
+    "BatchResult", "BatchSolver", "Configuration", "ConfigurationBatch", "DampingTask", "FrameTask", "IKBatch", "Model", "MultiDeviceSolver", "NoSolutionFound",
+    "NotWithinConfigurationLimits", "PinkError", "PostureTask", "TargetNotSet", "Task", "build_chain", "build_ik", "clear_device_cache",
     "load_urdf", "pack_configurations", "pack_terms", "solve_ik", "solve_ik_batch",
 ]

@@ -89,6 +89,14 @@ class BatchSolver:
         self._h = h
         self.device_id = device_id
 
+    @staticmethod
+    def sharded(device_ids, solver_factory=None):
+        """A :class:`pink_amd.sharding.MultiDeviceSolver` over these GPUs: same ``solve(batch)``, the batch cut into
+        contiguous shards, one handle + stream + host thread per device, all in this process."""
+        from .sharding import MultiDeviceSolver
+
+        return MultiDeviceSolver(device_ids, solver_factory)
+
     # -- plumbing --------------------------------------------------------------
     def _check(self, rc: int) -> None:
         if rc != 0:
@@ -139,6 +147,11 @@ class BatchSolver:
             dq, status, iters = out.dq, out.status, out.iters
             if dq.shape != (B, nv) or status.shape != (B,) or iters.shape != (B,):
                 raise ValueError("out has the wrong shape")
+            # the library writes through the raw pointers: anything but contiguous, writable float64 / int32 / int32
+            # arrays would be corrupted or misread silently
+            for name, arr, dt in (("dq", dq, np.float64), ("status", status, np.int32), ("iters", iters, np.int32)):
+                if not isinstance(arr, np.ndarray) or arr.dtype != dt or not arr.flags.c_contiguous or not arr.flags.writeable:
+                    raise ValueError(f"out.{name} must be a C-contiguous, writable {np.dtype(dt).name} array")
         else:
             dq = np.zeros((B, nv))
             status = np.zeros(B, dtype=np.int32)

@@ -247,7 +247,7 @@ class Configuration:
         self.oMf = [(SE3() if f.joint < 0 else self.oMi[f.joint]) * f.placement for f in m.frames]
 
     def check_limits(self, tol: float = 1e-6, safety_break: bool = True) -> None:
-        """``configuration.py:166-201``: raise (or warn) on the first violated joint limit."""
+        """``configuration.py:166-201``: raise on the first violated joint limit, or (``safety_break=False``) warn about every one."""
         m = self.model
         lo, up = m.lowerPositionLimit, m.upperPositionLimit
         root = m.root_joint
@@ -255,8 +255,7 @@ class Configuration:
         q = self.q
         bad = np.nonzero((up > lo + tol) & ((q < lo - tol) | (q > up + tol)))[0]
         bad = bad[bad >= start]
-        if bad.size:
-            i = int(bad[0])
+        for i in (int(k) for k in bad):  # raise on the first, or warn about each (configuration.py:183-201)
             if safety_break:
                 raise NotWithinConfigurationLimits(i, q[i], lo[i], up[i])
             logging.warning("Value %f at index %d is out of limits: [%f, %f]", q[i], i, lo[i], up[i])
@@ -316,6 +315,42 @@ class Configuration:
 # ---------------------------------------------------------------------------
 # builders
 # ---------------------------------------------------------------------------
+
+
+class ConfigurationBatch:
+    """``B`` configurations of one model as ONE array ``q [B, nq]``: what :func:`pink_amd.solve_ik_batch` takes in the
+    place of a list of :class:`Configuration` objects when forward kinematics, task rows and limits are evaluated by
+    the device kernels -- no per-instance Python object, no per-instance loop.  Indexing yields a
+    :class:`Configuration` (built on demand) so that host-evaluated tasks / limits still work on it."""
+
+    def __init__(self, model: Model, q: np.ndarray):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if q.ndim != 2 or q.shape[1] != model.nq:
+            raise ValueError(f"q must have shape [B, nq = {model.nq}], got {q.shape}")
+        self.model, self.q = model, q
+
+    def __len__(self) -> int:
+        return self.q.shape[0]
+
+    def __getitem__(self, b):
+        if isinstance(b, slice):
+            return ConfigurationBatch(self.model, self.q[b])
+        return Configuration(self.model, q=self.q[b])
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+    def check_limits(self, tol: float = 1e-6, safety_break: bool = True) -> None:
+        """``Configuration.check_limits`` (``pink/configuration.py:166-201``) over the batch, vectorised."""
+        m = self.model
+        lo, up = m.lowerPositionLimit, m.upperPositionLimit
+        start = m.root_joint.nq if m.root_joint is not None else 0
+        bad = (up > lo + tol) & ((self.q < lo - tol) | (self.q > up + tol))
+        bad[:, :start] = False
+        for b, i in zip(*(v.tolist() for v in np.nonzero(bad))):
+            if safety_break:
+                raise NotWithinConfigurationLimits(i, self.q[b, i], lo[i], up[i], instance=b)
+            logging.warning("Value %f at index %d of instance %d is out of limits: [%f, %f]", self.q[b, i], i, b, lo[i], up[i])
 
 
 def _rpy(r: float, p: float, y: float) -> np.ndarray:

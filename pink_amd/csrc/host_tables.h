@@ -32,7 +32,10 @@ inline int padded_nv(int nv) {
 inline std::string build_tables(const pinkhip_desc &d, HostTables &t) {
   if (d.B < 0) return "B must be >= 0";
   if (d.nv < 1 || d.nv > PINKHIP_MAX_NV) return "nv must be in 1..PINKHIP_MAX_NV";
-  if (d.md < 0 || d.md > PINKHIP_MAX_MD) return "md must be in 0..PINKHIP_MAX_MD";
+  if (d.md < 0 || d.md > PINKHIP_MAX_MD)
+    return "md must be in 0..PINKHIP_MAX_MD = " + std::to_string(PINKHIP_MAX_MD) +
+           " dense rows per instance (one lane of the QP's group per row); got " + std::to_string(d.md) +
+           ": merge axis-aligned rows into the box, or keep only the rows that can become active (e.g. the closest pairs of a SelfCollisionBarrier)";
   if (d.n_eq < 0 || d.n_eq > d.md || d.n_eq > d.nv) return "n_eq must be in 0..min(md, nv): equalities are the leading dense rows";
   if (d.T < 0 || d.Kd < 0 || d.K < d.Kd) return "need T >= 0 and 0 <= Kd <= K";
   if (d.T > 0 && (!d.task_rows || !d.task_kind || !d.gain || !d.lm_damping))

@@ -184,6 +184,21 @@ class DeviceRollout:
         self.steps_done = 0
         self._pending = False  # a solved dq waits to be integrated by the next whole-step launch
 
+    def reset(self, q0: np.ndarray, q_posture: Optional[np.ndarray] = None, safety_break: bool = True) -> None:
+        """New initial configurations (and posture targets) for the same robots / task stack: buffers, model tables
+        and descriptors are kept (``solve_ik_batch`` re-uses one rollout per call shape)."""
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        if q0.shape != (self.B, self.nq):
+            raise ValueError(f"q0 must have shape {(self.B, self.nq)}, got {q0.shape}")
+        self._check_limits(self.model, q0, safety_break)
+        a = self.api
+        a.put(self.d_q, q0)
+        if self.n_post:
+            a.put(self.d_qt, q0 if q_posture is None else np.ascontiguousarray(np.broadcast_to(q_posture, (self.B, self.nq)), dtype=np.float64))
+        a.put(self.d_fail, np.zeros(self.B, dtype=np.int32))
+        self.steps_done = 0
+        self._pending = False
+
     def set_targets(self, targets: np.ndarray) -> None:
         """Frame targets, ``[B, n_frame_tasks, 12]`` poses (rotation row-major, translation)."""
         t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, len(self.frames), 12)

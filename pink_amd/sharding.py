@@ -96,3 +96,66 @@ def solve_sharded(batch: IKBatch, solver, comm, gather_to: Optional[int] = 0) ->
     dq[:n], st[:n], it[:n] = local.dq, local.status, local.iters
     parts = comm.gather_arrays([dq, st, it], gather_to)
     return _assemble(parts, sizes, nv) if receiver else None
+
+
+class MultiDeviceSolver:
+    """Several GPUs driven from ONE process (SURVEY.md 8(b) ``pinkhip_create(h, device_ids, n_devices)``, section 5
+    ``device_ids=``): one :class:`BatchSolver` -- handle, stream, staging area -- per device and one host thread per
+    device; ``ctypes`` releases the GIL inside the library calls, so the shards copy and compute concurrently.  A
+    batch is cut into contiguous ranges (``shard_bounds``) and nothing is exchanged between the devices; the results
+    are concatenated on the host.  ``solver_factory(device_id)`` builds the per-device solver (the tests pass the CPU
+    wave emulator)."""
+
+    def __init__(self, device_ids, solver_factory=None):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .batch_solver import BatchSolver
+
+        ids = [int(d) for d in device_ids]
+        if not ids or len(set(ids)) != len(ids):
+            raise ValueError("device_ids must be a non-empty list of distinct device indices")
+        make = solver_factory or (lambda d: BatchSolver(device_id=d))
+        self.device_ids = ids
+        self.solvers = [make(d) for d in ids]
+        self._pool = ThreadPoolExecutor(max_workers=len(ids), thread_name_prefix="pinkhip-dev")
+
+    def map(self, fn):
+        """``[fn(r, solver_r) for r]``, each on its own thread."""
+        return list(self._pool.map(lambda rs: fn(*rs), enumerate(self.solvers)))
+
+    def solve(self, batch: IKBatch, max_iter: int = 0) -> BatchResult:
+        world = len(self.solvers)
+        bounds = [shard_bounds(batch.B, r, world) for r in range(world)]
+        parts = self.map(lambda r, s: s.solve(batch.slice(*bounds[r]), max_iter=max_iter) if bounds[r][1] > bounds[r][0] else None)
+        parts = [p for p in parts if p is not None]
+        if not parts:
+            return self.solvers[0].solve(batch, max_iter=max_iter)
+        return BatchResult(np.concatenate([p.dq for p in parts]), np.concatenate([p.status for p in parts]),
+                           np.concatenate([p.iters for p in parts]))
+
+    def stack(self, batch: IKBatch):
+        return self.solvers[0].stack(batch)
+
+    def frame_task_terms(self, *args):
+        return self.solvers[0].frame_task_terms(*args)
+
+    def sync(self) -> None:
+        for s in self.solvers:
+            s.sync()
+
+    def close(self) -> None:
+        self._pool.shutdown(wait=True)
+        for s in self.solvers:
+            s.close()
+
+
+_POOLS = {}
+
+
+def device_pool(device_ids) -> MultiDeviceSolver:
+    """The process-wide :class:`MultiDeviceSolver` for this tuple of devices (created on first use)."""
+    key = tuple(int(d) for d in device_ids)
+    if key not in _POOLS:
+        _POOLS[key] = MultiDeviceSolver(key)
+    return _POOLS[key]
+

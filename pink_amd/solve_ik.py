@@ -17,6 +17,29 @@ from .batch import BarrierTerm, DenseTaskTerm, DiagonalTaskTerm, IKBatch, pack_t
 from .exceptions import NoSolutionFound, PinkError
 
 SOLVER_NAMES = ("mi355x", "pinkhip")
+# ``solver=`` strings of the reference (``pink/solve_ik.py:210,270`` forwards them to ``qpsolvers.solve_problem``; its
+# README and examples say "quadprog", its tests "daqp" / "proxqp" / "osqp"): accepted as aliases so that existing Pink
+# calls run unchanged -- every one of them is served by the MI355X solver, which returns the same minimiser (the QP is
+# strictly convex).
+REFERENCE_SOLVER_NAMES = ("quadprog", "daqp", "proxqp", "osqp", "clarabel", "cvxopt", "ecos", "gurobi", "highs", "hpipm",
+                          "jaxopt_osqp", "kvxopt", "mosek", "nppro", "piqp", "qpalm", "qpax", "qpoases", "qpswift", "qtqp",
+                          "scs", "sip")
+_aliased = set()
+
+
+def _check_solver(solver: str) -> None:
+    """Accept the MI355X solver and, as aliases, the reference's qpsolvers names (logged once per name)."""
+    if solver in SOLVER_NAMES:
+        return
+    if solver in REFERENCE_SOLVER_NAMES:
+        if solver not in _aliased:
+            _aliased.add(solver)
+            import logging
+
+            logging.getLogger("pink_amd").info("solver=%r is served by the MI355X solver (pinkhip)", solver)
+        return
+    raise PinkError(f"solver={solver!r}: this build provides the MI355X solver {SOLVER_NAMES} (qpsolvers names "
+                    f"{REFERENCE_SOLVER_NAMES} are accepted as aliases of it)")
 
 
 class IKProblem:
@@ -124,8 +147,7 @@ def solve_ik(configuration, tasks: Iterable, dt: float, solver: str = "mi355x", 
              barriers=None, constraints=None, safety_break: bool = True, **kwargs) -> np.ndarray:
     """Velocity tangent to ``configuration`` that best fulfils ``tasks``
     (``pink/solve_ik.py:206-275``).  ``kwargs`` accepts ``max_iter``."""
-    if solver not in SOLVER_NAMES:
-        raise PinkError(f"solver={solver!r}: this build only provides the MI355X solver {SOLVER_NAMES}")
+    _check_solver(solver)
     from .runtime import default_solver
 
     configuration.check_limits(safety_break=safety_break)  # solve_ik.py:260
@@ -134,6 +156,15 @@ def solve_ik(configuration, tasks: Iterable, dt: float, solver: str = "mi355x", 
     if not result.all_found:  # solve_ik.py:271-273
         raise NoSolutionFound(problem, result, result.failed_indices(), result.status[result.status != 0])
     return result.dq[0] / dt
+
+
+def _check_same_length(tasks) -> None:
+    """Per-instance task lists must all have the length of the first one: a slot is one task of the stacked QP."""
+    n = len(tasks[0])
+    for b, tb in enumerate(tasks):
+        if not isinstance(tb, (list, tuple)) or len(tb) != n:
+            raise PinkError(f"per-instance task lists must have the same length: instance {b} has "
+                            f"{len(tb) if isinstance(tb, (list, tuple)) else type(tb).__name__}, instance 0 has {n}")
 
 
 def _pose12(T) -> np.ndarray:
@@ -161,6 +192,8 @@ def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, da
     B = len(configurations)
     nv = configurations[0].model.nv if B else 0
     per_instance = B > 0 and len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    if per_instance:
+        _check_same_length(tasks)
     n_tasks = len(tasks[0]) if per_instance else len(tasks)
     merged = []
     for k in range(n_tasks):
@@ -240,20 +273,68 @@ def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, da
                       dense_rows=dense_rows, barriers=barrier_terms, batch_size=B, equality_rows=equality_rows)
 
 
+def _spec_of(task):
+    """``(frame, position cost, orientation cost, gain, lm_damping)`` of a FrameTask, hashable."""
+    return (task.frame, tuple(float(v) for v in np.broadcast_to(np.asarray(task.position_cost, float), (3,))),
+            tuple(float(v) for v in np.broadcast_to(np.asarray(task.orientation_cost, float), (3,))), float(task.gain), float(task.lm_damping))
+
+
 def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints):
-    """``(model, frame task specs, target poses [B, nf, 12], posture task)`` when the whole batch can be evaluated on
-    the device from the configurations alone -- every task a FrameTask (one target per instance allowed) or one
-    PostureTask, the model's default limits, no barriers, no equality constraints, one model -- else ``None``."""
+    """``(model, q [B, nq], frame task specs, target poses [B, nf, 12], posture)`` when the whole batch can be evaluated
+    on the device from the configurations alone -- every task a FrameTask (one target per instance allowed) or one
+    PostureTask, the model's default limits, no barriers, no equality constraints, one model -- else ``None``.
+    ``posture`` is ``None`` or ``(cost, gain, lm_damping, q_posture [B, nq])``."""
+    from .configuration import ConfigurationBatch
     from .tasks.frame_task import FrameTask
     from .tasks.posture_task import PostureTask
 
     B = len(configurations)
     if B == 0 or barriers or constraints or limits is not None:
         return None
+    if isinstance(configurations, ConfigurationBatch):
+        # arrays in, arrays out: the tasks are shared objects carrying per-instance targets as arrays
+        model, q = configurations.model, configurations.q
+        if getattr(model, "floating_base_velocity_limit", None) is not None:
+            return None
+        specs, targets, posture = [], [], None
+        for t in tasks:
+            if type(t) is FrameTask:
+                if posture is not None:
+                    return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
+                if t.target_poses is not None:
+                    if t.target_poses.shape != (B, 12):
+                        raise PinkError(f"FrameTask {t.frame!r}: {t.target_poses.shape[0]} target poses for {B} configurations")
+                    targets.append(t.target_poses)
+                elif t.transform_target_to_world is not None:
+                    targets.append(np.broadcast_to(_pose12(t.transform_target_to_world), (B, 12)))
+                else:
+                    from .exceptions import TargetNotSet
+
+                    raise TargetNotSet(f"no target set for frame '{t.frame}'")
+                specs.append(_spec_of(t))
+            elif type(t) is PostureTask:
+                if posture is not None or np.ndim(t.cost) != 0:
+                    return None
+                if t.target_q_batch is not None:
+                    if t.target_q_batch.shape != q.shape:
+                        raise PinkError(f"PostureTask: targets {t.target_q_batch.shape} for configurations {q.shape}")
+                    qp = t.target_q_batch
+                elif t.target_q is not None:
+                    qp = np.broadcast_to(t.target_q, q.shape)
+                else:
+                    return None
+                posture = (float(t.cost), float(t.gain), float(t.lm_damping), qp)
+            else:
+                return None
+        if not specs:
+            return None
+        return model, q, specs, np.stack(targets, axis=1), posture
     model = configurations[0].model
     if any(c.model is not model for c in configurations) or getattr(model, "floating_base_velocity_limit", None) is not None:
         return None
     per_instance = len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    if per_instance:
+        _check_same_length(tasks)
     slots = [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))] if per_instance else [[t] * B for t in tasks]
     specs, targets, posture = [], [], None
     for col in slots:
@@ -271,7 +352,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         if type(t0) is FrameTask:
             if any(t.frame != t0.frame or t.transform_target_to_world is None for t in col) or posture is not None:
                 return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
-            specs.append((t0.frame, np.asarray(t0.position_cost, float), np.asarray(t0.orientation_cost, float), t0.gain, t0.lm_damping))
+            specs.append(_spec_of(t0))
             tg = np.empty((B, 12))
             for b, t in enumerate(col):
                 T_b = t.transform_target_to_world
@@ -281,44 +362,121 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         elif type(t0) is PostureTask:
             if posture is not None or any(t.target_q is None for t in col) or np.ndim(t0.cost) != 0:
                 return None
-            posture = col
+            posture = (float(t0.cost), float(t0.gain), float(t0.lm_damping), np.stack([t.target_q for t in col]))
         else:
             return None
     if not specs:
         return None
-    T = np.stack(targets, axis=1) if targets else np.zeros((B, 0, 12))
-    return model, specs, T, posture
+    q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
+    return model, q, specs, np.stack(targets, axis=1), posture
 
 
-def _solve_on_device(plan, configurations, dt, damping, safety_break, solver_handle, max_iter):
+# Device-resident state of the last few (model, batch size, task stack) combinations solve_ik_batch was called with,
+# kept per solver (= per device): model tables, buffers and descriptors are built once, a call only moves q and the
+# targets in and dq out.
+_ROLLOUT_CACHE_MAX = 4
+_CACHED_APIS: list = []
+
+
+def _rollout_cache(api) -> dict:
+    cache = getattr(api, "_pinkhip_rollouts", None)
+    if cache is None:
+        cache = {}
+        api._pinkhip_rollouts = cache
+        _CACHED_APIS.append(api)
+    return cache
+
+
+def clear_device_cache() -> None:
+    """Release the device buffers :func:`solve_ik_batch` keeps between calls."""
+    for api in _CACHED_APIS:
+        cache = getattr(api, "_pinkhip_rollouts", {})
+        for ro in cache.values():
+            try:
+                ro.free()
+            except Exception:  # noqa: BLE001  (a solver that was closed in the meantime)
+                pass
+        cache.clear()
+
+
+def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
     """FK, task rows, limits and the QP for the whole batch in device kernels (one launch where the whole-step
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
-    from .runtime import default_solver
 
-    model, specs, T, posture = plan
-    api = solver_handle or default_solver()
-    q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
-    kw = {}
-    if posture is not None:
-        p0 = posture[0]
-        kw = dict(posture_cost=float(p0.cost), posture_gain=p0.gain, posture_lm_damping=p0.lm_damping,
-                  q_posture=np.stack([t.target_q for t in posture]))
-    ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
-                       max_iter=max_iter, fused="kernel", safety_break=safety_break, **kw)
+    model, q, specs, T, posture = plan
+    B = q.shape[0]
+    pkey = None if posture is None else posture[:3]
+    key = (id(model), B, tuple(specs), float(dt), float(damping), pkey, int(max_iter),
+           float(model.configuration_limit.config_limit_gain))
+    cache = _rollout_cache(api)
+    ro = cache.pop(key, None)
+    if ro is None:
+        kw = {}
+        if posture is not None:
+            kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
+        ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
+                           max_iter=max_iter, fused="kernel", safety_break=safety_break, **kw)
+        ro._cache_owner = model  # keeps id(model) of the key alive and unique
+    else:
+        ro.reset(q, None if posture is None else posture[3], safety_break)
     try:
         ro.set_targets(T)
         ro.step(integrate=False)
         api.sync()
-        return ro.last_step()
-    finally:
+        out = ro.last_step()
+    except BaseException:
         ro.free()
+        raise
+    cache[key] = ro  # most recently used last
+    while len(cache) > _ROLLOUT_CACHE_MAX:
+        cache.pop(next(iter(cache))).free()
+    return out
+
+
+def _expand_batched_targets(tasks, B):
+    """Host-evaluated path: a shared task carrying per-instance targets as arrays (``FrameTask.set_target_poses``,
+    ``PostureTask.set_target_batch``) becomes one task object per instance, as the list form expects."""
+    import copy
+
+    from .lie import SE3
+
+    if B == 0 or (len(tasks) == B and isinstance(tasks[0], (list, tuple))):
+        return tasks
+    if not any(getattr(t, "target_poses", None) is not None or getattr(t, "target_q_batch", None) is not None for t in tasks):
+        return tasks
+    out = [[] for _ in range(B)]
+    for t in tasks:
+        poses, qb = getattr(t, "target_poses", None), getattr(t, "target_q_batch", None)
+        if poses is not None and poses.shape[0] != B or qb is not None and qb.shape[0] != B:
+            raise PinkError(f"{type(t).__name__}: per-instance targets for {(poses if poses is not None else qb).shape[0]} instances, batch of {B}")
+        for b in range(B):
+            c = t
+            if poses is not None:
+                c = copy.copy(t)
+                c.target_poses = None
+                c.transform_target_to_world = SE3(poses[b, :9].reshape(3, 3).copy(), poses[b, 9:].copy())
+            elif qb is not None:
+                c = copy.copy(t)
+                c.target_q_batch = None
+                c.target_q = qb[b].copy()
+            out[b].append(c)
+    return out
+
+
+def _slice_plan(plan, lo, hi):
+    model, q, specs, T, posture = plan
+    return model, q[lo:hi], specs, T[lo:hi], None if posture is None else posture[:3] + (posture[3][lo:hi],)
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
                    limits=None, barriers=None, constraints=None, safety_break: bool = True, solver_handle=None,
-                   device_kinematics: Optional[bool] = None, **kwargs) -> np.ndarray:
+                   device_kinematics: Optional[bool] = None, device_ids: Optional[Sequence[int]] = None, **kwargs) -> np.ndarray:
     """Batched ``solve_ik``: velocities ``[B, nv]`` for ``B`` configurations.
+
+    ``configurations`` is a list of :class:`Configuration` objects or a :class:`ConfigurationBatch` (one array
+    ``q [B, nq]``; tasks then carry per-instance targets as arrays, ``FrameTask.set_target_poses`` /
+    ``PostureTask.set_target_batch``): the array form has no per-instance Python work at all.
 
     Raises :class:`NoSolutionFound` listing the failing instances (the batched
     analogue of ``pink/solve_ik.py:271-273``).
@@ -326,11 +484,22 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     ``device_kinematics``: when the task stack is FrameTasks (+ one PostureTask) under the model's default limits,
     forward kinematics, task errors / Jacobians and limits can be evaluated by the device kernels from ``q`` alone
     instead of per configuration on the host (``None``: do so for batches of 64 and more; ``True``: require it).
+    Device buffers of the last few call shapes are kept (:func:`clear_device_cache`).
+
+    ``device_ids``: shard the batch contiguously over these GPUs from this one process (one handle, stream and staging
+    area per device, a thread each): no collective, results concatenated on the host.
     """
-    if solver not in SOLVER_NAMES:
-        raise PinkError(f"solver={solver!r}: this build only provides the MI355X solver {SOLVER_NAMES}")
+    _check_solver(solver)
     from .runtime import default_solver
 
+    max_iter = int(kwargs.get("max_iter", 0))
+    if device_ids is not None:
+        if solver_handle is not None:
+            raise PinkError("device_ids= and solver_handle= are mutually exclusive")
+        from .sharding import device_pool
+
+        solver_handle = device_pool(device_ids)
+    pool = getattr(solver_handle, "solvers", None)  # a MultiDeviceSolver
     plan = None
     if device_kinematics or (device_kinematics is None and len(configurations) >= 64):
         plan = _device_kinematics_plan(configurations, tasks, limits, barriers, constraints)
@@ -339,17 +508,31 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     if plan is not None:
         from .batch_solver import BatchResult
 
-        dq, status, iters = _solve_on_device(plan, configurations, dt, damping, safety_break, solver_handle,
-                                             int(kwargs.get("max_iter", 0)))
+        if pool is not None:
+            from .sharding import shard_bounds
+
+            bounds = [shard_bounds(len(configurations), r, len(pool)) for r in range(len(pool))]
+            parts = solver_handle.map(lambda r, api: _solve_on_device(_slice_plan(plan, *bounds[r]), dt, damping, safety_break, api, max_iter)
+                                      if bounds[r][1] > bounds[r][0] else None)
+            parts = [p for p in parts if p is not None]
+            dq, status, iters = (np.concatenate([p[k] for p in parts]) for k in range(3))
+        else:
+            dq, status, iters = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter)
         if (status != 0).any():
             result = BatchResult(dq, status, iters)
             raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
         return dq / dt
-    for cfg in configurations:
-        cfg.check_limits(safety_break=safety_break)
-    batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, solver_handle,
+    tasks = _expand_batched_targets(tasks, len(configurations))
+    if hasattr(configurations, "check_limits"):
+        configurations.check_limits(safety_break=safety_break)
+        configurations = list(configurations)
+    else:
+        for cfg in configurations:
+            cfg.check_limits(safety_break=safety_break)
+    api = solver_handle or default_solver()
+    batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, pool[0] if pool else solver_handle,
                                 gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)), constraints=constraints)
-    result = (solver_handle or default_solver()).solve(batch, max_iter=int(kwargs.get("max_iter", 0)))
+    result = api.solve(batch, max_iter=max_iter)
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])
     return result.dq / dt

@@ -18,6 +18,7 @@ class FrameTask(Task):
         super().__init__(cost=np.ones(6), gain=gain, lm_damping=lm_damping)
         self.frame = frame
         self.transform_target_to_world: Optional[SE3] = None
+        self.target_poses: Optional[np.ndarray] = None  # [B, 12] per-instance targets (set_target_poses)
         self.set_position_cost(position_cost)
         self.set_orientation_cost(orientation_cost)
 
@@ -48,6 +49,16 @@ class FrameTask(Task):
 
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.get_transform_frame_to_world(self.frame))
+
+    def set_target_poses(self, rotations: np.ndarray, translations: np.ndarray) -> None:
+        """One target per instance of a batch, as arrays: ``rotations [B, 3, 3]``, ``translations [B, 3]``
+        (target frame to world).  Used by :func:`pink_amd.solve_ik_batch` with a
+        :class:`pink_amd.ConfigurationBatch`; instance ``b`` then plays ``set_target(SE3(R[b], p[b]))``."""
+        R = np.asarray(rotations, dtype=np.float64)
+        t = np.asarray(translations, dtype=np.float64)
+        if R.ndim != 3 or R.shape[1:] != (3, 3) or t.shape != (R.shape[0], 3):
+            raise TaskDefinitionError(f"rotations [B, 3, 3] and translations [B, 3] expected, got {R.shape} and {t.shape}")
+        self.target_poses = np.ascontiguousarray(np.concatenate([R.reshape(-1, 9), t], axis=1))
 
     def compute_error(self, configuration) -> np.ndarray:
         """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``

@@ -29,12 +29,18 @@ class PostureTask(_ActuatedIdentityTask):
     def __init__(self, cost: float, lm_damping: float = 0.0, gain: float = 1.0):
         super().__init__(cost=cost, gain=gain, lm_damping=lm_damping)
         self.target_q: Optional[np.ndarray] = None
+        self.target_q_batch: Optional[np.ndarray] = None  # [B, nq] (set_target_batch)
 
     def set_target(self, target_q: np.ndarray) -> None:
         self.target_q = np.array(target_q, dtype=float)
 
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.q)
+
+    def set_target_batch(self, target_q: np.ndarray) -> None:
+        """One reference posture per instance of a batch, ``[B, nq]`` (for ``solve_ik_batch`` on a
+        :class:`pink_amd.ConfigurationBatch`)."""
+        self.target_q_batch = np.ascontiguousarray(target_q, dtype=np.float64)
 
     def compute_error(self, configuration) -> np.ndarray:
         """``q (-) q*`` on the actuated coordinates (``posture_task.py:100-107``; the code,

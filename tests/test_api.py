@@ -101,6 +101,18 @@ def test_check_limits_raises_or_warns(backend):
     solve_ik(cfg, [], dt=1e-3, safety_break=False, limits=[])  # warns only
 
 
+def test_check_limits_warns_about_every_violated_joint(caplog):
+    """pink/configuration.py:183-201: without the safety break every joint out of its limits is logged, not only the first."""
+    import logging
+
+    m = build_chain(6, limit=1.0)
+    cfg = Configuration(m, np.array([0.0, 1.5, 0.0, -1.2, 0.0, 2.0]))
+    with caplog.at_level(logging.WARNING):
+        cfg.check_limits(safety_break=False)
+    hits = [r for r in caplog.records if "out of limits" in r.getMessage()]
+    assert len(hits) == 3 and [r.args[1] for r in hits] == [1, 3, 5]
+
+
 def test_no_task_and_fulfilled_task_give_zero_velocity(backend):
     """tests/test_solve_ik.py:79-102."""
     m, cfg = _arm()
@@ -188,8 +200,24 @@ def test_solve_ik_batch_equals_loop_and_reports_failures(backend):
     with pytest.raises(NoSolutionFound) as ei:
         solve_ik_batch(cfgs, [task, post], 5e-3, limits=[Crossed()])
     assert ei.value.indices.tolist() == [0, 1, 2, 3, 4] and (ei.value.status == 2).all()
-    with pytest.raises(pink_amd.PinkError):
-        solve_ik(cfgs[0], [task], 5e-3, solver="quadprog")
+    # the reference's solver strings (pink/solve_ik.py:210, README "quadprog", tests "daqp" / "proxqp") are aliases of
+    # the MI355X solver: a Pink call runs unchanged; anything else is refused by name
+    v_ref = solve_ik(cfgs[0], [task], 5e-3)
+    for name in ("quadprog", "daqp", "proxqp", "osqp"):
+        assert np.array_equal(solve_ik(cfgs[0], [task], 5e-3, solver=name), v_ref)
+    assert np.array_equal(solve_ik_batch(cfgs, [task, post], 5e-3, solver="quadprog"), V)
+    with pytest.raises(pink_amd.PinkError, match="not_a_solver"):
+        solve_ik(cfgs[0], [task], 5e-3, solver="not_a_solver")
+    # per-instance task lists of different lengths are an error (not silently cut to the first one's length)
+    ragged = [[task, post] for _ in cfgs]
+    ragged[3] = [task, post, PostureTask(cost=1e-2)]
+    ragged[3][2].set_target_from_configuration(cfgs[3])
+    for dk in (False, None):
+        with pytest.raises(pink_amd.PinkError, match="same length"):
+            solve_ik_batch(cfgs, ragged, 5e-3, device_kinematics=dk)
+    ragged[3] = [task]
+    with pytest.raises(pink_amd.PinkError, match="same length"):
+        solve_ik_batch(cfgs, ragged, 5e-3)
 
 
 def test_equality_constraints_via_constraints_argument(backend):
@@ -437,6 +465,95 @@ def test_solve_ik_batch_device_kinematics_equals_host_path(backend):
     bar = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
     with pytest.raises(pink_amd.PinkError):
         solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
+
+
+def test_solve_ik_batch_on_arrays_equals_the_list_of_configurations(backend):
+    """``ConfigurationBatch`` (q as one array) + per-instance targets as arrays: same velocities as the list of
+    Configuration objects with per-instance task objects; a second call with other q re-uses the device state; the
+    in-process sharder over two solver handles (``device_ids=`` / ``MultiDeviceSolver``) returns the same batch."""
+    from pink_amd import ConfigurationBatch, MultiDeviceSolver
+    from pink_amd.runtime import default_solver
+
+    m, frames = build_chain(9, free_flyer=True, seed=3), ["tool0", "joint_4"]
+    rng = np.random.default_rng(5)
+    B = 9
+    pink_amd.clear_device_cache()  # (the solver of the test session may hold the states of earlier tests)
+
+    def draw():
+        q = np.tile(m.neutral(), (B, 1))
+        for j in m.joints:
+            if j.kind != "free_flyer":
+                q[:, j.idx_q] = rng.uniform(-0.9, 0.9, size=B)
+        return q
+
+    for trial in range(2):  # the second trial hits the cached device state with new configurations and targets
+        q = draw()
+        cfgs = [Configuration(m, q[b]) for b in range(B)]
+        shared = [FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9) for k, f in enumerate(frames)]
+        post = PostureTask(cost=1e-2, gain=0.7)
+        qp = draw()
+        post.set_target_batch(qp)
+        per_instance = [[] for _ in range(B)]
+        for k, f in enumerate(frames):
+            R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+            for b, cfg in enumerate(cfgs):
+                T = cfg.get_transform_frame_to_world(f) * SE3(np.eye(3), 0.03 * rng.normal(size=3))
+                R[b], t[b] = T.rotation, T.translation
+                ft = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+                ft.set_target(T)
+                per_instance[b].append(ft)
+            shared[k].set_target_poses(R, t)
+        for b in range(B):
+            p = PostureTask(cost=1e-2, gain=0.7)
+            p.set_target(qp[b])
+            per_instance[b].append(p)
+        V_list = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=True)
+        V_arr = solve_ik_batch(ConfigurationBatch(m, q), shared + [post], 5e-3, device_kinematics=True)
+        assert np.array_equal(V_arr, V_list) and np.abs(V_arr).max() > 1e-3
+        V_host = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=False, gpu_frame_tasks=False)
+        assert np.abs(V_arr - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
+        # the array form through the host-evaluated path: per-instance targets are expanded to task objects
+        V_arr_host = solve_ik_batch(ConfigurationBatch(m, q), shared + [post], 5e-3, device_kinematics=False, gpu_frame_tasks=False)
+        assert np.array_equal(V_arr_host, V_host)
+    assert len(default_solver()._pinkhip_rollouts) == 1  # one call shape: one cached device state
+    # two handles driven from this process, contiguous shards (on the GPU box both handles sit on device 0)
+    class Serialised:  # the CPU wave emulator is one global wavefront: its calls take turns
+        import threading
+
+        lock = threading.Lock()
+
+        def __init__(self, inner):
+            object.__setattr__(self, "_inner", inner)
+
+        def __getattr__(self, name):
+            attr = getattr(self._inner, name)
+            if not callable(attr):
+                return attr
+
+            def call(*a, **k):
+                with Serialised.lock:
+                    return attr(*a, **k)
+
+            return call
+
+    mk = (lambda d: Serialised(default_solver())) if backend == "emu" else (lambda d: pink_amd.BatchSolver(device_id=0))
+    pool = MultiDeviceSolver([0, 1], solver_factory=mk)
+    try:
+        V_pool = solve_ik_batch(ConfigurationBatch(m, q), shared + [post], 5e-3, device_kinematics=True, solver_handle=pool)
+        assert np.array_equal(V_pool, V_arr)
+        V_pool_host = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=False, gpu_frame_tasks=False, solver_handle=pool)
+        assert np.array_equal(V_pool_host, V_host)
+        with pytest.raises(pink_amd.PinkError):
+            solve_ik_batch(cfgs, per_instance, 5e-3, solver_handle=pool, device_ids=[0])
+    finally:
+        if backend != "emu":
+            pool.close()
+        pink_amd.clear_device_cache()
+    # limits are checked on the array form too
+    q_bad = q.copy()
+    q_bad[4, 7 + 2] = 9.0
+    with pytest.raises(NotWithinConfigurationLimits):
+        solve_ik_batch(ConfigurationBatch(m, q_bad), shared + [post], 5e-3, device_kinematics=True)
 
 
 def _biped():

@@ -66,6 +66,7 @@ WORKER = textwrap.dedent(
     g.build_hip = lambda force=False: None
     sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "ur5", "--batch", "6"] + EXTRA
     import bench
+    bench._device_count = lambda: 2
     bench.main()
     """
 )
@@ -115,3 +116,26 @@ def test_two_rank_strong_scaling_splits_the_global_batch(built, tmp_path):
     line = _run(tmp_path, ["--scaling", "strong", "--global-batch", "10", "--headline-only", "--no-cpu-baseline"])
     assert line["scaling"] == "strong" and line["config"]["global_batch"] == 10 and line["config"]["batch_per_gpu"] == 5
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather"]["bytes_per_rank"] == 8 * 5 * 6
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks(built, tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment launches its two ranks itself (one JSON line,
+    n_gpus = 2, per-rank kernel and end-to-end times) instead of running one rank."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "extra": ["--headline-only", "--no-cpu-baseline"]})
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["per_rank_kernel_ms"]) == 2 and line["config"]["global_batch"] == 12
+
+
+def test_gpus_n_refuses_when_devices_are_missing(built, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text((WORKER % {"root": ROOT, "extra": []}).replace("bench._device_count = lambda: 2", "bench._device_count = lambda: 1"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr
+
