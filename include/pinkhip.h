@@ -263,6 +263,9 @@ typedef struct pinkhip_rollout_step {
   int32_t *first_failure;    /* [B] sticky `status | (step << 8)`, may be NULL */
   double config_limit_gain;
   int32_t target_batched, step, integrate;
+  int64_t sT_b, sT_f;        /* strides (doubles) of T_target: pose of instance b, frame f at T_target + b sT_b + f sT_f;
+                                both 0: the contiguous [B,nf,12] (12 nf, 12).  (12, 12 B) addresses one [B,12] array per
+                                frame, uploaded as it is (pink_amd.FrameTask.set_target_poses) */
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);
@@ -272,6 +275,11 @@ int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *model,
                                   double config_limit_gain, const double *q, const double *q_target,
                                   int32_t target_batched, double *lb, double *ub, double *e, int32_t K,
                                   int32_t e_off);
+/* Configuration.check_limits (pink/configuration.py:166-201) over a batch resident on the device: *first_bad receives
+ * b * nq + i of the first entry with q_max > q_min + tol that lies outside [q_min - tol, q_max + tol] (coordinates of
+ * the root joint skipped), or -1.  q is a device pointer, first_bad a host pointer; synchronises the stream. */
+int pinkhip_check_limits_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const double *q, double tol,
+                                int64_t *first_bad);
 /* q [B,nq] <- q (+) dq [B,nv], in place */
 int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double *q,
                              const double *dq);

@@ -104,6 +104,7 @@ class RolloutStep(ctypes.Structure):
         ("q_target", ctypes.c_void_p), ("dq", ctypes.c_void_p), ("status", ctypes.c_void_p), ("iters", ctypes.c_void_p),
         ("first_failure", ctypes.c_void_p), ("config_limit_gain", ctypes.c_double),
         ("target_batched", ctypes.c_int32), ("step", ctypes.c_int32), ("integrate", ctypes.c_int32),
+        ("sT_b", ctypes.c_int64), ("sT_f", ctypes.c_int64),
     ]
 
 
@@ -114,7 +115,7 @@ ABI_SYMBOLS = (
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
     "pinkhip_fk_frame_tasks_device", "pinkhip_step_device", "pinkhip_rollout_step_device",
-    "pinkhip_limits_posture_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
+    "pinkhip_limits_posture_device", "pinkhip_check_limits_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_host_alloc", "pinkhip_host_free", "pinkhip_malloc", "pinkhip_free",
@@ -159,6 +160,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_step_device.argtypes = [vp, vp, i64, ctypes.POINTER(Step)]
     lib.pinkhip_rollout_step_device.argtypes = [vp, ctypes.POINTER(Desc), vp, ctypes.POINTER(RolloutStep)]
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
+    lib.pinkhip_check_limits_device.argtypes = [vp, vp, i64, vp, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
     lib.pinkhip_integrate_checked_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32]
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]

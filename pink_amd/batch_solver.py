@@ -318,6 +318,13 @@ class BatchSolver:
         self._check(self._lib.pinkhip_limits_posture_device(self._h, ctypes.c_void_p(model), B, dt, gain, q, q_target,
                                                             batched, lb, ub, e, K, e_off))
 
+    def check_limits(self, model, B, q, tol: float = 1e-6) -> int:
+        """``b * nq + i`` of the first configuration entry of the device batch ``q`` outside its joint limits, or -1
+        (``pinkhip_check_limits_device``; synchronises)."""
+        bad = ctypes.c_int64(-1)
+        self._check(self._lib.pinkhip_check_limits_device(self._h, ctypes.c_void_p(model), B, q, float(tol), ctypes.byref(bad)))
+        return int(bad.value)
+
     def integrate(self, model, B, q, dq) -> None:
         self._check(self._lib.pinkhip_integrate_device(self._h, ctypes.c_void_p(model), B, q, dq))
 

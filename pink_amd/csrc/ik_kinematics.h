@@ -179,7 +179,8 @@ struct FkArgs {
   // fused kernel: every model frame f carries a FrameTask with target T_target[b, f]; its error goes to
   // e_out[b * sE + 6 f ..], its Jacobian to rows 6 f .. 6 f + 5 of J_out[b * sJo + ...] (pitch nv), i.e.
   // straight into the packed e [B, K] / J [B, Kd, nv] streams of the solve kernel
-  const double *T_target = nullptr;  // [B, nf, 12]
+  const double *T_target = nullptr;  // [B, nf, 12], or strided: pose (b, f) at T_target + b sTb + f sTf
+  long long sTb = 0, sTf = 12;       // (sTb = 0: 12 nf)
   double *e_out = nullptr;
   double *J_out = nullptr;
   long long sE = 0, sJo = 0;
@@ -249,7 +250,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *si
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       pf_FP[i] = m.frame_placement[12 * f0 + i];
-      pf_Tt[i] = a.T_target[(b * m.nf + f0) * 12 + i];
+      pf_Tt[i] = a.T_target[b * (a.sTb ? a.sTb : 12LL * m.nf) + f0 * a.sTf + i];
     }
     const int j0 = li < m.nv ? li : 0;
     pf_jt = m.dof_joint[j0];
@@ -338,7 +339,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *si
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         FP[i] = first ? pf_FP[i] : m.frame_placement[12 * f + i];
-        Tt[i] = first ? pf_Tt[i] : a.T_target[(b * m.nf + f) * 12 + i];
+        Tt[i] = first ? pf_Tt[i] : a.T_target[b * (a.sTb ? a.sTb : 12LL * m.nf) + f * a.sTf + i];
       }
       if (fj >= 0) {
         se3_mul(oM + 12 * fj, FP, F);
@@ -491,7 +492,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *si
     if constexpr (FUSED) {
       double Tt[12], R[9], pr[3], xi[6], Jl[36];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) Tt[i] = a.T_target[(b * m.nf + f) * 12 + i];
+      for (int i = 0; i < 12; ++i) Tt[i] = a.T_target[b * (a.sTb ? a.sTb : 12LL * m.nf) + f * a.sTf + i];
       se3_act_inv(F, Tt, R, pr);  // e = log6(T_frame^-1 T_target), frame_task.py:181-193
       log6(R, pr, xi);
       if (valid) {
@@ -608,6 +609,32 @@ __device__ inline void ik_limits_posture_thread(const LimitsPostureArgs &a, long
 #ifndef PINKHIP_NO_ELEMENTWISE_KERNELS  // (non-template kernels: defined by the host translation unit only)
 __global__ void __launch_bounds__(256) ik_limits_posture_kernel(LimitsPostureArgs a) {
   ik_limits_posture_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+#endif
+
+struct CheckLimitsArgs {
+  ModelDev m;
+  long long B;
+  const double *q;  // [B, nq]
+  double tol;
+  int start;        // configuration entries of the root joint, skipped (configuration.py:183-187)
+  long long *first_bad;  // device: min over the violating entries of b nq + i, or LLONG_MAX
+};
+
+// one thread per (instance, configuration entry)
+__device__ inline void ik_check_limits_thread(const CheckLimitsArgs &a, long long t) {
+  const ModelDev &m = a.m;
+  if (t >= a.B * m.nq) return;
+  const int i = (int)(t % m.nq);
+  if (i < a.start) return;
+  const double lo = m.q_min[i], up = m.q_max[i], qi = a.q[t];
+  if (up > lo + a.tol && (qi < lo - a.tol || qi > up + a.tol))
+    atomicMin(reinterpret_cast<unsigned long long *>(a.first_bad), static_cast<unsigned long long>(t));
+}
+
+#ifndef PINKHIP_NO_ELEMENTWISE_KERNELS
+__global__ void __launch_bounds__(256) ik_check_limits_kernel(CheckLimitsArgs a) {
+  ik_check_limits_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 #endif
 

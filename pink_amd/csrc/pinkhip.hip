@@ -165,7 +165,7 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
   const size_t K = t.row_gain.size(), nd = t.dtask_k.size(), nb = t.barrier_safe_gain.size();
   const size_t nbytes = 8 * (2 * K + nb) + 4 * (3 * nd + (nb + 1));
-  if (nbytes > kTableBytes) return fail(h, PINKHIP_E_INVALID, "task tables exceed 64 KiB");
+  if (nbytes > kTableBytes - 8) return fail(h, PINKHIP_E_INVALID, "task tables exceed 64 KiB");  // (last 8 bytes: result slot of pinkhip_check_limits_device)
   std::vector<char> img(nbytes);
   char *p = img.data();
   auto put = [&](const void *src, size_t n) {
@@ -778,6 +778,8 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   f.q_rw = st->q;
   f.T_frames = st->T_frames;
   f.T_target = st->T_target;
+  f.sTb = st->sT_b;
+  f.sTf = (st->sT_b || st->sT_f) ? st->sT_f : 12;
   f.dt = desc->dt;
   f.config_limit_gain = st->config_limit_gain;
   f.q_target = n_post ? st->q_target : nullptr;
@@ -811,6 +813,29 @@ int pinkhip_limits_posture_device(pinkhip_handle *h, const pinkhip_model *m, int
   const long long n = B * m->dev.nv;
   hipLaunchKernelGGL(pinkhip::ik_limits_posture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
   PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
+int pinkhip_check_limits_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, const double *q, double tol,
+                                int64_t *first_bad) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (!m || !first_bad || (B > 0 && !q)) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  *first_bad = -1;
+  if (B <= 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  // the result slot: eight bytes of the handle's table area (not used by any kernel of this call)
+  long long *slot = reinterpret_cast<long long *>(h->d_tables + kTableBytes - 8);
+  const long long none = 0x7fffffffffffffffLL;
+  PH_HIP(h, hipMemcpyAsync(slot, &none, 8, hipMemcpyHostToDevice, h->stream));
+  pinkhip::CheckLimitsArgs a{m->dev, B, q, tol, 0, slot};
+  a.start = m->image.root_nv == 6 ? 7 : m->image.root_nv;  // a free-flyer root has 7 configuration entries
+  const long long n = B * m->dev.nq;
+  hipLaunchKernelGGL(pinkhip::ik_check_limits_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  long long got = none;
+  PH_HIP(h, hipMemcpyAsync(&got, slot, 8, hipMemcpyDeviceToHost, h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->stream));
+  *first_bad = (got == none) ? -1 : got;
   return PINKHIP_OK;
 }
 

@@ -114,7 +114,6 @@ class DeviceRollout:
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0):
         self.api, self.model, self.dt = api, model, float(dt)
-        self._check_limits(model, np.asarray(q0, dtype=np.float64), safety_break)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
         self.B = B = int(q0.shape[0])
@@ -170,10 +169,17 @@ class DeviceRollout:
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self.d_qt = f8(B, nq)
+        self.qt_batched = 1  # d_qt holds [B, nq] (one posture target per robot) or [nq] (one for all)
+        self.targets_per_frame = False  # d_Tt holds [B, nf, 12], or one [B, 12] array per frame
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
         a.put(self.d_q, q0)
-        a.put(self.d_qt, q0 if q_posture is None else np.ascontiguousarray(np.broadcast_to(q_posture, (B, nq)), dtype=np.float64))
+        self._put_posture(q0, q_posture)
         a.put(self.d_cost, self.cost)
+        try:
+            self._check_limits_device(q0, safety_break)
+        except BaseException:
+            self.free()
+            raise
         p = Problem()
         p.J, p.e, p.cost, p.lb, p.ub = self.d_J, self.d_e, self.d_cost, self.d_lb, self.d_ub
         p.Gd, p.hd, p.c_extra = None, None, None
@@ -190,19 +196,58 @@ class DeviceRollout:
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
         if q0.shape != (self.B, self.nq):
             raise ValueError(f"q0 must have shape {(self.B, self.nq)}, got {q0.shape}")
-        self._check_limits(self.model, q0, safety_break)
         a = self.api
         a.put(self.d_q, q0)
+        self._check_limits_device(q0, safety_break)
         if self.n_post:
-            a.put(self.d_qt, q0 if q_posture is None else np.ascontiguousarray(np.broadcast_to(q_posture, (self.B, self.nq)), dtype=np.float64))
+            self._put_posture(q0, q_posture)
         a.put(self.d_fail, np.zeros(self.B, dtype=np.int32))
         self.steps_done = 0
         self._pending = False
 
-    def set_targets(self, targets: np.ndarray) -> None:
-        """Frame targets, ``[B, n_frame_tasks, 12]`` poses (rotation row-major, translation)."""
-        t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, len(self.frames), 12)
+    def _put_posture(self, q0: np.ndarray, q_posture: Optional[np.ndarray]) -> None:
+        """Posture target(s): ``None`` = each robot's initial configuration, ``[nq]`` = one for all robots (uploaded
+        as it is: the kernels take either form, ``target_batched``), ``[B, nq]`` = one per robot."""
+        if q_posture is None:
+            self.api.put(self.d_qt, q0)
+            self.qt_batched = 1
+            return
+        qp = np.asarray(q_posture, dtype=np.float64)
+        if qp.ndim == 2 and qp.strides[0] == 0:  # a broadcast view of one vector
+            qp = qp[0]
+        if qp.ndim == 1:
+            self.api.put(self.d_qt, np.ascontiguousarray(qp))
+            self.qt_batched = 0
+        else:
+            self.api.put(self.d_qt, np.ascontiguousarray(np.broadcast_to(qp, (self.B, self.nq))))
+            self.qt_batched = 1
+
+    def _check_limits_device(self, q0: np.ndarray, safety_break: bool) -> None:
+        """``Configuration.check_limits`` (``pink/configuration.py:166-201``) on the uploaded batch, by a device kernel
+        (a vectorised host check of 65 536 x 37 entries costs 2 ms per call); the host loop only runs to report."""
+        if not hasattr(self.api, "check_limits"):
+            return self._check_limits(self.model, q0, safety_break)
+        if self.api.check_limits(self.dmodel, self.B, self.d_q) >= 0:
+            self._check_limits(self.model, q0, safety_break)
+
+    def set_targets(self, targets) -> None:
+        """Frame targets: ``[B, n_frame_tasks, 12]`` poses (rotation row-major, translation), or a list with one
+        ``[B, 12]`` array per frame task (uploaded one after the other, no host-side stacking; the whole-step kernel
+        addresses them through strides)."""
+        nf = len(self.frames)
+        if isinstance(targets, (list, tuple)):
+            if len(targets) != nf:
+                raise ValueError(f"{nf} frame tasks, {len(targets)} target arrays")
+            if self.fused == "kernel":
+                for f, t in enumerate(targets):
+                    t = np.ascontiguousarray(np.broadcast_to(t, (self.B, 12)), dtype=np.float64)
+                    self.api.put(self.d_Tt + 8 * 12 * self.B * f, t)
+                self.targets_per_frame = True
+                return
+            targets = np.stack([np.broadcast_to(t, (self.B, 12)) for t in targets], axis=1)
+        t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, nf, 12)
         self.api.put(self.d_Tt, t)
+        self.targets_per_frame = False
 
     def step(self, integrate: bool = True) -> None:
         """Enqueue one IK step for every robot (asynchronous).  ``integrate=False`` only solves (dq, status and
@@ -210,6 +255,11 @@ class DeviceRollout:
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             self.fused = True  # no instantiation for this model: two launches from now on
+            if self.targets_per_frame:  # those kernels read [B, nf, 12]: restack what was uploaded frame by frame
+                t = np.zeros((nf, B, 12))
+                a.get(t, self.d_Tt)
+                a.put(self.d_Tt, np.ascontiguousarray(t.transpose(1, 0, 2)))
+                self.targets_per_frame = False
         if self.fused == "kernel":
             pass
         elif self.fused:
@@ -218,7 +268,7 @@ class DeviceRollout:
             st.q = self.d_q
             st.dq_prev = self.d_dq if self._pending else None
             st.status, st.first_failure, st.step = self.d_status, self.d_fail, max(self.steps_done - 1, 0)
-            st.target_batched = 1
+            st.target_batched = self.qt_batched
             st.T_target, st.T_frames = self.d_Tt, self.d_T
             st.e, st.sE, st.J, st.sJ = self.d_e, self.K, self.d_J, self.Kd * nv
             st.dt, st.config_limit_gain = self.dt, self.config_limit_gain
@@ -233,7 +283,7 @@ class DeviceRollout:
                 a.frame_task_strided(B, nv, self.d_T + 8 * 12 * t, 12 * nf, self.d_Tt + 8 * 12 * t, 12 * nf,
                                      self.d_Jb + 8 * 6 * nv * t, 6 * nv * nf, self.d_e + 8 * 6 * t, self.K,
                                      self.d_J + 8 * 6 * nv * t, self.Kd * nv)
-            a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, 1, self.d_lb, self.d_ub,
+            a.limits_posture(self.dmodel, B, self.dt, self.config_limit_gain, self.d_q, self.d_qt, self.qt_batched, self.d_lb, self.d_ub,
                              self.d_e if self.n_post else None, self.K, self.Kd)
             a.solve_raw(self.desc, self.problem, self.result)
             if integrate:
@@ -247,7 +297,9 @@ class DeviceRollout:
         st.q_target = self.d_qt if self.n_post else None
         st.dq, st.status, st.iters, st.first_failure = self.d_dq, self.d_status, self.d_iters, self.d_fail
         st.config_limit_gain = self.config_limit_gain
-        st.target_batched, st.step, st.integrate = 1, self.steps_done, int(integrate)
+        st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
+        if self.targets_per_frame:
+            st.sT_b, st.sT_f = 12, 12 * self.B
         return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def flush(self) -> None:
@@ -303,9 +355,9 @@ class DeviceRollout:
 
     def last_step(self):
         """``(dq, status, iters)`` of the most recent step."""
-        dq = np.zeros((self.B, self.nv))
-        st = np.zeros(self.B, np.int32)
-        it = np.zeros(self.B, np.int32)
+        dq = np.empty((self.B, self.nv))
+        st = np.empty(self.B, np.int32)
+        it = np.empty(self.B, np.int32)
         self.api.get(dq, self.d_dq)
         self.api.get(st, self.d_status)
         self.api.get(it, self.d_iters)

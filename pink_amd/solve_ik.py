@@ -320,7 +320,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
                         raise PinkError(f"PostureTask: targets {t.target_q_batch.shape} for configurations {q.shape}")
                     qp = t.target_q_batch
                 elif t.target_q is not None:
-                    qp = np.broadcast_to(t.target_q, q.shape)
+                    qp = np.asarray(t.target_q, dtype=np.float64)  # [nq]: one target for all
                 else:
                     return None
                 posture = (float(t.cost), float(t.gain), float(t.lm_damping), qp)
@@ -328,7 +328,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
                 return None
         if not specs:
             return None
-        return model, q, specs, np.stack(targets, axis=1), posture
+        return model, q, specs, targets, posture  # (targets: one [B, 12] array per frame task, uploaded as they are)
     model = configurations[0].model
     if any(c.model is not model for c in configurations) or getattr(model, "floating_base_velocity_limit", None) is not None:
         return None
@@ -466,7 +466,10 @@ def _expand_batched_targets(tasks, B):
 
 def _slice_plan(plan, lo, hi):
     model, q, specs, T, posture = plan
-    return model, q[lo:hi], specs, T[lo:hi], None if posture is None else posture[:3] + (posture[3][lo:hi],)
+    T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
+    if posture is not None and np.ndim(posture[3]) == 2:
+        posture = posture[:3] + (posture[3][lo:hi],)
+    return model, q[lo:hi], specs, T, posture
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
@@ -518,10 +521,10 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             dq, status, iters = (np.concatenate([p[k] for p in parts]) for k in range(3))
         else:
             dq, status, iters = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter)
-        if (status != 0).any():
+        if status.any():
             result = BatchResult(dq, status, iters)
             raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
-        return dq / dt
+        return np.divide(dq, dt, out=dq)  # v = dq / dt (pink/solve_ik.py:274), in place: dq is this call's own array
     tasks = _expand_batched_targets(tasks, len(configurations))
     if hasattr(configurations, "check_limits"):
         configurations.check_limits(safety_break=safety_break)

@@ -145,6 +145,13 @@ class EmuSolver:
                                                         ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
         self.lib.pinkhip_emu_limits_posture(model, B, dt, gain, q, q_target, batched, lb, ub, e, K, e_off)
 
+    def check_limits(self, model, B, q, tol=1e-6):
+        vp = ctypes.c_void_p
+        bad = ctypes.c_longlong(-1)
+        self.lib.pinkhip_emu_check_limits.argtypes = [vp, ctypes.c_longlong, vp, ctypes.c_double, ctypes.POINTER(ctypes.c_longlong)]
+        self.lib.pinkhip_emu_check_limits(model, B, q, tol, ctypes.byref(bad))
+        return int(bad.value)
+
     def integrate(self, model, B, q, dq):
         vp = ctypes.c_void_p
         self.lib.pinkhip_emu_integrate.argtypes = [vp, ctypes.c_longlong, vp, vp]

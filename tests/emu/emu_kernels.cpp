@@ -288,6 +288,8 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   f.q_rw = st->q;
   f.T_frames = st->T_frames;
   f.T_target = st->T_target;
+  f.sTb = st->sT_b;
+  f.sTf = (st->sT_b || st->sT_f) ? st->sT_f : 12;
   f.dt = d->dt;
   f.config_limit_gain = st->config_limit_gain;
   f.q_target = (d->K > d->Kd) ? st->q_target : nullptr;
@@ -321,6 +323,19 @@ int pinkhip_emu_limits_posture(void *mp, long long B, double dt, double gain, co
   EmuModel *m = static_cast<EmuModel *>(mp);
   pinkhip::LimitsPostureArgs a{m->dev, B, dt, gain, q, q_target, target_batched, lb, ub, e, K, e_off};
   for (long long t = 0; t < B * m->dev.nv; ++t) pinkhip::ik_limits_posture_thread(a, t);
+  return PINKHIP_OK;
+}
+int pinkhip_emu_check_limits(void *mp, long long B, const double *q, double tol, long long *first_bad) {
+  EmuModel *m = static_cast<EmuModel *>(mp);
+  // the device kernel takes an atomic minimum over its threads; in a plain loop the first hit is the minimum
+  *first_bad = -1;
+  const int start = m->image.root_nv == 6 ? 7 : m->image.root_nv;
+  for (long long t = 0; t < B * m->dev.nq && *first_bad < 0; ++t) {
+    const int i = static_cast<int>(t % m->dev.nq);
+    if (i < start) continue;
+    const double lo = m->dev.q_min[i], up = m->dev.q_max[i];
+    if (up > lo + tol && (q[t] < lo - tol || q[t] > up + tol)) *first_bad = t;
+  }
   return PINKHIP_OK;
 }
 int pinkhip_emu_integrate(void *mp, long long B, double *q, const double *dq) {

@@ -37,6 +37,13 @@ struct EmuDim3 {
 };
 static EmuDim3 blockIdx, threadIdx;
 
+// element-wise kernels: one "thread" at a time in the emulator
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
+  const unsigned long long old = *p;
+  if (v < old) *p = v;
+  return old;
+}
+
 namespace pinkhip {
 
 constexpr int kWave = 64;
