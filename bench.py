@@ -335,12 +335,12 @@ def traffic_from_profiles():
     pass was collected on exactly these kernel sources (content hash), else null."""
     import __graft_entry__ as g
 
-    path = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    path = os.path.join(ROOT, "profiles", "traffic_r03.json")
     try:
         t = json.load(open(path))
         if t.get("source_hash") == g._source_hash(g.HIP_DEPS):
-            return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
-        return None, "profiles/traffic_r02.json is from other kernel sources: not reported"
+            return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
+        return None, "profiles/traffic_r03.json is from other kernel sources: not reported"
     except (OSError, ValueError, KeyError):
         return None, "no PMC pass committed for these sources"
 

@@ -1,10 +1,12 @@
+"""Host-call latency of small batches through pinkhip_solve_host (UR5 shape, B = 1 .. 256): Python call, raw C-ABI call.
+    python scripts/host_latency.py [library ...]      (GPU box; default: the product library)"""
 import os, sys, time, statistics
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from pink_amd import _lib, synthetic
 from pink_amd.batch_solver import BatchSolver
 from oracle import c_oracle
-for path in sys.argv[1:]:
+for path in (sys.argv[1:] or [os.path.join("pink_amd", "csrc", "libpinkhip.so")]):  # default: the product library
     s = BatchSolver(0, library=_lib.load_library(os.path.abspath(path)))
     for B in (1, 16, 64, 256):
         terms = synthetic.make_terms("ur5", B, bounds="kinematic", jacobians="kinematic")

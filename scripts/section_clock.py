@@ -16,13 +16,23 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 LIB = os.environ.get("PINKHIP_CLOCK_LIBRARY", os.path.join(ge.CSRC, "libpinkhip_clock.so"))
-SECTIONS = ["stacking", "Cholesky", "J = L^-T, x0", "selection", "d = J^T n (row)", "norms, v, sync", "z, w",
-            "r = P d1", "steps, x/u update", "add (J2, P column)", "drop", "exit"]
+SECTIONS_PACKED = ["stacking", "Cholesky", "J = L^-T, x0", "selection", "d = J^T n (row)", "norms, v, sync", "z, w",
+                   "r = P d1", "steps, x/u update", "add (J2, P column)", "drop", "exit"]
+SECTIONS_SWEEP = ["stacking + parking", "initial sweeps", "x0", "selection", "column (+ refinement)", "steps, x/u update",
+                  "column of the leaving", "pivot", "exit"]
+SECTIONS = SECTIONS_PACKED if os.environ.get("PINKHIP_SOLVER") == "packed" else SECTIONS_SWEEP
 
 
 def build():
-    """One-kernel profiling library: make DEV=1 SECTION_CLOCK=1 (the headline instantiation only)."""
-    subprocess.run(["make", "-j4", "DEV=1", "SECTION_CLOCK=1", "OBJDIR=build_clock", "OUT=libpinkhip_clock.so"], cwd=ge.CSRC, check=True)
+    """One-kernel profiling library: make DEV=1 SECTION_CLOCK=1 (one instantiation: CLOCK_NV / CLOCK_MD / CLOCK_W,
+    default the headline one; the sweep-tableau kernel exports the counters unless PINKHIP_SOLVER=packed)."""
+    nv, md, w = (os.environ.get(k, d) for k, d in (("CLOCK_NV", "30"), ("CLOCK_MD", "0"), ("CLOCK_W", "32")))
+    extra = "" if os.environ.get("PINKHIP_SOLVER") == "packed" else "-DPINKHIP_CLOCK_SWEEP"
+    if os.environ.get("PINKHIP_SOLVER") == "packed" and md != "0":
+        extra = "-DPINKHIP_CLOCK_DENSE=1"
+    out = os.environ.get("CLOCK_OUT", "libpinkhip_clock.so")
+    subprocess.run(["make", "-j4", "DEV=1", "SECTION_CLOCK=1", f"DEVNV={nv}", f"DEVMD={md}", f"DEVW={w}", f"EXTRA={extra}",
+                    f"OBJDIR=build_clock_{nv}_{md}", f"OUT={out}"], cwd=ge.CSRC, check=True)
 
 
 def main():
@@ -54,7 +64,8 @@ def main():
     r = s.download(dev)
     c = np.array(list(out), dtype=np.float64)[:len(SECTIONS)]
     print(f"{name} {bounds} B={B}: {ms:.3f} ms (instrumented), mean iterations {r.iters.mean():.1f}")
-    sampled = (B // 2 + 63) // 64  # every 64th wave of B / 2 adds its cycles
+    per_wave = 64 // int(os.environ.get("CLOCK_W", "32"))
+    sampled = (B // per_wave + 63) // 64  # every 64th wave adds its cycles
     for n, v in zip(SECTIONS, c):
         print(f"  {n:22s} {100 * v / c.sum():5.1f} %   {v / c.sum() * ms * 1e3 :8.1f} us of the launch   {v / sampled:9.0f} cycles per sampled wave")
 
