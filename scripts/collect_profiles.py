@@ -19,6 +19,8 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "prof", "r01_kernel_stats.csv"), os.path.join(dst, f"kernel_stats_{tag}.csv"))
+if os.path.exists(os.path.join(src, "prof_all", "r01_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "prof_all", "r01_kernel_stats.csv"), os.path.join(dst, f"kernel_stats_all_configs_{tag}.csv"))
 if os.path.exists(os.path.join(src, "prof_rollout", "r01_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "prof_rollout", "r01_kernel_stats.csv"), os.path.join(dst, f"kernel_stats_rollout_{tag}.csv"))
 if os.path.exists(os.path.join(src, "rollout_bench.json")):
