@@ -248,7 +248,7 @@ int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B
  * QP solve and q <- q (+) dq -- the task Jacobians never reach memory (they are formed from the joints' world
  * twists while the objective is stacked).  `desc` describes the task stack of the model: one 6-row dense task per
  * model frame (in frame order: Kd = 6 nf), optionally followed by one diagonal task on the actuated coordinates
- * (the PostureTask: col0 = root_nv, nv - root_nv rows); box limits only (md = 0).  Returns
+ * (the PostureTask: col0 = root_nv, nv - root_nv rows); box limits, plus md rows of position barriers (below).  Returns
  * PINKHIP_E_UNSUPPORTED when no instantiation fits the model (nv > 56, or a group of lanes cannot hold the
  * joints / the kinematics scratch): use pinkhip_step_device + pinkhip_solve_device then. */
 typedef struct pinkhip_rollout_step {
@@ -263,6 +263,15 @@ typedef struct pinkhip_rollout_step {
   int32_t *first_failure;    /* [B] sticky `status | (step << 8)`, may be NULL */
   double config_limit_gain;
   int32_t target_batched, step, integrate;
+  /* PositionBarrier rows formed on chip (pink/barriers/position_barrier.py:109-153): desc.md rows, grouped into
+   * desc.n_barriers barriers by desc.barrier_rows (desc.barrier_safe_gain per barrier).  Row d keeps
+   * sign_d (p_frame_d[axis_d] - bound_d) >= 0:  G_d = -sign_d (R J_lin)[axis_d] / dt,  h_d = gain_d sign_d (p - bound)
+   * (pink/barriers/barrier.py:246-254).  Device pointers, [md] each; all NULL when desc.md = 0. */
+  const int32_t *barrier_frame;  /* model frame index of the row */
+  const int32_t *barrier_axis;   /* 0, 1, 2: world x, y, z */
+  const double *barrier_sign;    /* +1: a p_min row, -1: a p_max row */
+  const double *barrier_bound;
+  const double *barrier_gain;
   int64_t sT_b, sT_f;        /* strides (doubles) of T_target: pose of instance b, frame f at T_target + b sT_b + f sT_f;
                                 both 0: the contiguous [B,nf,12] (12 nf, 12).  (12, 12 B) addresses one [B,12] array per
                                 frame, uploaded as it is (pink_amd.FrameTask.set_target_poses) */

@@ -104,6 +104,8 @@ class RolloutStep(ctypes.Structure):
         ("q_target", ctypes.c_void_p), ("dq", ctypes.c_void_p), ("status", ctypes.c_void_p), ("iters", ctypes.c_void_p),
         ("first_failure", ctypes.c_void_p), ("config_limit_gain", ctypes.c_double),
         ("target_batched", ctypes.c_int32), ("step", ctypes.c_int32), ("integrate", ctypes.c_int32),
+        ("barrier_frame", ctypes.c_void_p), ("barrier_axis", ctypes.c_void_p), ("barrier_sign", ctypes.c_void_p),
+        ("barrier_bound", ctypes.c_void_p), ("barrier_gain", ctypes.c_void_p),
         ("sT_b", ctypes.c_int64), ("sT_f", ctypes.c_int64),
     ]
 

@@ -18,6 +18,7 @@ class Barrier(abc.ABC):
                  gain_function: Optional[Callable[[float], float]] = None, safe_displacement_gain: float = 0.0):
         self.dim = dim
         self.gain = gain if isinstance(gain, np.ndarray) else np.ones(dim) * gain
+        self.identity_gain_function = gain_function is None  # (the device-resident path forms h on chip: identity only)
         self.gain_function = gain_function if gain_function is not None else (lambda x: x)
         self.safe_displacement = np.zeros(dim)
         self.safe_displacement_gain = safe_displacement_gain

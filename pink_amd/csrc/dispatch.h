@@ -12,6 +12,11 @@
 #endif
 #define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
 #define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
+#if PINKHIP_DEV_MD > 0
+#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
+#else
+#define PINKHIP_ROLLOUT_DENSE_TABLE(X)
+#endif
 #define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
 #else
 // X(NV, MD, W): the sweep-tableau kernel ik_solve_sweep_kernel<NV, MD, W> (ik_sweep.h): NV coordinates + MD dense rows
@@ -23,6 +28,8 @@
   X(12, 4, 16) X(24, 8, 32) X(30, 2, 32) X(30, 8, 64) X(34, 8, 64) X(40, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
 #define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
+// ... and, with position-barrier rows formed on chip (X(NV, MD, W): NV + MD tableau rows on W lanes), for these
+#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(12, 4, 16) X(30, 8, 64) X(34, 8, 64) X(50, 6, 64) X(56, 8, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
   X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
 #endif
@@ -74,7 +81,7 @@ inline bool prefer_sweep(int nv, int md, long long B) {
 
 // Doubles of LDS per QP of the sweep-tableau kernel (= SweepLds<NV, MD, W>::stride, checked at compile time in
 // tu_sweep.hip): H packed, c, the columns of G.
-constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + W + MD * W; }
+constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + 2 * W + MD * W; }
 
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger.
@@ -85,6 +92,19 @@ constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles) {
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
 // kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the 64 / W
 // robots of a wavefront must fit the 64 KiB of LDS a workgroup may ask for.
+// ... with md > 0 rows of position barriers: {NV, MD, W} from PINKHIP_ROLLOUT_DENSE_TABLE
+inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md) {
+#define PINKHIP_PICK(NV_, MD_, W_)                                                                          \
+  if (nv <= NV_ && md <= MD_ && nj <= W_) {                                                                 \
+    const int need = ((fk_doubles + 1) & ~1) > sweep_lds_doubles(NV_, MD_, W_) ? ((fk_doubles + 1) & ~1)    \
+                                                                               : sweep_lds_doubles(NV_, MD_, W_); \
+    if (8 * need * (64 / W_) + 16 <= 65536) return SweepChoice{NV_, MD_, W_};                               \
+  }
+  PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_PICK)
+#undef PINKHIP_PICK
+  return SweepChoice{0, 0, 0};
+}
+
 inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
   // robots that fit an 8-lane group keep the two-launch step: padding them to 16 lanes halves the robots per
   // wavefront (measured, 6-dof arm: 0.107 ms in one kernel at NV = 12 against 0.068 ms in two launches at NV = 6)

@@ -351,6 +351,10 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *si
 #pragma unroll
         for (int i = 0; i < 12; ++i) a.T_frames[(b * m.nf + f) * 12 + i] = F[i];
       }
+      // world position of the frame, for the rows of position barriers formed on chip (ik_rollout.h)
+      fMo[12 * f + 9] = F[9];
+      fMo[12 * f + 10] = F[10];
+      fMo[12 * f + 11] = F[11];
       double R1[9], p1[3], w[3], th;
       se3_act_inv(F, Tt, R1, p1);  // T_f^-1 T_t
       log3(R1, w, th);

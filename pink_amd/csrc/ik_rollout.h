@@ -22,6 +22,11 @@ struct RolloutArgs {
   int integrate;       // apply dq to q at the end of the step (instances whose solve failed keep their q)
   int *first_failure;  // [B] sticky status | (step << 8), may be NULL
   int step;
+  // PositionBarrier rows (pink/barriers/position_barrier.py:109-153), k.md of them: row d keeps
+  // sign_d (p_frame_d [axis_d] - bound_d) >= 0;  G_d = -sign_d (R J_lin)[axis_d] / dt,  h_d = gain_d sign_d (p - bound)
+  // (pink/barriers/barrier.py:246-254), both formed on chip from the world twists of the joint axes
+  const int *bar_frame = nullptr, *bar_axis = nullptr;
+  const double *bar_sign = nullptr, *bar_bound = nullptr, *bar_gain = nullptr;
 };
 
 // doubles of kinematics scratch per robot: joint poses, ancestor pointers, U / V blocks, frame errors, joint scalars
@@ -52,9 +57,28 @@ struct FkTerms {
   }
   __device__ __forceinline__ double error(int k) const { return es[k]; }
   __device__ __forceinline__ double diag_error(int) const { return post_e; }
+  // dense rows = position barriers: this lane's entry (tangent column li) of row d, and the row's right-hand side.
+  // World velocity of the frame origin p_f per unit of this column's joint velocity: lin + ang x p_f (zero unless the
+  // joint is an ancestor of the frame) = column li of R J_lin (position_barrier.py:136-145).
+  const int *bar_frame = nullptr, *bar_axis = nullptr;
+  const double *bar_sign = nullptr, *bar_bound = nullptr, *bar_gain = nullptr;
+  const double *pfs = nullptr;  // LDS: frame f's world position at pfs[12 f + 9 .. 11]
+  double inv_dt = 0.0;
+  __device__ __forceinline__ double dense_col(int d) const {
+    const int f = bar_frame[d], i = bar_axis[d];
+    const double *pf = pfs + 12 * f + 9;
+    const double v0 = lin[0] + ang[1] * pf[2] - ang[2] * pf[1];
+    const double v1 = lin[1] + ang[2] * pf[0] - ang[0] * pf[2];
+    const double v2 = lin[2] + ang[0] * pf[1] - ang[1] * pf[0];
+    const double vi = i == 0 ? v0 : (i == 1 ? v1 : v2);
+    return (((anc >> f) & 1u) != 0) ? -bar_sign[d] * vi * inv_dt : 0.0;
+  }
+  __device__ __forceinline__ double dense_h(int d) const {
+    return bar_gain[d] * bar_sign[d] * (pfs[12 * bar_frame[d] + 9 + bar_axis[d]] - bar_bound[d]);
+  }
 };
 
-template <int NV, int W>
+template <int NV, int MD, int W>
 __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.fk.m;
@@ -69,9 +93,15 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
   FkTerms<W> t;
   t.es = sm + fk_lds_doubles(m.nj, m.nf);
   t.UV = sm + 12 * (m.nj + m.nf) + ((m.nj + 1) & ~1);  // = Jls of ik_fk_instance
+  if constexpr (MD > 0) {
+    t.bar_frame = a.bar_frame, t.bar_axis = a.bar_axis;
+    t.bar_sign = a.bar_sign, t.bar_bound = a.bar_bound, t.bar_gain = a.bar_gain;
+    t.pfs = sm + 12 * m.nj;  // = fMo of ik_fk_instance
+    t.inv_dt = 1.0 / a.k.dt;
+  }
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();
-  ik_sweep_instance<NV, 0, W, FkTerms<W>>(a.k, block, &t);
+  ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
   const int st = t.status;  // group-uniform
   const bool isj = li < m.nj;
@@ -99,9 +129,9 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
   }
 }
 
-template <int NV, int W>
-__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_ROLLOUT(NV) ik_rollout_kernel(RolloutArgs a) {
-  ik_rollout_instance<NV, W>(a, block_id());
+template <int NV, int MD, int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_ROLLOUT(NV + MD) ik_rollout_kernel(RolloutArgs a) {
+  ik_rollout_instance<NV, MD, W>(a, block_id());
 }
 
 }  // namespace pinkhip

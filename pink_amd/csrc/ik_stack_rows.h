@@ -19,6 +19,8 @@ struct HbmTerms {
   __device__ __forceinline__ void frame_rows(int, double (&)[6]) const {}
   __device__ __forceinline__ double error(int) const { return 0.0; }
   __device__ __forceinline__ double diag_error(int) const { return 0.0; }
+  __device__ __forceinline__ double dense_col(int) const { return 0.0; }
+  __device__ __forceinline__ double dense_h(int) const { return 0.0; }
 };
 
 // Dense task rows.  Lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row; the next

@@ -58,7 +58,8 @@ struct SweepLds {
   static __host__ __device__ constexpr int tri(int i) { return i * (i + 1) / 2; }  // H[i][0..i]
   static constexpr int oC = (NV * (NV + 1) / 2 + 1) & ~1;                            // c, one entry per lane
   static constexpr int oG = oC + W;                                                  // G[d][li] at d W + li
-  static constexpr int stride = oG + MD * W;
+  static constexpr int oR = oG + MD * W;                                             // one row of T in transit (W entries)
+  static constexpr int stride = oR + W;
 };
 
 template <int NV, int MD, int W, class Src = HbmTerms>
@@ -102,20 +103,39 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   if constexpr (DENSE) {
     if (md > 0) {
       // K = [H G^T; G 0]: coordinate lane li takes G[d][li] into column NV + d, the lane of dense row d its row
-      const double *Gb = a.Gd + b * (long long)md * nv;
+      const double *Gb = Src::kOnTheFly ? nullptr : a.Gd + b * (long long)md * nv;
       static_for<0, MD>([&](auto Dc) {
         constexpr int d = decltype(Dc)::value;
-        T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+        if constexpr (Src::kOnTheFly) T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
+        else T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
       });
+      if constexpr (Src::kOnTheFly) {
+        // the rows of G exist only as column entries in the coordinate lanes: the lane of row d collects G[d][j] from
+        // lane j (K is symmetric)
+        static_for<0, MD>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value;
+          if (d < md) {  // wave-uniform
+            const BcT gb = bcast_prepare<W>(T[NV + d]);
+            static_for<0, NV>([&](auto Jc) {
+              constexpr int j = decltype(Jc)::value;
+              const double v = value_bcast<W, j>(gb);
+              if (dr == d) T[j] = v;
+            });
+          }
+        });
+      }
       if (dlane) {
-        const double *gr = Gb + (long long)dr * nv;
         double n2 = 0.0;
+        if constexpr (!Src::kOnTheFly) {
+          const double *gr = Gb + (long long)dr * nv;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          T[j] = (j < nv) ? gr[j] : 0.0;
-          n2 += T[j] * T[j];
+          for (int j = 0; j < NV; ++j) T[j] = (j < nv) ? gr[j] : 0.0;
+          hv = a.hd[b * (long long)md + dr];
+        } else {
+          hv = terms->dense_h(dr);
         }
-        hv = a.hd[b * (long long)md + dr];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) n2 += T[j] * T[j];
         ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
       }
       // barrier objective (barrier.py:193-200): rho_b = r_b / ||J_h||_F^2 on the diagonal, J_h = -dt G rows
@@ -283,6 +303,38 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     return r;
   };
 
+#ifndef PINKHIP_SWEEP_LDS_COLUMN
+#define PINKHIP_SWEEP_LDS_COLUMN 1
+#endif
+  // Column p of T for a group-uniform run-time p (-1: none).  T is symmetric: the column is row p, which lane p holds
+  // in its registers.  Either lane p hands it over through LDS (NT / 2 16-byte writes by one lane, one read per lane:
+  // the LDS pipe is otherwise idle and the VALU is what the kernel is short of), or every lane multiplies its row
+  // with the indicator of p (NT broadcast-FMAs, no LDS round trip on the dependent chain).
+  double *rowbuf = sm + SL::oR;
+  auto column_of = [&](int p) -> double {
+    if constexpr (PINKHIP_SWEEP_LDS_COLUMN) {
+      if (li == p) {
+        Pair *dst = reinterpret_cast<Pair *>(__builtin_assume_aligned(rowbuf, 16));
+#pragma unroll
+        for (int j = 0; j + 1 < NT; j += 2) dst[j >> 1] = Pair{T[j], T[j + 1]};
+        if constexpr (NT % 2) rowbuf[NT - 1] = T[NT - 1];
+      }
+      wave_sync();
+      const double c = rowbuf[li < NT ? li : 0];
+      wave_sync();  // (read before the next hand-over overwrites the row)
+      return (p >= 0 && li < NT) ? c : 0.0;
+    } else {
+      const BcT eb = bcast_indicator<W>(p);
+      double c0 = 0.0, c1 = 0.0;
+      static_for<0, NT>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
+        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+      });
+      return c0 + c1;
+    }
+  };
+
   for (;;) {
     // (a) entering constraint, for the groups that have none pending: the violated constraint that is farthest away
     // in the metric of the objective, violation / sqrt(n^T Z n) with Z the reduced inverse Hessian -- n^T Z n is the
@@ -345,7 +397,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
 
     // (b) column src of T: col_m = sum_j T[m][j] [j == src]; for a finishing group the product T r instead
     double col;
-    {
+    if (!PINKHIP_SWEEP_LDS_COLUMN || wave_any(ref)) {
       BcT eb = bcast_indicator<W>(act ? src : -1);
       double rres = 0.0, sdiag = 0.0;
       if (wave_any(ref)) {
@@ -372,6 +424,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         x += dxv;
         refined = !(more && ++nref < 3);
       }
+    } else {
+      col = column_of(act ? src : -1);
     }
     // (a closing trip that asks for another one falls through the rest of the body, everything masked off: a second
     // back edge -- `continue` -- makes the register allocator keep two copies of T and move one onto the other per trip)
@@ -458,16 +512,10 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       need_sel = true;
     }
     if (wave_any(do_drop)) {
-      const BcT eb = bcast_indicator<W>(do_drop ? kd : -1);
-      double c0 = 0.0, c1 = 0.0;
-      static_for<0, NT>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
-        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
-      });
+      const double ck = column_of(do_drop ? kd : -1);
       const double pk = group_bcast<W>(tdiag, kd);
       if (do_drop) {
-        col = (li == kd) ? tdiag : c0 + c1;
+        col = (li == kd) ? tdiag : ck;
         pi = kd;
         pvt = pk;
         if (li == kd) {

@@ -31,6 +31,10 @@ struct RolloutArgs;
 #define PINKHIP_DECLARE(NV, W) hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W)(hipStream_t stream, const RolloutArgs &a);
 PINKHIP_ROLLOUT_TABLE(PINKHIP_DECLARE)
 #undef PINKHIP_DECLARE
+#define PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(NV, MD, W) PINKHIP_PASTE6(launch_rollout_dense_, NV, MD, W)
+#define PINKHIP_DECLARE(NV, MD, W) hipError_t PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(NV, MD, W)(hipStream_t stream, const RolloutArgs &a);
+PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_DECLARE)
+#undef PINKHIP_DECLARE
 
 
 

@@ -751,8 +751,10 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   if (rc) return rc;
   const pinkhip::ModelDev &md = m->dev;
   if (desc->B == 0) return PINKHIP_OK;
-  if (desc->nv != md.nv || desc->Kd != 6 * md.nf || desc->md != 0 || desc->n_eq != 0)
-    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, Kd = 6 nf, md = 0)");
+  if (desc->nv != md.nv || desc->Kd != 6 * md.nf || desc->n_eq != 0)
+    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, Kd = 6 nf, n_eq = 0)");
+  if (desc->md > 0 && (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain))
+    return fail(h, PINKHIP_E_INVALID, "md > 0 rows of position barriers need the barrier_* tables");
   const int n_post = desc->K - desc->Kd;
   if (desc->T != md.nf + (n_post ? 1 : 0)) return fail(h, PINKHIP_E_INVALID, "expected one dense task per frame (+ one diagonal task)");
   for (int t = 0; t < md.nf; ++t)
@@ -764,9 +766,24 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     return fail(h, PINKHIP_E_INVALID, "null pointer");
   if (!(st->config_limit_gain > 0.0 && st->config_limit_gain <= 1.0) || st->step < 0 || st->step >= (1 << 23))
     return fail(h, PINKHIP_E_INVALID, "bad limit gain / step");
-  const pinkhip::PackedChoice pc = pinkhip::select_rollout(md.nv, md.nj, pinkhip::rollout_fk_doubles(md.nj, md.nf));
-  if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
-  ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, pinkhip::rollout_fk_doubles(md.nj, md.nf));
+  const int fkd = pinkhip::rollout_fk_doubles(md.nj, md.nf);
+  pinkhip::PackedChoice pc{0, 0};
+  pinkhip::SweepChoice dc{0, 0, 0};
+  if (desc->md > 0) {
+    dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md);
+    if (dc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation with barrier rows fits this model");
+    const int sl = pinkhip::sweep_lds_doubles(dc.NV, dc.MD, dc.W);
+    ra.k.lds_pitch = ((fkd + 1) & ~1) > sl ? ((fkd + 1) & ~1) : sl;
+    ra.bar_frame = st->barrier_frame;
+    ra.bar_axis = st->barrier_axis;
+    ra.bar_sign = st->barrier_sign;
+    ra.bar_bound = st->barrier_bound;
+    ra.bar_gain = st->barrier_gain;
+  } else {
+    pc = pinkhip::select_rollout(md.nv, md.nj, fkd);
+    if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
+    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, fkd);
+  }
   ra.k.cost = st->cost;
   ra.k.dq = st->dq;
   ra.k.status = st->status;
@@ -788,11 +805,20 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   ra.first_failure = st->first_failure;
   ra.step = st->step;
   hipError_t e = hipErrorInvalidValue;
-  switch (pc.NV) {
+  if (desc->md > 0) {
+    switch (dc.NV * 100 + dc.MD) {
+#define PINKHIP_CASE(NV, MD, W) \
+  case NV * 100 + MD: e = pinkhip::PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(NV, MD, W)(h->stream, ra); break;
+      PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    }
+  } else {
+    switch (pc.NV) {
 #define PINKHIP_CASE(NV, W) \
   case NV: e = pinkhip::PINKHIP_LAUNCH_ROLLOUT_NAME(NV, W)(h->stream, ra); break;
-    PINKHIP_ROLLOUT_TABLE(PINKHIP_CASE)
+      PINKHIP_ROLLOUT_TABLE(PINKHIP_CASE)
 #undef PINKHIP_CASE
+    }
   }
   PH_HIP(h, e);
   return PINKHIP_OK;

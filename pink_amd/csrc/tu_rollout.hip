@@ -10,17 +10,25 @@
 // clang-format on
 
 #if !defined(PINKHIP_TU_NV) || !defined(PINKHIP_TU_W)
-#error "tu_rollout.hip is compiled once per (NV, W): see the Makefile"
+#error "tu_rollout.hip is compiled once per (NV, W) or (NV, MD, W): see the Makefile"
+#endif
+#ifndef PINKHIP_TU_MD
+#define PINKHIP_TU_MD 0  // rows of position barriers formed on chip
 #endif
 
 namespace pinkhip {
 
+#if PINKHIP_TU_MD == 0
 hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(PINKHIP_TU_NV, PINKHIP_TU_W)(hipStream_t stream, const RolloutArgs &a) {
-  constexpr int NV = PINKHIP_TU_NV, W = PINKHIP_TU_W, G = kWave / W;
-  static_assert(sweep_lds_doubles(NV, 0, W) == SweepLds<NV, 0, W>::stride, "dispatch.h restates the LDS layout");
+#else
+hipError_t PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKHIP_TU_W)(hipStream_t stream, const RolloutArgs &a) {
+#endif
+  constexpr int NV = PINKHIP_TU_NV, MD = PINKHIP_TU_MD, W = PINKHIP_TU_W, G = kWave / W;
+  using SL = SweepLds<NV, MD, W>;
+  static_assert(sweep_lds_doubles(NV, MD, W) == SL::stride, "dispatch.h restates the LDS layout");
   const size_t lds = 8 * static_cast<size_t>(a.k.lds_pitch) * G + 16;
   const dim3 grid(static_cast<unsigned>((a.k.B + G - 1) / G)), block(kWave);
-  hipLaunchKernelGGL((ik_rollout_kernel<NV, W>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((ik_rollout_kernel<NV, MD, W>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

@@ -112,7 +112,8 @@ class DeviceRollout:
     def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
-                 fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0):
+                 fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
+                 position_barriers: Sequence = ()):
         self.api, self.model, self.dt = api, model, float(dt)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
@@ -139,16 +140,40 @@ class DeviceRollout:
         if n_post:
             cost += [float(posture_cost)] * n_post
         self.cost = np.ascontiguousarray(cost if cost else [0.0], dtype=np.float64)
-        self.brow = np.zeros(1, dtype=np.int32)
-        self.bsafe = np.zeros(1, dtype=np.float64)
+        # position barriers (pink/barriers/position_barrier.py): one dense row per (index, side), rows in Pink's order
+        # (p_min rows, then p_max rows); formed on chip by the whole-step kernel (fused="kernel" only)
+        bf, ba, bs, bb, bg, brow, bsafe = [], [], [], [], [], [0], []
+        for bar in position_barriers:
+            if bar.frame not in self.frames:
+                raise ValueError(f"position barrier on frame {bar.frame!r}: the frame must carry one of the frame tasks")
+            if not getattr(bar, "identity_gain_function", False):
+                raise ValueError("position barriers on the device use the identity class-K function (the default)")
+            f = self.frames.index(bar.frame)
+            gains = np.asarray(bar.gain, dtype=float)
+            k = 0
+            for sign, bound in ((1.0, bar.p_min), (-1.0, bar.p_max)):
+                if bound is None:
+                    continue
+                for i, idx in enumerate(bar.indices):
+                    bf.append(f), ba.append(int(idx)), bs.append(sign), bb.append(float(np.asarray(bound)[i])), bg.append(float(gains[k]))
+                    k += 1
+            brow.append(len(bf))
+            bsafe.append(float(bar.safe_displacement_gain))
+        self.md = len(bf)
+        if self.md and self.fused != "kernel":
+            raise ValueError('position barriers need the whole-step kernel: fused="kernel"')
+        self.brow = np.ascontiguousarray(brow, dtype=np.int32)
+        self.bsafe = np.ascontiguousarray(bsafe if bsafe else [0.0], dtype=np.float64)
+        self._bar_host = [np.ascontiguousarray(v if v else [0], dtype=t) for v, t in
+                          ((bf, np.int32), (ba, np.int32), (bs, np.float64), (bb, np.float64), (bg, np.float64))]
         d = Desc()
-        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, T, self.Kd, self.K, 0, 0
+        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, T, self.Kd, self.K, self.md, 0
         d.task_rows = self.task_rows.ctypes.data_as(c_int32_p)
         d.task_kind = self.task_kind.ctypes.data_as(c_int32_p)
         d.task_col0 = self.task_col0.ctypes.data_as(c_int32_p)
         d.gain = self.gain.ctypes.data_as(c_double_p)
         d.lm_damping = self.lm.ctypes.data_as(c_double_p)
-        d.n_barriers = 0
+        d.n_barriers = len(position_barriers)
         d.barrier_rows = self.brow.ctypes.data_as(c_int32_p)
         d.barrier_safe_gain = self.bsafe.ctypes.data_as(c_double_p)
         d.damping, d.dt, d.cost_is_batched, d.max_iter = float(damping), self.dt, 0, int(max_iter)
@@ -169,6 +194,12 @@ class DeviceRollout:
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self.d_qt = f8(B, nq)
+        self.d_bar = []
+        if self.md:
+            for arr in self._bar_host:
+                ptr = a.alloc(max(arr.nbytes, 8))
+                a.put(ptr, arr)
+                self.d_bar.append(ptr)
         self.qt_batched = 1  # d_qt holds [B, nq] (one posture target per robot) or [nq] (one for all)
         self.targets_per_frame = False  # d_Tt holds [B, nf, 12], or one [B, 12] array per frame
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
@@ -254,6 +285,10 @@ class DeviceRollout:
         iteration counts of ``last_step`` are those of the current configurations, which stay as they are)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
+            if self.md:
+                from .exceptions import PinkError
+
+                raise PinkError("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
             self.fused = True  # no instantiation for this model: two launches from now on
             if self.targets_per_frame:  # those kernels read [B, nf, 12]: restack what was uploaded frame by frame
                 t = np.zeros((nf, B, 12))
@@ -300,6 +335,8 @@ class DeviceRollout:
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
+        if self.md:
+            st.barrier_frame, st.barrier_axis, st.barrier_sign, st.barrier_bound, st.barrier_gain = self.d_bar
         return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def flush(self) -> None:
@@ -371,5 +408,8 @@ class DeviceRollout:
 
     def free(self) -> None:
         for name in self._BUFFERS:
-            self.api.release(getattr(self, name))
+            self.api.release(getattr(self, name, None))
+        for ptr in getattr(self, "d_bar", []):
+            self.api.release(ptr)
+        self.d_bar = []
         self.api.model_destroy(self.dmodel)

@@ -283,14 +283,43 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     """``(model, q [B, nq], frame task specs, target poses [B, nf, 12], posture)`` when the whole batch can be evaluated
     on the device from the configurations alone -- every task a FrameTask (one target per instance allowed) or one
     PostureTask, the model's default limits, no barriers, no equality constraints, one model -- else ``None``.
-    ``posture`` is ``None`` or ``(cost, gain, lm_damping, q_posture [B, nq])``."""
+    ``posture`` is ``None`` or ``(cost, gain, lm_damping, q_posture [B, nq] or [nq])``; the plan ends with the tuple of
+    position barriers to form on chip."""
+    from .barriers.barrier import Barrier
+    from .barriers.position_barrier import PositionBarrier
+
+    B = len(configurations)
+    if B == 0 or constraints or limits is not None:
+        return None
+    for bar in barriers or ():
+        # position barriers with the default class-K function and no safe displacement of their own are formed on chip
+        if (type(bar) is not PositionBarrier or not bar.identity_gain_function
+                or type(bar).compute_safe_displacement is not Barrier.compute_safe_displacement):
+            return None
+    plan = _device_kinematics_plan_tasks(configurations, tasks)
+    if plan is not None and barriers:
+        frames = [sp[0] for sp in plan[2]]
+        if any(bar.frame not in frames for bar in barriers):
+            return None
+        plan = plan + (tuple(barriers),)
+    elif plan is not None:
+        plan = plan + ((),)
+    return plan
+
+
+def _barrier_key(bar):
+    return (bar.frame, tuple(bar.indices), None if bar.p_min is None else tuple(np.asarray(bar.p_min, float)),
+            None if bar.p_max is None else tuple(np.asarray(bar.p_max, float)), tuple(np.asarray(bar.gain, float)),
+            float(bar.safe_displacement_gain))
+
+
+def _device_kinematics_plan_tasks(configurations, tasks):
+    """The task half of :func:`_device_kinematics_plan`: ``(model, q, specs, targets, posture)`` or ``None``."""
     from .configuration import ConfigurationBatch
     from .tasks.frame_task import FrameTask
     from .tasks.posture_task import PostureTask
 
     B = len(configurations)
-    if B == 0 or barriers or constraints or limits is not None:
-        return None
     if isinstance(configurations, ConfigurationBatch):
         # arrays in, arrays out: the tasks are shared objects carrying per-instance targets as arrays
         model, q = configurations.model, configurations.q
@@ -404,11 +433,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture = plan
+    model, q, specs, T, posture, bars = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
     key = (id(model), B, tuple(specs), float(dt), float(damping), pkey, int(max_iter),
-           float(model.configuration_limit.config_limit_gain))
+           float(model.configuration_limit.config_limit_gain), tuple(_barrier_key(b) for b in bars))
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     if ro is None:
@@ -416,7 +445,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
         if posture is not None:
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
-                           max_iter=max_iter, fused="kernel", safety_break=safety_break, **kw)
+                           max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
     else:
         ro.reset(q, None if posture is None else posture[3], safety_break)
@@ -465,11 +494,11 @@ def _expand_batched_targets(tasks, B):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture = plan
+    model, q, specs, T, posture, bars = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture
+    return model, q[lo:hi], specs, T, posture, bars
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
@@ -507,7 +536,8 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     if device_kinematics or (device_kinematics is None and len(configurations) >= 64):
         plan = _device_kinematics_plan(configurations, tasks, limits, barriers, constraints)
         if plan is None and device_kinematics:
-            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask), default limits, no barriers / constraints")
+            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask), default limits, no constraints, "
+                            "and no barriers other than PositionBarriers (default class-K function) on the task frames")
     if plan is not None:
         from .batch_solver import BatchResult
 

@@ -166,7 +166,11 @@ void lane_main_step(void *p) {
 
 template <int NV, int W>
 void lane_main_rollout(void *p) {
-  pinkhip::ik_rollout_instance<NV, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
+  pinkhip::ik_rollout_instance<NV, 0, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
+}
+template <int NV, int MD, int W>
+void lane_main_rollout_dense(void *p) {
+  pinkhip::ik_rollout_instance<NV, MD, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
 }
 
 struct EmuModel {
@@ -264,7 +268,8 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   a.nv = d->nv;
   a.Kd = d->Kd;
   a.K = d->K;
-  a.md = 0;
+  a.md = d->md;
+  a.n_barriers = d->n_barriers;
   a.n_dtasks = static_cast<int>(t.dtask_k.size());
   a.cost_batched = d->cost_is_batched;
   a.max_iter = d->max_iter;
@@ -297,11 +302,33 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   ra.integrate = st->integrate;
   ra.first_failure = st->first_failure;
   ra.step = st->step;
-  const pinkhip::PackedChoice pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
-  a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf));
+  const int fkd = pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf);
   pinkhip::LaneFn fn = nullptr;
   long long blocks = 0;
-  switch (pc.NV) {
+  pinkhip::PackedChoice pc{0, 0};
+  if (d->md > 0) {
+    const pinkhip::SweepChoice dc = pinkhip::select_rollout_dense(m->dev.nv, m->dev.nj, fkd, d->md);
+    const int sl = pinkhip::sweep_lds_doubles(dc.NV, dc.MD, dc.W);
+    a.lds_pitch = ((fkd + 1) & ~1) > sl ? ((fkd + 1) & ~1) : sl;
+    ra.bar_frame = st->barrier_frame;
+    ra.bar_axis = st->barrier_axis;
+    ra.bar_sign = st->barrier_sign;
+    ra.bar_bound = st->barrier_bound;
+    ra.bar_gain = st->barrier_gain;
+    switch (dc.NV * 100 + dc.MD) {
+#define PINKHIP_CASE(NV, MD, W)                \
+  case NV * 100 + MD:                          \
+    fn = lane_main_rollout_dense<NV, MD, W>;   \
+    blocks = (d->B + 64 / W - 1) / (64 / W);   \
+    break;
+      PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    }
+  } else {
+    pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, fkd);
+    a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, fkd);
+  }
+  if (d->md == 0) switch (pc.NV) {
 #define PINKHIP_CASE(NV, W)                  \
   case NV:                                   \
     fn = lane_main_rollout<NV, W>;           \

@@ -182,6 +182,71 @@ def test_closed_loop_matches_host_loop_and_converges(api, which, fused):
     ro.free()
 
 
+@pytest.mark.parametrize("which", [1, 2])
+def test_closed_loop_with_position_barriers_matches_host_loop(api, which):
+    """PositionBarrier rows (pink/barriers/position_barrier.py:109-153; G = -J_h / dt, h = gain * barrier,
+    pink/barriers/barrier.py:246-254) formed on chip by the whole-step kernel: the closed loop with two barriers --
+    one of them active along the way, one with a safe-displacement gain -- follows the host loop (per-instance
+    solve_ik(..., barriers=...) + integrate_inplace) to 1e-8, and solve_ik_batch takes the same device path."""
+    from pink_amd import solve_ik_batch
+    from pink_amd.barriers import PositionBarrier
+
+    model, frames = _models()[which]
+    rng = np.random.default_rng(70 + which)
+    B, dt, steps = 3, 5e-3, 25
+    q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
+    if which == 1:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    cfgs = [Configuration(model, q0[b]) for b in range(B)]
+    specs = [(f, 1.0, 0.5 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
+    p0 = np.array([[c.get_transform_frame_to_world(f).translation for f in frames] for c in cfgs])  # [B, nf, 3]
+    # a ceiling 1 cm above the highest tool position while every target sits 8 cm above its tool: the barrier binds;
+    # a box around the second frame that never binds but carries a safe-displacement gain (rho on the diagonal)
+    bars = [PositionBarrier(frames[0], indices=[2], p_max=np.array([p0[:, 0, 2].max() + 0.01]), gain=np.array([50.0])),
+            PositionBarrier(frames[1], indices=[0, 1], p_min=p0[:, 1, :2].min(axis=0) - 0.5, p_max=p0[:, 1, :2].max(axis=0) + 0.5,
+                            gain=np.array([100.0, 100.0]), safe_displacement_gain=1.0)]
+    targets = np.zeros((B, len(frames), 12))
+    host_tasks = []
+    for b, cfg in enumerate(cfgs):
+        tl = []
+        for i, (f, pc, oc, gain, lm) in enumerate(specs):
+            t = FrameTask(f, pc, oc, lm_damping=lm, gain=gain)
+            tgt = cfg.get_transform_frame_to_world(f).copy()
+            tgt.translation = tgt.translation + (np.array([0.0, 0.0, 0.08]) if i == 0 else 0.02 * rng.normal(size=3))
+            t.set_target(tgt)
+            targets[b, i] = pose12(tgt)
+            tl.append(t)
+        p = PostureTask(cost=1e-2)
+        p.set_target(q0[b])
+        tl.append(p)
+        host_tasks.append(tl)
+    # one step through the API: the device path is taken (barriers no longer send the batch to the host path)
+    V_dev = solve_ik_batch(cfgs, host_tasks, dt, barriers=bars, device_kinematics=True)
+    for b, cfg in enumerate(cfgs):
+        assert np.abs(V_dev[b] - solve_ik(cfg, host_tasks[b], dt, barriers=bars)).max() < 1e-8
+    pink_amd.clear_device_cache()
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-2, fused="kernel", position_barriers=bars)
+    ro.set_targets(targets)
+    ro.run(steps)
+    assert ro.fused == "kernel" and ro.md == 5
+    qd = ro.configurations()
+    _, st, it = ro.last_step()
+    assert (st == 0).all()
+    bound_hit = False
+    for b, cfg in enumerate(cfgs):
+        for _ in range(steps):
+            cfg.integrate_inplace(solve_ik(cfg, host_tasks[b], dt, barriers=bars), dt)
+        cd = Configuration(model, qd[b])
+        for f in frames:
+            Ta, Tb = cd.get_transform_frame_to_world(f), cfg.get_transform_frame_to_world(f)
+            assert np.abs(Ta.translation - Tb.translation).max() < 1e-8 and np.abs(Ta.rotation - Tb.rotation).max() < 1e-8
+        z = cd.get_transform_frame_to_world(frames[0]).translation[2]
+        assert z <= bars[0].p_max[0] + 1e-9  # the barrier holds
+        bound_hit |= z > bars[0].p_max[0] - 5e-3
+    assert bound_hit  # ... and it was needed: at least one robot ends up against it
+    ro.free()
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_fused_fk_frame_tasks_equal_separate_launches(api, which):
     """pinkhip_fk_frame_tasks_device writes the same e / J rows into the packed streams as
