@@ -330,6 +330,48 @@ def _slice_task(task, n):
     return t
 
 
+def closed_loop_figures(solver, B: int) -> dict:
+    """Device-resident closed loop (pink_amd.rollout.DeviceRollout, the whole control step in one kernel): B robots,
+    HIP-event time per step.  Headline shape (nv = 30, 4 FrameTasks + posture) and BASELINE config 4's shape (nv = 50,
+    4 FrameTasks + posture + 2 PositionBarriers = 6 barrier rows formed on chip)."""
+    from pink_amd import Configuration, build_chain
+    from pink_amd.barriers import PositionBarrier
+    from pink_amd.rollout import DeviceRollout
+
+    out = {}
+    for label, model, frames, nbar in (("nv30_4frames_posture", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"], 0),
+                                       ("jvrc_shape_nv50_4frames_posture_2barriers", build_chain(44, free_flyer=True, seed=4), ["tool0", "joint_10", "joint_20", "joint_30"], 2)):
+        rng = np.random.default_rng(1)
+        q0 = np.tile(model.neutral(), (B, 1))
+        for j in model.joints:
+            if j.kind != "free_flyer":
+                q0[:, j.idx_q] = rng.uniform(-0.8, 0.8, size=B)
+        specs = [(f, 1.0, 1.0 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
+        bars = []
+        for f in frames[:nbar]:
+            p = np.array([Configuration(model, q0[b]).get_transform_frame_to_world(f).translation for b in range(min(B, 64))])
+            bars.append(PositionBarrier(f, p_min=p.min(axis=0) - 0.02, gain=np.array([100.0] * 3), safe_displacement_gain=1.0))
+        ro = DeviceRollout(solver, model, q0, specs, 5e-3, posture_cost=1e-1, fused="kernel", position_barriers=bars)
+        try:
+            ro.step()
+            solver.sync()
+            T = ro.frame_poses()
+            T[:, :, 9:12] += 0.05 * rng.normal(size=(B, len(frames), 3))
+            ro.set_targets(T)
+            ro.run(5)
+            steps = 30
+            solver.timer_start()
+            for _ in range(steps):
+                ro.step()
+            ms = solver.timer_stop() / steps
+            _, st, it = ro.last_step()
+            out[label] = {"nv": model.nv, "B": B, "ms_per_step": ms, "robot_steps_per_s": B / (ms * 1e-3), "launches_per_step": 1 if ro.fused == "kernel" else 2,
+                          "barrier_rows": ro.md, "qp_iters_mean": float(it.mean()), "failed": int((st != 0).sum())}
+        finally:
+            ro.free()
+    return out
+
+
 def traffic_from_profiles():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC pass -- reported only when that
     pass was collected on exactly these kernel sources (content hash), else null."""
@@ -602,6 +644,10 @@ def main() -> None:
                                       "kernel_only": kernel_ms_of(solver, d1, 50) * 1e3}
             d1.free()
 
+            try:
+                extra["closed_loop_on_device"] = closed_loop_figures(solver, 65536 if B >= 4096 else B)
+            except Exception as exc:  # noqa: BLE001  never lose the bench line
+                extra["closed_loop_on_device"] = {"failed": repr(exc)}
             # Pink's own calling pattern, batched: solve_ik_batch on Configuration objects (BASELINE config 2's shape:
             # 6-dof arm, 1 FrameTask + PostureTask, one target per instance)
             try:

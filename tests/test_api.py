@@ -461,10 +461,17 @@ def test_solve_ik_batch_device_kinematics_equals_host_path(backend):
         V_dev = solve_ik_batch(cfgs, per_instance, 5e-3, device_kinematics=True)
         assert np.abs(V_dev - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
         assert np.abs(V_host).max() > 1e-3
-    # not eligible: a barrier in the stack
+    # a PositionBarrier on a task frame stays on the device (its rows are formed on chip) ...
     bar = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
-    with pytest.raises(pink_amd.PinkError):
-        solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
+    V_bar = solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
+    assert np.abs(V_bar - solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=False, gpu_frame_tasks=False)).max() < 1e-8
+    # ... not eligible: a barrier with its own class-K function, or on a frame that carries no task
+    odd = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
+    odd.gain_function, odd.identity_gain_function = (lambda h: 2.0 * h), False
+    other = PositionBarrier("joint_2", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
+    for b_ in (odd, other):
+        with pytest.raises(pink_amd.PinkError):
+            solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[b_], device_kinematics=True)
 
 
 def test_solve_ik_batch_on_arrays_equals_the_list_of_configurations(backend):
