@@ -25,6 +25,9 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _MAGIC = b"PINKHIP1"
+# Upper bound of one control-plane / host-transport message: the largest thing that ever crosses these sockets is the
+# all-gather of host result arrays (HostComm, test transport); a length prefix beyond this is a foreign or broken peer.
+MAX_MESSAGE_BYTES = int(os.environ.get("PINKHIP_RDZV_MAX_BYTES", str(4 << 30)))
 
 
 def _send(sock: socket.socket, payload: bytes) -> None:
@@ -41,9 +44,39 @@ def _recv_exact(sock: socket.socket, n: int) -> bytes:
     return bytes(buf)
 
 
-def _recv(sock: socket.socket) -> bytes:
+def _recv(sock: socket.socket, limit: int = 0) -> bytes:
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > (limit or MAX_MESSAGE_BYTES):
+        raise ConnectionError(f"rendezvous message of {n} bytes exceeds the limit")
     return _recv_exact(sock, n)
+
+
+def _job_secret(token: int, world: int) -> bytes:
+    """What a peer must present to join: ``PINKHIP_RDZV_SECRET`` (set it to a random string in the launcher's
+    environment for jobs on a shared network) hashed with the job's (MASTER_PORT, world size).  Without the variable the
+    handshake only tells this job's ranks from another job's probing the same port window."""
+    import hashlib
+
+    return hashlib.sha256(os.environ.get("PINKHIP_RDZV_SECRET", "").encode() + struct.pack("<qq", int(token), int(world))).digest()
+
+
+def _is_local(addr: str) -> bool:
+    """``addr`` names this host (then rank 0 listens on it alone, not on every interface)."""
+    try:
+        infos = socket.getaddrinfo(addr, None)
+    except OSError:
+        return False
+    for info in infos:
+        ip = info[4][0]
+        if ip.startswith("127.") or ip == "::1":
+            return True
+        try:
+            with socket.socket(info[0], socket.SOCK_DGRAM) as probe:
+                probe.bind((ip, 0))
+                return True
+        except OSError:
+            continue
+    return False
 
 
 class HostRendezvous:
@@ -64,7 +97,7 @@ class HostRendezvous:
         self.rank, self.world = int(rank), int(world)
         self._peers: List[Optional[socket.socket]] = [None] * world  # rank 0: sockets to 1..world-1
         self._root: Optional[socket.socket] = None
-        hello = _MAGIC + struct.pack("<qq", int(token), self.world)
+        hello = _MAGIC + _job_secret(token, self.world)
         if world == 1:
             return
         deadline = time.monotonic() + timeout
@@ -74,7 +107,9 @@ class HostRendezvous:
                 s = socket.socket()
                 s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
-                    s.bind(("", p))  # every interface: MASTER_ADDR may be a name of this host
+                    # the job's own address when it names this host (the usual single-node case: 127.0.0.1); every
+                    # interface only when MASTER_ADDR does not resolve to a local one
+                    s.bind((addr if _is_local(addr) else "", p))
                     srv = s
                     break
                 except OSError:
@@ -93,7 +128,7 @@ class HostRendezvous:
                     continue
                 c.settimeout(timeout)
                 try:
-                    msg = _recv(c)
+                    msg = _recv(c, limit=256)  # a hello is 48 bytes
                 except (ConnectionError, socket.timeout, struct.error):
                     c.close()
                     continue
@@ -120,7 +155,7 @@ class HostRendezvous:
                     try:
                         s.settimeout(timeout)
                         _send(s, hello + struct.pack("<q", self.rank))
-                        if _recv(s) == hello:
+                        if _recv(s, limit=256) == hello:
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             s.settimeout(None)
                             self._root = s
@@ -139,7 +174,8 @@ class HostRendezvous:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         master_port = int(os.environ.get("MASTER_PORT", "29500"))
-        port = int(os.environ.get("PINKHIP_RDZV_PORT", 20000 + (master_port * 7 + 13) % 20000))
+        # below the Linux ephemeral range (32768-60999): outgoing connections of other processes cannot sit on it
+        port = int(os.environ.get("PINKHIP_RDZV_PORT", 20000 + (master_port * 7 + 13) % 12000))
         return cls(rank, world, addr, port, token=master_port, timeout=timeout)
 
     # -- collectives (all blocking, all ranks must call them in the same order) ----------------
