@@ -250,6 +250,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   const double thr_lo = -tol * (1.0 + fabs(lbv)), thr_up = -tol * (1.0 + fabs(ubv));  // infinite bound: never violated
   const double thr_d = -tol * (1.0 + fabs(hv) * ginv);
   const int max_iter = late->max_iter > 0 ? late->max_iter : 20 * (nv + md) + 50;
+  const bool empty_box_somewhere = wave_any(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up));
   // per lane: state 0 = free coordinate / inactive row, 1 = fixed at lb / active row, 2 = fixed at ub;
   // x = coordinate value; u = multiplier (fixed coordinate, active row) or slack h - g x (inactive row)
   int state = 0;
@@ -304,7 +305,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   };
 
 #ifndef PINKHIP_SWEEP_LDS_COLUMN
-#define PINKHIP_SWEEP_LDS_COLUMN 1
+#define PINKHIP_SWEEP_LDS_COLUMN 0
 #endif
   // Column p of T for a group-uniform run-time p (-1: none).  T is symmetric: the column is row p, which lane p holds
   // in its registers.  Either lane p hands it over through LDS (NT / 2 16-byte writes by one lane, one read per lane:
@@ -343,26 +344,34 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       const bool sel = running && need_sel;
       const double slo = x - lbv, sup = ubv - x;
       const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
-      // A fixed coordinate sits on its bound: its other bound can only be violated when the box is empty, and so are
-      // both bounds of a free one -- quadprog's "constraints are inconsistent".
-      const bool conflict = (vlo && vup) || (state != 0 && in && (vlo || vup));
       // (no curvature left along the normal -- it depends on the active ones: the weight is just large; the step
-      // then finds the constraint that has to leave, or that there is none)
-      const double zd = -tdiag;
-      const double wz = (zd > 1e-290) ? approx_rcp(zd) : 1e290;
-      double key = 0.0;
+      // then finds the constraint that has to leave, or that there is none).  The key only ranks the candidates: fp32.
+      const float zf = static_cast<float>(-tdiag);
+      const float wz = (zf > 1e-30f) ? approx_rcpf(zf) : 1e30f;
+      const float flo = static_cast<float>(slo), fup = static_cast<float>(sup);
+      const bool clo = vlo && state == 0;
+      bool has = clo;
+      float key = -(flo * flo) * wz;
       int id = li;
-      if (vlo && state == 0) key = -(slo * slo) * wz - 1e-300;
       if (vup && state == 0) {
-        const double ku = -(sup * sup) * wz - 1e-300;
-        if (ku < key) key = ku, id = 64 + li;
+        const float ku = -(fup * fup) * wz;
+        if (!clo || ku < key) key = ku, id = 64 + li;
+        has = true;
       }
       if constexpr (DENSE) {
-        if (dlane && dr >= n_eq && state == 0 && u * ginv < thr_d) key = -(u * u) * wz - 1e-300;
+        if (dlane && dr >= n_eq && state == 0 && u * ginv < thr_d) {
+          const float fu = static_cast<float>(u);
+          key = -(fu * fu) * wz;
+          has = true;
+        }
       }
-      const float best32 = group_min32<W>(key < 0.0 ? key32_pack(key, id) : 3.0e38f);
+      const float best32 = group_min32<W>(has ? key32_packf(key, id) : 3.0e38f);
       const bool none = !(best32 < 0.0f);
-      const bool bad = group_first_lane<W>(conflict) < W;
+      // A fixed coordinate sits on its bound: its other bound can only be violated when the box is empty, and so are
+      // both bounds of a free one -- quadprog's "constraints are inconsistent".  Only a wave that holds an empty box
+      // looks for it.
+      bool bad = false;
+      if (empty_box_somewhere) bad = group_first_lane<W>((vlo && vup) || (state != 0 && in && (vlo || vup))) < W;
       if (sel) {
         uplus = 0.0;
         if (bad) {

@@ -279,6 +279,7 @@ __device__ __forceinline__ double fast_rsqrt1(double x) {
 
 // hardware reciprocal seed only (~2^-26 relative... v_rcp_f64 gives ~1e-8): for keys that merely rank candidates
 __device__ __forceinline__ double approx_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ float approx_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
@@ -457,6 +458,10 @@ __device__ __forceinline__ float key32_pack(double v, int payload) {
   // keys are negative; clamped into the normal floats so that neither -inf | payload (a NaN that v_min_f32 drops)
   // nor -0.0f (which reads as "none") can come out of the cast
   const float f = fmaxf(fminf(static_cast<float>(v), -1.17549435e-38f), -3.0e38f);
+  return __int_as_float((__float_as_int(f) & ~0xFF) | (payload & 0xFF));
+}
+__device__ __forceinline__ float key32_packf(float v, int payload) {
+  const float f = fmaxf(fminf(v, -1.17549435e-38f), -3.0e38f);
   return __int_as_float((__float_as_int(f) & ~0xFF) | (payload & 0xFF));
 }
 __device__ __forceinline__ int key32_payload(float k) { return __float_as_int(k) & 0xFF; }

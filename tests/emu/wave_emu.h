@@ -190,6 +190,7 @@ inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline double fast_rcp1(double x) { return 1.0 / x; }
 inline double approx_rcp(double x) { return 1.0 / x; }
+inline float approx_rcpf(float x) { return 1.0f / x; }
 inline double fast_rsqrt1(double x) { return 1.0 / std::sqrt(x); }
 
 inline bool wave_any(bool p) {
@@ -295,6 +296,15 @@ inline double group_min(double v) {
 // 32-bit arg-min key (wave.h): float with the payload in its low 8 mantissa bits
 inline float key32_pack(double v, int payload) {
   const float f = std::fmax(std::fmin(static_cast<float>(v), -1.17549435e-38f), -3.0e38f);
+  int b;
+  std::memcpy(&b, &f, 4);
+  b = (b & ~0xFF) | (payload & 0xFF);
+  float r;
+  std::memcpy(&r, &b, 4);
+  return r;
+}
+inline float key32_packf(float v, int payload) {
+  const float f = std::fmax(std::fmin(v, -1.17549435e-38f), -3.0e38f);
   int b;
   std::memcpy(&b, &f, 4);
   b = (b & ~0xFF) | (payload & 0xFF);
