@@ -254,6 +254,10 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   // per lane: state 0 = free coordinate / inactive row, 1 = fixed at lb / active row, 2 = fixed at ub;
   // x = coordinate value; u = multiplier (fixed coordinate, active row) or slack h - g x (inactive row)
   int state = 0;
+  // ... and as factors of the update of a step (kept in registers, changed where the state changes): phi = -1 / +1 for a
+  // coordinate fixed at lb / ub and +1 for an active inequality row (the multiplier moves by -phi col nu and may block),
+  // xfree = 1 for a free coordinate (x moves by -col nu)
+  double phi = 0.0, xfree = 1.0;
   // group-uniform
   int it = 0, eq_next = 0, src = 0, kind = 0;  // kind 0: lower bound, 1: upper bound, 2: dense row, 3: equality row
   double uplus = 0.0;
@@ -459,24 +463,22 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     // column: free coordinates x -= col nu, multipliers of fixed coordinates u -= phi col nu (phi = -1 at lb, +1 at
     // ub), multipliers of active rows / slacks of inactive rows u -= col nu.  Full step: the entering constraint
     // becomes tight, nu = num / (-pv); it is cut short where the first multiplier reaches zero.
-    const double rz = lin_dep ? 0.0 : fast_rcp1(-pv);
+    // (BIG stands for "no bound on the step")
+    const double rz = fast_rcp1(-pv);
     const double sgn = (num >= 0.0) ? 1.0 : -1.0;
-    const double full = lin_dep ? INF : fabs(num) * rz;
-    double phi = 0.0;
-    if (li < NV) phi = (state == 1) ? -1.0 : (state == 2 ? 1.0 : 0.0);
-    else if (DENSE && state == 1) phi = (dr >= n_eq) ? 1.0 : 0.0;  // equalities never leave
+    const double full = lin_dep ? BIG : fabs(num) * rz;
     const double rate = phi * col * sgn;
     const bool blocking = act && rate > 0.0;
-    const double ratio = blocking ? (u > 0.0 ? u * fast_rcp1(rate) : 0.0) : BIG;
+    const double ratio = blocking ? fmax(u, 0.0) * fast_rcp1(rate) : BIG;
     const double k1 = group_min<W>(ratio);
     const int kd = group_first_lane<W>(blocking && ratio == k1) & (W - 1);
-    const double t1 = (k1 < BIG) ? k1 : INF;
-    const double tstep = (t1 < full) ? t1 : full;
+    const double tstep = (k1 < full) ? k1 : full;
+    const bool stuck = !(tstep < BIG);
     double hs = 0.0;
     if constexpr (DENSE) {
-      if (wave_any(act && !(tstep < INF))) hs = group_bcast<W>(hv, src);  // (cross-lane: wave-uniform control flow)
+      if (wave_any(act && stuck)) hs = group_bcast<W>(hv, src);  // (cross-lane: wave-uniform control flow)
     }
-    if (act && !(tstep < INF)) {
+    if (act && stuck) {
       if (DENSE && kind == 3 && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
         // equality implied by the active ones and already satisfied: nothing to add
         ++eq_next;
@@ -486,19 +488,16 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         running = false;
       }
     }
-    const bool act2 = act && running && (tstep < INF);
-    const bool do_add = act2 && !(t1 < full);
+    const bool act2 = act && running && !stuck;
+    const bool do_add = act2 && !(k1 < full);
     const bool do_drop = act2 && !do_add;
-    if (act2) {
-      const double nu = sgn * tstep;
+    {
+      const double nu = act2 ? sgn * tstep : 0.0;
       const double d = col * nu;
-      if (li < NV) {
-        if (state == 0) x -= d;
-        else u -= phi * d;
-      } else {
-        u -= d;
-      }
-      uplus += (kind == 3) ? nu : tstep;
+      x = fma(-xfree, d, x);
+      u = fma((DENSE && li >= NV) ? -1.0 : -phi, d, u);  // rows: slack or multiplier, both move by -col nu
+      if constexpr (DENSE) uplus += (kind == 3) ? nu : fabs(nu);
+      else uplus += fabs(nu);
     }
     PINKHIP_TICK(5);  // step lengths, x / u update
     // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves; the
@@ -512,9 +511,12 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         if (li < NV) {
           state = kind + 1;
           x = (kind == 0) ? lbv : ubv;
+          phi = (kind == 0) ? -1.0 : 1.0;
         } else {
           state = 1;
+          phi = (DENSE && dr >= n_eq) ? 1.0 : 0.0;  // equalities never leave
         }
+        xfree = 0.0;
         u = uplus;
       }
       if (DENSE && kind == 3) ++eq_next;
@@ -530,6 +532,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         if (li == kd) {
           state = 0;
           u = 0.0;
+          phi = 0.0;
+          xfree = 1.0;
         }
       }
     }
@@ -537,11 +541,10 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     {
       // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
       // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
-      const bool piv = pi >= 0;
       const double sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
-      const double rp = fast_rcp(pvt);
-      double t = piv ? col * rp : 0.0;
-      double cp = piv ? col : 0.0;
+      const double rp = (pi >= 0) ? fast_rcp(pvt) : 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
+      double t = col * rp;
+      double cp = col;
       if (li == pi) {
         // lane pi: its row becomes sg col / p -- as T[pi][j] - (1 - sg / p) col_j -- and the column the other lanes
         // see at j = pi is p - sg, so that their entry T[m][pi] - t_m (p - sg) becomes sg t_m
