@@ -90,13 +90,19 @@ def test_makefile_builds_every_instantiation_of_the_dispatch_table():
     assert rollout == [f"{nv}_{w}" for nv, w in rpairs] and set(rpairs) <= set(pairs) and all(int(w) >= 16 for _, w in rpairs)
     # the sweep-tableau kernel: one unit per (NV, MD, W) of PINKHIP_SWEEP_TABLE, NV + MD tableau rows on W lanes
     src = open(os.path.join(csrc, "dispatch.h")).read()
-    st = src[src.index("#define PINKHIP_SWEEP_TABLE(X)  "):]
-    st = st[:st.index("#endif")]
-    triples = re.findall(r"X\((\d+), (\d+), (\d+)\)", st)
-    mk = open(os.path.join(csrc, "Makefile")).read()
-    sweep = re.search(r"^SWEEP\s*:=\s*(.*?)\nifdef", mk.replace("\\\n", " "), re.M | re.S).group(1).split()
+    def table(name):
+        t = src[src.rindex(f"#define {name}(X) "):]  # (the real tables follow the development ones)
+        t = t[:re.search(r"\n(?!\s*X\()", t).start()]  # the define and its continuation lines
+        return re.findall(r"X\((\d+), (\d+), (\d+)\)", t)
+
+    mk = open(os.path.join(csrc, "Makefile")).read().replace("\\\n", " ")
+    triples = table("PINKHIP_SWEEP_TABLE")
+    sweep = re.search(r"^SWEEP\s*:=\s*(.*)$", mk, re.M).group(1).split()
     assert sweep == [f"{nv}_{md}_{w}" for nv, md, w in triples] and len(triples) >= 20
-    for nv, md, w in triples:
+    dense = table("PINKHIP_ROLLOUT_DENSE_TABLE")
+    rdense = re.search(r"^RDENSE\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert rdense == [f"{nv}_{md}_{w}" for nv, md, w in dense] and len(dense) >= 4
+    for nv, md, w in triples + dense:
         assert int(nv) + int(md) <= int(w) and int(nv) % 2 == 0 and int(w) in (16, 32, 64)
 
 
