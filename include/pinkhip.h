@@ -242,6 +242,9 @@ typedef struct pinkhip_step {
   const double *q_target;     /* posture target, NULL: no posture rows */
   double *lb, *ub;            /* [B,nv] */
   int32_t e_off;
+  const double *root_box;     /* [12] device, or NULL: lo[6], hi[6] of the free-flyer's tangent coordinates -- the
+                                 axis-aligned rows of a FloatingBaseVelocityLimit
+                                 (pink/limits/floating_base_velocity_limit.py:104-148), constant in q */
 } pinkhip_step;
 int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, const pinkhip_step *args);
 /* The whole control step in ONE kernel: forward kinematics, FrameTask rows, limits, posture error, stacking,
@@ -275,6 +278,16 @@ typedef struct pinkhip_rollout_step {
   int64_t sT_b, sT_f;        /* strides (doubles) of T_target: pose of instance b, frame f at T_target + b sT_b + f sT_f;
                                 both 0: the contiguous [B,nf,12] (12 nf, 12).  (12, 12 B) addresses one [B,12] array per
                                 frame, uploaded as it is (pink_amd.FrameTask.set_target_poses) */
+  /* FloatingBaseVelocityLimit (pink/limits/floating_base_velocity_limit.py:104-148): +-J_root dq <= dt twist_max with
+   * J_root the (constant) Jacobian of a frame attached to the root joint on the root's six tangent coordinates.  Its
+   * axis-aligned rows arrive as root_box ([12] device: lo[6], hi[6]; NULL: none), the others as the FIRST
+   * n_limit_rows of the desc.md dense rows (Pink stacks limits before barriers, pink/solve_ik.py:62-84): row d is
+   * limit_rows[6 d ..] on the root coordinates, right-hand side limit_h[d].  The barrier_* tables then hold
+   * desc.md - n_limit_rows entries and desc.barrier_rows offsets start at n_limit_rows. */
+  const double *root_box;
+  int32_t n_limit_rows;
+  const double *limit_rows;  /* [n_limit_rows,6] device */
+  const double *limit_h;     /* [n_limit_rows] device */
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);

@@ -93,6 +93,7 @@ class Step(ctypes.Structure):
         ("e", ctypes.c_void_p), ("sE", ctypes.c_int64), ("J", ctypes.c_void_p), ("sJ", ctypes.c_int64),
         ("dt", ctypes.c_double), ("config_limit_gain", ctypes.c_double),
         ("q_target", ctypes.c_void_p), ("lb", ctypes.c_void_p), ("ub", ctypes.c_void_p), ("e_off", ctypes.c_int32),
+        ("root_box", ctypes.c_void_p),
     ]
 
 
@@ -107,6 +108,8 @@ class RolloutStep(ctypes.Structure):
         ("barrier_frame", ctypes.c_void_p), ("barrier_axis", ctypes.c_void_p), ("barrier_sign", ctypes.c_void_p),
         ("barrier_bound", ctypes.c_void_p), ("barrier_gain", ctypes.c_void_p),
         ("sT_b", ctypes.c_int64), ("sT_f", ctypes.c_int64),
+        ("root_box", ctypes.c_void_p), ("n_limit_rows", ctypes.c_int32), ("limit_rows", ctypes.c_void_p),
+        ("limit_h", ctypes.c_void_p),
     ]
 
 

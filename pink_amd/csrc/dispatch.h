@@ -29,7 +29,7 @@
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
 #define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
 // ... and, with position-barrier rows formed on chip (X(NV, MD, W): NV + MD tableau rows on W lanes), for these
-#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(12, 4, 16) X(30, 8, 64) X(34, 8, 64) X(50, 6, 64) X(56, 8, 64)
+#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(12, 4, 16) X(30, 8, 64) X(34, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
   X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
 #endif

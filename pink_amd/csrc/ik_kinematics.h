@@ -153,11 +153,21 @@ __device__ inline void integrate_joint(const ModelDev &m, int j, double *q, cons
 }
 
 // merged box of ConfigurationLimit + VelocityLimit for tangent coordinate j whose joint has the scalar
-// configuration qi (configuration_limit.py:50-56, 111-120; velocity_limit.py:61-64, 118-120)
-__device__ inline void coordinate_box(const ModelDev &m, int j, int jt, double qi, double dt, double gain, double &lo, double &hi) {
+// configuration qi (configuration_limit.py:50-56, 111-120; velocity_limit.py:61-64, 118-120).  root_box (or NULL):
+// lo[6], hi[6] for the tangent coordinates of the free-flyer -- the axis-aligned rows of a
+// FloatingBaseVelocityLimit (floating_base_velocity_limit.py:104-148), which do not depend on q.
+__device__ inline void coordinate_box(const ModelDev &m, int j, int jt, double qi, double dt, double gain, double &lo, double &hi,
+                                      const double *root_box = nullptr) {
   lo = -INFINITY;
   hi = INFINITY;
-  if (m.jtype[jt] == JOINT_FREE_FLYER) return;
+  if (m.jtype[jt] == JOINT_FREE_FLYER) {
+    if (root_box) {
+      const int sub = j - m.idx_v[jt];
+      lo = root_box[sub];
+      hi = root_box[6 + sub];
+    }
+    return;
+  }
   const int iq = m.idx_q[jt];
   const double qmin = m.q_min[iq], qmax = m.q_max[iq], vmax = m.v_max[j];
   if (qmax < 1e20 && qmax > qmin + 1e-10) {
@@ -193,6 +203,7 @@ struct FkArgs {
   int *first_failure = nullptr;     // [B] sticky status | (step << 8), may be NULL
   int step = 0;
   double dt = 0.0, config_limit_gain = 0.5;
+  const double *root_box = nullptr;  // [12] box of the free-flyer's tangent coordinates (coordinate_box), or NULL
   const double *q_target = nullptr;  // [B, nq] / [nq] posture target, NULL: no posture rows
   int target_batched = 0;
   double *lb = nullptr, *ub = nullptr;  // [B, nv]
@@ -451,7 +462,7 @@ __device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *si
       // 5. merged box limits and the posture error of tangent coordinate j (qs was published before step 2's barriers)
       const double qi = qs[jt];
       double lo, hi;
-      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi);
+      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi, a.root_box);
       if constexpr (Sink::kKeep) {
         sink->lb = lo;
         sink->ub = hi;

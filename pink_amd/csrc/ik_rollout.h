@@ -27,6 +27,12 @@ struct RolloutArgs {
   // (pink/barriers/barrier.py:246-254), both formed on chip from the world twists of the joint axes
   const int *bar_frame = nullptr, *bar_axis = nullptr;
   const double *bar_sign = nullptr, *bar_bound = nullptr, *bar_gain = nullptr;
+  // FloatingBaseVelocityLimit rows that are not axis-aligned (floating_base_velocity_limit.py:128-148): the FIRST n_lim
+  // of the k.md dense rows (Pink stacks limits before barriers, solve_ik.py:62-84), constant: row d is lim_rows[6 d ..]
+  // on the six tangent coordinates of the root joint, zero elsewhere, with right-hand side lim_h[d].  The bar_*
+  // tables are indexed by d - n_lim.
+  int n_lim = 0;
+  const double *lim_rows = nullptr, *lim_h = nullptr;
 };
 
 // doubles of kinematics scratch per robot: joint poses, ancestor pointers, U / V blocks, frame errors, joint scalars
@@ -64,7 +70,11 @@ struct FkTerms {
   const double *bar_sign = nullptr, *bar_bound = nullptr, *bar_gain = nullptr;
   const double *pfs = nullptr;  // LDS: frame f's world position at pfs[12 f + 9 .. 11]
   double inv_dt = 0.0;
+  int n_lim = 0, root_sub = -1;  // constant rows of the floating-base limit; this lane's coordinate of the root joint
+  const double *lim_rows = nullptr, *lim_h = nullptr;
   __device__ __forceinline__ double dense_col(int d) const {
+    if (d < n_lim) return root_sub >= 0 ? lim_rows[6 * d + root_sub] : 0.0;
+    d -= n_lim;
     const int f = bar_frame[d], i = bar_axis[d];
     const double *pf = pfs + 12 * f + 9;
     const double v0 = lin[0] + ang[1] * pf[2] - ang[2] * pf[1];
@@ -74,6 +84,8 @@ struct FkTerms {
     return (((anc >> f) & 1u) != 0) ? -bar_sign[d] * vi * inv_dt : 0.0;
   }
   __device__ __forceinline__ double dense_h(int d) const {
+    if (d < n_lim) return lim_h[d];
+    d -= n_lim;
     return bar_gain[d] * bar_sign[d] * (pfs[12 * bar_frame[d] + 9 + bar_axis[d]] - bar_bound[d]);
   }
 };
@@ -98,6 +110,11 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
     t.bar_sign = a.bar_sign, t.bar_bound = a.bar_bound, t.bar_gain = a.bar_gain;
     t.pfs = sm + 12 * m.nj;  // = fMo of ik_fk_instance
     t.inv_dt = 1.0 / a.k.dt;
+    t.n_lim = a.n_lim, t.lim_rows = a.lim_rows, t.lim_h = a.lim_h;
+    if (a.n_lim > 0 && m.root_nv == 6) {  // (the free-flyer is the first joint after the universe: columns 0 .. 5)
+      const int jt = m.dof_joint[li < m.nv ? li : 0];
+      if (li < m.nv && m.jtype[jt] == JOINT_FREE_FLYER) t.root_sub = li - m.idx_v[jt];
+    }
   }
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();

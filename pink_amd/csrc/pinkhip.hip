@@ -724,6 +724,7 @@ int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, co
   a.step = st->step;
   a.dt = st->dt;
   a.config_limit_gain = st->config_limit_gain;
+  a.root_box = st->root_box;
   a.q_target = st->q_target;
   a.target_batched = st->target_batched;
   a.lb = st->lb;
@@ -753,8 +754,13 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   if (desc->B == 0) return PINKHIP_OK;
   if (desc->nv != md.nv || desc->Kd != 6 * md.nf || desc->n_eq != 0)
     return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, Kd = 6 nf, n_eq = 0)");
-  if (desc->md > 0 && (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain))
-    return fail(h, PINKHIP_E_INVALID, "md > 0 rows of position barriers need the barrier_* tables");
+  if (st->n_limit_rows < 0 || st->n_limit_rows > desc->md || (st->n_limit_rows > 0 && (!st->limit_rows || !st->limit_h)))
+    return fail(h, PINKHIP_E_INVALID, "n_limit_rows must lie in [0, md] and come with limit_rows / limit_h");
+  if (desc->md > st->n_limit_rows &&
+      (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain))
+    return fail(h, PINKHIP_E_INVALID, "rows of position barriers need the barrier_* tables");
+  if ((st->root_box || st->n_limit_rows) && md.root_nv != 6)
+    return fail(h, PINKHIP_E_INVALID, "a floating-base velocity limit needs a free-flyer root joint");
   const int n_post = desc->K - desc->Kd;
   if (desc->T != md.nf + (n_post ? 1 : 0)) return fail(h, PINKHIP_E_INVALID, "expected one dense task per frame (+ one diagonal task)");
   for (int t = 0; t < md.nf; ++t)
@@ -779,6 +785,9 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     ra.bar_sign = st->barrier_sign;
     ra.bar_bound = st->barrier_bound;
     ra.bar_gain = st->barrier_gain;
+    ra.n_lim = st->n_limit_rows;
+    ra.lim_rows = st->limit_rows;
+    ra.lim_h = st->limit_h;
   } else {
     pc = pinkhip::select_rollout(md.nv, md.nj, fkd);
     if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
@@ -799,6 +808,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   f.sTf = (st->sT_b || st->sT_f) ? st->sT_f : 12;
   f.dt = desc->dt;
   f.config_limit_gain = st->config_limit_gain;
+  f.root_box = st->root_box;
   f.q_target = n_post ? st->q_target : nullptr;
   f.target_batched = st->target_batched;
   ra.integrate = st->integrate;

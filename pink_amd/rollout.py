@@ -90,6 +90,26 @@ class ModelArrays:
         self.desc = d
 
 
+def _floating_base_rows(model, limit, dt: float):
+    """``(root_box [12], rows [n, 6], h [n])`` of a :class:`~pink_amd.limits.FloatingBaseVelocityLimit`
+    (``pink/limits/floating_base_velocity_limit.py:104-148``): ``+-A dq_root <= dt twist_max`` with ``A`` the adjoint
+    of the inverse placement of the limit's frame on the root joint -- the body Jacobian of that frame on the root's
+    tangent coordinates, whatever the configuration.  ``(None, ...)`` when no component is bounded."""
+    from .batch import split_box_rows
+    from .configuration import _adjoint
+
+    finite = np.isfinite(limit.twist_max)
+    if not finite.any():
+        return None, np.zeros((0, 6)), np.zeros(0)
+    if limit.root_nv != 6:
+        raise ValueError("the floating-base velocity limit on the device needs a free-flyer root joint")
+    frame = model.frames[model.getFrameId(limit.base_frame)]
+    A = _adjoint(frame.placement.inverse())[finite]
+    bounds = float(dt) * limit.twist_max[finite]
+    lb, ub, G, h = split_box_rows(np.vstack([A, -A]), np.hstack([bounds, bounds]), 6)
+    return np.ascontiguousarray(np.hstack([lb, ub])), np.ascontiguousarray(G), np.ascontiguousarray(h)
+
+
 class DeviceRollout:
     """``B`` robots iterating differential IK on the device.
 
@@ -113,7 +133,7 @@ class DeviceRollout:
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
-                 position_barriers: Sequence = ()):
+                 position_barriers: Sequence = (), floating_base_limit=None):
         self.api, self.model, self.dt = api, model, float(dt)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
@@ -142,7 +162,16 @@ class DeviceRollout:
         self.cost = np.ascontiguousarray(cost if cost else [0.0], dtype=np.float64)
         # position barriers (pink/barriers/position_barrier.py): one dense row per (index, side), rows in Pink's order
         # (p_min rows, then p_max rows); formed on chip by the whole-step kernel (fused="kernel" only)
-        bf, ba, bs, bb, bg, brow, bsafe = [], [], [], [], [], [0], []
+        # FloatingBaseVelocityLimit (pink/limits/floating_base_velocity_limit.py:104-148): the Jacobian of a frame attached
+        # to the root joint, on the root's tangent coordinates, is the constant adjoint of the frame's placement -- its
+        # axis-aligned rows become a box on those coordinates, the others the first dense rows (constant too)
+        self.root_box, self.lim_rows, self.lim_h = None, np.zeros((0, 6)), np.zeros(0)
+        if floating_base_limit is not None:
+            self.root_box, self.lim_rows, self.lim_h = _floating_base_rows(model, floating_base_limit, self.dt)
+            if self.fused is False and self.root_box is not None:
+                raise ValueError("a floating-base velocity limit needs fused=True or fused=\"kernel\"")
+        n_lim = len(self.lim_h)
+        bf, ba, bs, bb, bg, brow, bsafe = [], [], [], [], [], [n_lim], []
         for bar in position_barriers:
             if bar.frame not in self.frames:
                 raise ValueError(f"position barrier on frame {bar.frame!r}: the frame must carry one of the frame tasks")
@@ -157,11 +186,11 @@ class DeviceRollout:
                 for i, idx in enumerate(bar.indices):
                     bf.append(f), ba.append(int(idx)), bs.append(sign), bb.append(float(np.asarray(bound)[i])), bg.append(float(gains[k]))
                     k += 1
-            brow.append(len(bf))
+            brow.append(n_lim + len(bf))
             bsafe.append(float(bar.safe_displacement_gain))
-        self.md = len(bf)
+        self.md = n_lim + len(bf)
         if self.md and self.fused != "kernel":
-            raise ValueError('position barriers need the whole-step kernel: fused="kernel"')
+            raise ValueError('position barriers and dense floating-base limit rows need the whole-step kernel: fused="kernel"')
         self.brow = np.ascontiguousarray(brow, dtype=np.int32)
         self.bsafe = np.ascontiguousarray(bsafe if bsafe else [0.0], dtype=np.float64)
         self._bar_host = [np.ascontiguousarray(v if v else [0], dtype=t) for v, t in
@@ -194,8 +223,13 @@ class DeviceRollout:
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self.d_qt = f8(B, nq)
-        self.d_bar = []
-        if self.md:
+        self.d_bar, self.d_lim = [], []
+        for arr in ([] if self.root_box is None else [self.root_box, np.ascontiguousarray(self.lim_rows), self.lim_h]):
+            ptr = a.alloc(max(arr.nbytes, 8))
+            if arr.nbytes:
+                a.put(ptr, arr)
+            self.d_lim.append(ptr)
+        if self.md > n_lim:
             for arr in self._bar_host:
                 ptr = a.alloc(max(arr.nbytes, 8))
                 a.put(ptr, arr)
@@ -309,6 +343,7 @@ class DeviceRollout:
             st.dt, st.config_limit_gain = self.dt, self.config_limit_gain
             st.q_target = self.d_qt if self.n_post else None
             st.lb, st.ub, st.e_off = self.d_lb, self.d_ub, self.Kd
+            st.root_box = self.d_lim[0] if self.d_lim else None
             a.step_kernel(self.dmodel, B, st)
             a.solve_raw(self.desc, self.problem, self.result)
             self._pending = bool(integrate)
@@ -335,8 +370,11 @@ class DeviceRollout:
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
-        if self.md:
+        if self.d_bar:
             st.barrier_frame, st.barrier_axis, st.barrier_sign, st.barrier_bound, st.barrier_gain = self.d_bar
+        if self.d_lim:
+            st.root_box, st.limit_rows, st.limit_h = self.d_lim
+            st.n_limit_rows = len(self.lim_h)
         return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def flush(self) -> None:
@@ -409,7 +447,7 @@ class DeviceRollout:
     def free(self) -> None:
         for name in self._BUFFERS:
             self.api.release(getattr(self, name, None))
-        for ptr in getattr(self, "d_bar", []):
+        for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []):
             self.api.release(ptr)
-        self.d_bar = []
+        self.d_bar, self.d_lim = [], []
         self.api.model_destroy(self.dmodel)

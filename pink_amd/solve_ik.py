@@ -323,8 +323,6 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     if isinstance(configurations, ConfigurationBatch):
         # arrays in, arrays out: the tasks are shared objects carrying per-instance targets as arrays
         model, q = configurations.model, configurations.q
-        if getattr(model, "floating_base_velocity_limit", None) is not None:
-            return None
         specs, targets, posture = [], [], None
         for t in tasks:
             if type(t) is FrameTask:
@@ -359,7 +357,7 @@ def _device_kinematics_plan_tasks(configurations, tasks):
             return None
         return model, q, specs, targets, posture  # (targets: one [B, 12] array per frame task, uploaded as they are)
     model = configurations[0].model
-    if any(c.model is not model for c in configurations) or getattr(model, "floating_base_velocity_limit", None) is not None:
+    if any(c.model is not model for c in configurations):
         return None
     per_instance = len(tasks) == B and isinstance(tasks[0], (list, tuple))
     if per_instance:
@@ -436,8 +434,10 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
     model, q, specs, T, posture, bars = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
+    fb = getattr(model, "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
+    fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
     key = (id(model), B, tuple(specs), float(dt), float(damping), pkey, int(max_iter),
-           float(model.configuration_limit.config_limit_gain), tuple(_barrier_key(b) for b in bars))
+           float(model.configuration_limit.config_limit_gain), tuple(_barrier_key(b) for b in bars), fkey)
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     if ro is None:
@@ -445,7 +445,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
         if posture is not None:
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
-                           max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, **kw)
+                           max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
     else:
         ro.reset(q, None if posture is None else posture[3], safety_break)

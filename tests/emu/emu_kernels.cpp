@@ -242,6 +242,7 @@ int pinkhip_emu_step(void *mp, long long B, const pinkhip_step *st) {
   a.step = st->step;
   a.dt = st->dt;
   a.config_limit_gain = st->config_limit_gain;
+  a.root_box = st->root_box;
   a.q_target = st->q_target;
   a.target_batched = st->target_batched;
   a.lb = st->lb;
@@ -297,6 +298,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   f.sTf = (st->sT_b || st->sT_f) ? st->sT_f : 12;
   f.dt = d->dt;
   f.config_limit_gain = st->config_limit_gain;
+  f.root_box = st->root_box;
   f.q_target = (d->K > d->Kd) ? st->q_target : nullptr;
   f.target_batched = st->target_batched;
   ra.integrate = st->integrate;
@@ -315,6 +317,9 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
     ra.bar_sign = st->barrier_sign;
     ra.bar_bound = st->barrier_bound;
     ra.bar_gain = st->barrier_gain;
+    ra.n_lim = st->n_limit_rows;
+    ra.lim_rows = st->limit_rows;
+    ra.lim_h = st->limit_h;
     switch (dc.NV * 100 + dc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \

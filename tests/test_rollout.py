@@ -247,6 +247,88 @@ def test_closed_loop_with_position_barriers_matches_host_loop(api, which):
     ro.free()
 
 
+@pytest.mark.parametrize("placement", ["identity", "offset", "rotated"])
+def test_closed_loop_with_floating_base_velocity_limit_matches_host_loop(api, placement):
+    """FloatingBaseVelocityLimit (pink/limits/floating_base_velocity_limit.py:104-148) on the device: the Jacobian of
+    a frame attached to the root joint is constant on the root columns, so its axis-aligned rows are a box on the root
+    coordinates (identity placement: all twelve) and the others the first dense rows of the whole-step kernel
+    (offset: six, rotated: twelve), stacked before a PositionBarrier's as Pink does.  The closed loop follows the host
+    loop -- solve_ik with the limit attached to the model, as pink/solve_ik.py:94-105 picks it up -- to 1e-8, and the
+    limit binds along the way."""
+    from pink_amd import solve_ik_batch
+    from pink_amd.barriers import PositionBarrier
+    from pink_amd.limits import FloatingBaseVelocityLimit
+    from pink_amd.rollout import _floating_base_rows
+
+    model, frames = _models()[1]
+    root_id = model.joints.index(model.root_joint)
+    Rz = exp6(np.array([0, 0, 0, 0.3, -0.2, 0.5])).rotation
+    T = {"identity": SE3(np.eye(3), np.zeros(3)), "offset": SE3(np.eye(3), [0.05, -0.02, 0.1]), "rotated": SE3(Rz, [0.05, -0.02, 0.1])}[placement]
+    model.add_frame("pelvis", root_id, T)
+    rng = np.random.default_rng(90)
+    B, dt, steps = 3, 5e-3, 20
+    q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
+    q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    limit = FloatingBaseVelocityLimit(model, "pelvis", max_linear_velocity=[0.2, 0.3, np.inf], max_angular_velocity=0.5)
+    box, rows, h = _floating_base_rows(model, limit, dt)
+    assert len(h) == {"identity": 0, "offset": 4, "rotated": 10}[placement]
+    assert np.isfinite(box).sum() == {"identity": 10, "offset": 6, "rotated": 0}[placement]
+    cfgs = [Configuration(model, q0[b]) for b in range(B)]
+    specs = [(f, 1.0, 0.5 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
+    p0 = np.array([[c.get_transform_frame_to_world(f).translation for f in frames] for c in cfgs])
+    bars = [PositionBarrier(frames[0], indices=[2], p_max=np.array([p0[:, 0, 2].max() + 0.05]), gain=np.array([50.0]))]
+    targets = np.zeros((B, len(frames), 12))
+    host_tasks = []
+    for b, cfg in enumerate(cfgs):
+        tl = []
+        for i, (f, pc, oc, gain, lm) in enumerate(specs):
+            t = FrameTask(f, pc, oc, lm_damping=lm, gain=gain)
+            tgt = cfg.get_transform_frame_to_world(f).copy()
+            tgt.translation = tgt.translation + np.array([0.3, -0.2, 0.1])  # far: the base wants to move fast
+            t.set_target(tgt)
+            targets[b, i] = pose12(tgt)
+            tl.append(t)
+        p = PostureTask(cost=1e-1)
+        p.set_target(q0[b])
+        tl.append(p)
+        host_tasks.append(tl)
+    model.floating_base_velocity_limit = limit
+    try:
+        V_dev = solve_ik_batch(cfgs, host_tasks, dt, barriers=bars, device_kinematics=True)
+        bound = False
+        for b, cfg in enumerate(cfgs):
+            v = solve_ik(cfg, host_tasks[b], dt, barriers=bars)
+            assert np.abs(V_dev[b] - v).max() < 1e-8
+            twist = cfg.get_frame_jacobian("pelvis")[:, :6] @ v[:6]
+            assert (np.abs(twist) <= limit.twist_max + 1e-9).all()
+            bound |= bool((np.abs(twist) > limit.twist_max - 1e-6).any())
+        assert bound  # the limit is active in the first step of at least one robot
+        pink_amd.clear_device_cache()
+        ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-1, fused="kernel", position_barriers=bars, floating_base_limit=limit)
+        ro.set_targets(targets)
+        ro.run(steps)
+        assert ro.fused == "kernel" and ro.md == len(h) + 1
+        qd = ro.configurations()
+        _, st, _ = ro.last_step()
+        assert (st == 0).all()
+        for b, cfg in enumerate(cfgs):
+            for _ in range(steps):
+                cfg.integrate_inplace(solve_ik(cfg, host_tasks[b], dt, barriers=bars), dt)
+            assert np.abs(qd[b] - cfg.q).max() < 1e-8
+        ro.free()
+        if placement == "identity":  # a box only: the two-launch path (step kernel + solve) takes it too
+            ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-1, fused=True, floating_base_limit=limit)
+            ro.set_targets(targets)
+            ro.step(integrate=False)
+            dq2, st2, _ = ro.last_step()
+            for b in range(B):
+                v = solve_ik(Configuration(model, q0[b]), host_tasks[b], dt)
+                assert st2[b] == 0 and np.abs(dq2[b] / dt - v).max() < 1e-8
+            ro.free()
+    finally:
+        model.floating_base_velocity_limit = None
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_fused_fk_frame_tasks_equal_separate_launches(api, which):
     """pinkhip_fk_frame_tasks_device writes the same e / J rows into the packed streams as
