@@ -387,6 +387,27 @@ def traffic_from_profiles():
         return None, "no PMC pass committed for these sources"
 
 
+def _valu_issue(kernel_ms: float, n_cu: int):
+    """VALU-issue roofline of the solve kernel: wavefront-level VALU instructions per launch (SQ_INSTS_VALU of the
+    committed counter pass, same kernel sources) over the live launch duration, against the issue rate of the SIMDs --
+    n_cu x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per SIMD; fp64 FMA has the full rate on
+    MI355X), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)."""
+    import __graft_entry__ as g
+
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
+        if t.get("source_hash") != g._source_hash(g.HIP_DEPS) or "solve_kernel_valu_instructions_per_launch" not in t:
+            return None
+    except (OSError, ValueError):
+        return None
+    insts = t["solve_kernel_valu_instructions_per_launch"]
+    peak = n_cu * 4 * 2.4e9 / 4 / 1e9
+    achieved = insts / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "valu issue", "achieved": achieved, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": achieved / peak,
+            "valu_instructions_per_launch": insts, "fma_f64_share": t.get("solve_kernel_fma_f64_instructions_per_launch", 0.0) / insts,
+            "source": "SQ_INSTS_VALU of profiles/sq_counters_r03.txt (rocprofv3 --pmc, same kernel sources) / kernel_ms measured here"}
+
+
 def _with_timeout(fn, seconds: float, what: str):
     """`fn()` on a daemon thread; TimeoutError if it is not back after `seconds` (collectives that never return must
     not cost the bench line; the caller then leaves the process through os._exit)."""
@@ -696,6 +717,7 @@ def main() -> None:
                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                 "model": "Kd nv (nv+1) + 2 Kd nv + nv^3/3 + 2 nv^2 + iters (4 nv^2 + 2 md nv), SURVEY.md 8(d); useful flops, not issued lanes",
             },
+            "roofline_valu_issue": _valu_issue(kernel_ms, int(info.get("compute_units") or 256)),
             "solver_stats": {"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())},
             "per_rank_kernel_ms": kernel_ms_ranks,
             "per_rank_end_to_end_ms": e2e_ranks,

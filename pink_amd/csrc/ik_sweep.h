@@ -50,6 +50,11 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #endif
 #endif
 
+// dependent FMA chains of the column extraction (two: what three or four waves per SIMD hide)
+#ifndef PINKHIP_SWEEP_COLUMN_CHAINS
+#define PINKHIP_SWEEP_COLUMN_CHAINS(NT) 2
+#endif
+
 namespace pinkhip {
 
 // LDS of one QP (doubles): the stated problem, parked for the closing refinement step
@@ -330,13 +335,14 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       return (p >= 0 && li < NT) ? c : 0.0;
     } else {
       const BcT eb = bcast_indicator<W>(p);
-      double c0 = 0.0, c1 = 0.0;
+      constexpr int NC = PINKHIP_SWEEP_COLUMN_CHAINS(NT);
+      double c[NC] = {};
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
-        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, T[j]);
       });
-      return c0 + c1;
+      if constexpr (NC == 4) return (c[0] + c[1]) + (c[2] + c[3]);
+      else return c[0] + c[1];
     }
   };
 

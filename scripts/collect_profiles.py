@@ -66,5 +66,21 @@ for k, d in per.items():
         out[f"{name}_hbm_read_bytes_per_launch"] = rd
         out[f"{name}_hbm_write_bytes_per_launch"] = wr
         out[f"{name}_hbm_bytes_per_launch"] = rd + wr
+# SQ counters of the headline kernel (scripts/gpu_profile.sh: "p<pass> NAME launches average-per-launch"): the VALU
+# instruction count per launch is what bench.py prices against the issue rate of the SIMDs (roofline_valu_issue)
+sq = os.path.join(src, "sq_counters.txt")
+if os.path.exists(sq):
+    vals = {}
+    for ln in open(sq):
+        f = ln.split()
+        if len(f) == 4 and f[0].startswith("p") and f[1].startswith("SQ_"):
+            vals[f[1]] = float(f[3])
+    for key, name in (("SQ_INSTS_VALU", "solve_kernel_valu_instructions_per_launch"), ("SQ_WAVES", "solve_kernel_waves_per_launch"),
+                      ("SQ_ACTIVE_INST_VALU", "solve_kernel_valu_active_quad_cycles_per_launch"),
+                      ("SQ_INSTS_VALU_FMA_F64", "solve_kernel_fma_f64_instructions_per_launch"),
+                      ("SQ_INSTS_SALU", "solve_kernel_salu_instructions_per_launch"),
+                      ("SQ_INSTS_LDS", "solve_kernel_lds_instructions_per_launch")):
+        if key in vals:
+            out[name] = vals[key]
 json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

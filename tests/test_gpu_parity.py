@@ -72,8 +72,9 @@ def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
     g = np.einsum("bij,bj->bi", H, dq) + c
     scale = 1.0 + np.abs(c).max(axis=1, keepdims=True)
     tol = 1e-9
-    at_lb = np.isfinite(lb) & (dq <= lb + tol * (1 + np.abs(lb)))
-    at_ub = np.isfinite(ub) & (dq >= ub - tol * (1 + np.abs(ub)))
+    with np.errstate(invalid="ignore"):  # (unbounded coordinates: inf - inf, masked by isfinite)
+        at_lb = np.isfinite(lb) & (dq <= lb + tol * (1 + np.abs(lb)))
+        at_ub = np.isfinite(ub) & (dq >= ub - tol * (1 + np.abs(ub)))
     viol = max(float(np.max(np.where(np.isfinite(lb), lb - dq, -1.0))), float(np.max(np.where(np.isfinite(ub), dq - ub, -1.0))))
     if Gd is not None and Gd.shape[1]:
         slack = hd - np.einsum("bmj,bj->bm", Gd, dq)
