@@ -51,7 +51,7 @@ extern "C" {
 #define PINKHIP_TASK_DIAGONAL 1 /* J = eye(nv)[col0:col0+k] (pink/tasks/posture_task.py:128-129) */
 
 #define PINKHIP_MAX_NV 64 /* tangent dimension supported by the wave-per-QP kernels */
-#define PINKHIP_MAX_MD 32 /* dense inequality rows per instance                      */
+#define PINKHIP_MAX_MD 64 /* dense inequality rows per instance (one lane of a 64-lane group each) */
 
 typedef struct pinkhip_handle pinkhip_handle;
 

@@ -41,7 +41,8 @@ struct PackedChoice {
 };
 
 // Smallest instantiation that holds the problem.  Lane li < md of a group owns dense row li, so a group of W
-// lanes takes at most W dense rows (PINKHIP_MAX_MD = 32 <= W for W >= 32).
+// lanes takes at most W dense rows: up to PINKHIP_MAX_MD = 64 in the 64-lane instantiations (more rows than the
+// smallest group for nv has lanes move the problem to a wider group).
 inline PackedChoice select_packed(int nv, int md) {
 #define PINKHIP_PICK(NV_, W_) \
   if (nv <= NV_ && md <= W_) return PackedChoice{NV_, W_};

@@ -612,7 +612,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
     }
     if (md > 0 && wave_any(act && (DENSE && kind >= 2))) {
       const bool dn = act && (DENSE && kind >= 2);
-      const double gi = (in && dn) ? ((kind == 3) ? Gs[(src & 31) * GP + li] : -Gs[(src & 31) * GP + li]) : 0.0;
+      const double gi = (in && dn) ? ((kind == 3) ? Gs[(src & 63) * GP + li] : -Gs[(src & 63) * GP + li]) : 0.0;
       // d_j = sum over the lanes i of J[i][j] g_i for every j at once (one group reduction per j before)
       const double dj = transpose_reduce<W, NV, 0>([&](auto Jc) { return Jr[decltype(Jc)::value] * gi; });
       if (dn) dl = dj;
@@ -788,7 +788,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
           if (kind == 0) bstate = 1;
           else if (kind == 1) bstate = 2;
         }
-        if ((DENSE && kind >= 2) && li == (src & 31)) dactive = 1;
+        if ((DENSE && kind >= 2) && li == (src & 63)) dactive = 1;
         if ((DENSE && kind >= 2) && src < n_eq) ++eq_next;
         ++q;
         need_sel = true;
@@ -802,7 +802,7 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
       if (do_drop) {
         if (!DENSE || (idk >> 6) < 2) {
           if (li == (idk & 63)) bstate = 0;
-        } else if (li == (idk & 31)) {
+        } else if (li == (idk & 63)) {
           dactive = 0;
         }
       }

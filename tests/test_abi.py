@@ -59,7 +59,7 @@ def test_descriptor_validation(emu):
     assert err(lambda a: None)[0] == 0
     for mut, word in [
         (lambda a: setattr(a.desc, "nv", 65), "nv"),
-        (lambda a: setattr(a.desc, "md", 33), "md"),
+        (lambda a: setattr(a.desc, "md", 65), "md"),
         (lambda a: setattr(a.desc, "n_eq", 1), "n_eq"),
         (lambda a: setattr(a.desc, "dt", 0.0), "dt"),
         (lambda a: setattr(a.desc, "K", 13), "task_rows"),

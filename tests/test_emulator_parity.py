@@ -24,7 +24,7 @@ def test_every_padding_class(emu, nv):
     ps.random_dims(emu, nv, B=2, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
 
 
-@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32)])
+@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32), (12, 48), (30, 64)])
 def test_dense_inequality_rows(emu, nv, md):
     ps.random_dims(emu, nv, B=3, seed=500 + nv, md=md)
 

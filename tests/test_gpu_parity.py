@@ -30,7 +30,7 @@ def test_every_padding_class(gpu_solver, nv):
     ps.random_dims(gpu_solver, nv, B=256, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
 
 
-@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32), (50, 12)])
+@pytest.mark.parametrize("nv,md", [(6, 1), (12, 5), (30, 6), (31, 32), (50, 12), (12, 48), (30, 64), (64, 64)])
 def test_dense_inequality_rows(gpu_solver, nv, md):
     ps.random_dims(gpu_solver, nv, B=256, seed=500 + nv, md=md)
 
