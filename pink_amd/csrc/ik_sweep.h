@@ -408,18 +408,20 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         running = false;
       }
     }
-    // once no group of the wave is running any more, one closing trip takes the refinement step of all of them
-    const bool ref = !wave_any(running) && !refined;
-    if (!wave_any(running || ref)) break;
+    // once no group of the wave is running any more, closing trips take the refinement steps of all of them
+    // (`closing` is wave-uniform: an ordinary trip pays one ballot and scalar branches for all of this)
+    const bool closing = !wave_any(running);
+    const bool ref = closing && !refined;
+    if (closing && !wave_any(ref)) break;
     const bool act = running;
     PINKHIP_TICK(3);  // selection
 
     // (b) column src of T: col_m = sum_j T[m][j] [j == src]; for a finishing group the product T r instead
     double col;
-    if (!PINKHIP_SWEEP_LDS_COLUMN || wave_any(ref)) {
+    if (!PINKHIP_SWEEP_LDS_COLUMN || closing) {
       BcT eb = bcast_indicator<W>(act ? src : -1);
       double rres = 0.0, sdiag = 0.0;
-      if (wave_any(ref)) {
+      if (closing) {
         rres = residual();
         if (!ref || status != STATUS_OPTIMAL) rres = 0.0;
         // (the product below meets the unmaintained copy of the diagonal inside T: replaced by the maintained one)
@@ -428,27 +430,31 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
           if (j == li) sdiag = T[j];
         eb = bcast_select<W>(ref, bcast_prepare<W>(rres), eb);
       }
-      double c0 = 0.0, c1 = 0.0;
+      constexpr int NC = PINKHIP_SWEEP_COLUMN_CHAINS(NT);
+      double c[NC] = {};
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
-        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, T[j]);
       });
-      col = c0 + c1;
-      // A correction that is not small (a nearly singular H: T is then a poor inverse, accurate to cond(H) eps) calls
-      // for another step, at most three in all: every step shrinks the residual by the relative accuracy of T.
-      const double dxv = (ref && in && state == 0) ? col + (tdiag - sdiag) * rres : 0.0;
-      const bool more = wave_any(ref) && group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
-      if (ref) {
-        x += dxv;
-        refined = !(more && ++nref < 3);
+      if constexpr (NC == 4) col = (c[0] + c[1]) + (c[2] + c[3]);
+      else col = c[0] + c[1];
+      if (closing) {
+        // A correction that is not small (a nearly singular H: T is then a poor inverse, accurate to cond(H) eps)
+        // calls for another step, at most three in all: every step shrinks the residual by the relative accuracy of T.
+        const double dxv = (ref && in && state == 0) ? col + (tdiag - sdiag) * rres : 0.0;
+        const bool more = group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
+        if (ref) {
+          x += dxv;
+          refined = !(more && ++nref < 3);
+        }
+        // (a closing trip that asks for another one falls through the rest of the body, everything masked off: a
+        // second back edge -- `continue` -- makes the register allocator keep two copies of T and move one onto the
+        // other per trip)
+        if (!wave_any(!refined)) break;
       }
     } else {
       col = column_of(act ? src : -1);
     }
-    // (a closing trip that asks for another one falls through the rest of the body, everything masked off: a second
-    // back edge -- `continue` -- makes the register allocator keep two copies of T and move one onto the other per trip)
-    if (!wave_any(act || !refined)) break;
     if (li == src) col = tdiag;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
