@@ -397,7 +397,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         } else {
           const int pl = key32_payload(best32);
           src = pl & 63;
-          kind = (src >= NV) ? 2 : (pl >> 6) & 1;
+          if constexpr (DENSE) kind = (src >= NV) ? 2 : (pl >> 6) & 1;
+          else kind = (pl >> 6) & 1;
           need_sel = false;
         }
       }
@@ -458,7 +459,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     if (li == src) col = tdiag;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
-    const double cand = (li < NV) ? ((kind == 0 ? lbv : ubv) - x) : -u;
+    double cand = (kind == 0 ? lbv : ubv) - x;
+    if constexpr (DENSE) cand = (li < NV) ? cand : -u;
     const double num = group_bcast<W>(cand, src);
     double pv = group_bcast<W>(tdiag, src);
     bool lin_dep = false;
@@ -469,7 +471,8 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       const double z0 = group_bcast<W>(zd0, src);
       lin_dep = !(-pv * 1e10 > z0);
     }
-    if (!act) pv = -1.0;
+    // (a group without an entering constraint computes on garbage from here on: everything it could change is
+    // masked by act / act2 below)
     PINKHIP_TICK(4);  // column
     // (c) step: the driving parameter nu (multiplier of the entering constraint) moves every quantity along the
     // column: free coordinates x -= col nu, multipliers of fixed coordinates u -= phi col nu (phi = -1 at lb, +1 at
@@ -481,7 +484,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     const double full = lin_dep ? BIG : fabs(num) * rz;
     const double rate = phi * col * sgn;
     const bool blocking = act && rate > 0.0;
-    const double ratio = blocking ? fmax(u, 0.0) * fast_rcp1(rate) : BIG;
+    const double ratio = blocking ? max_raw(u, 0.0) * fast_rcp1(rate) : BIG;
     const double k1 = group_min<W>(ratio);
     const int kd = group_first_lane<W>(blocking && ratio == k1) & (W - 1);
     const double tstep = (k1 < full) ? k1 : full;
@@ -553,7 +556,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     {
       // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
       // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
-      const double sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
+      const double sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
       const double rp = (pi >= 0) ? fast_rcp(pvt) : 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
       double t = col * rp;
       double cp = col;

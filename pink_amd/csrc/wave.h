@@ -173,6 +173,16 @@ __device__ __forceinline__ double min_raw(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float min_raw32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7-i within 8
@@ -477,7 +487,7 @@ __device__ __forceinline__ float group_min32(float v) {
   if (W >= 16) { PINKHIP_MIN32_DPP("row_mirror") }
   if (W >= 32) {
     const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fminf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+    v = min_raw32(__uint_as_float(p[0]), __uint_as_float(p[1]));
   }
   if (W == 64) v = fminf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0)),
                          __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32)));
