@@ -479,9 +479,9 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     // ub), multipliers of active rows / slacks of inactive rows u -= col nu.  Full step: the entering constraint
     // becomes tight, nu = num / (-pv); it is cut short where the first multiplier reaches zero.
     // (BIG stands for "no bound on the step")
-    const double rz = fast_rcp1(-pv);
+    const double rpv = fast_rcp(pv);  // (also the reciprocal of the pivot when the entering constraint is added)
     const double sgn = (num >= 0.0) ? 1.0 : -1.0;
-    const double full = lin_dep ? BIG : fabs(num) * rz;
+    const double full = lin_dep ? BIG : -fabs(num) * rpv;
     const double rate = phi * col * sgn;
     const bool blocking = act && rate > 0.0;
     const double ratio = blocking ? max_raw(u, 0.0) * fast_rcp1(rate) : BIG;
@@ -518,10 +518,11 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves; the
     // entering one stays pending and its column is extracted again from the new tableau)
     int pi = -1;
-    double pvt = 1.0;
+    double pvt = 1.0, rp = 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
     if (do_add) {
       pi = src;
       pvt = pv;
+      rp = rpv;
       if (li == src) {
         if (li < NV) {
           state = kind + 1;
@@ -544,6 +545,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         col = (li == kd) ? tdiag : ck;
         pi = kd;
         pvt = pk;
+        rp = fast_rcp(pk);
         if (li == kd) {
           state = 0;
           u = 0.0;
@@ -557,7 +559,6 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
       // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
       const double sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
-      const double rp = (pi >= 0) ? fast_rcp(pvt) : 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
       double t = col * rp;
       double cp = col;
       if (li == pi) {

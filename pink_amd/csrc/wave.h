@@ -293,6 +293,8 @@ __device__ __forceinline__ float approx_rcpf(float x) { return __builtin_amdgcn_
 
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
+// A value every lane of the wave agrees on, as a scalar the compiler keeps in an SGPR and branches on with s_cbranch_scc.
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Index inside its group of W lanes of the first lane whose predicate holds (W if none): one ballot, the group's bits
 // shifted down, count of trailing zeros -- no LDS crossbar.
