@@ -341,6 +341,11 @@ int pinkhip_host_free(pinkhip_handle *h, void *hptr);
 int pinkhip_malloc(pinkhip_handle *h, void **dptr, int64_t bytes);
 int pinkhip_free(pinkhip_handle *h, void *dptr);
 int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+/* The same copy on the handle's COPY stream: it waits only for itself, not for the kernels enqueued on the compute
+ * stream, so that the upload of the next piece of a batch overlaps the kernels of the previous one.  Returns when the
+ * source has been consumed and the data is on the device: a kernel launched afterwards sees it.  The caller keeps the
+ * destination disjoint from what enqueued kernels still read or write. */
+int pinkhip_memcpy_h2d_overlapped(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes); /* stream-ordered, asynchronous */
 int pinkhip_sync(pinkhip_handle *h);

@@ -124,7 +124,7 @@ ABI_SYMBOLS = (
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_host_alloc", "pinkhip_host_free", "pinkhip_malloc", "pinkhip_free",
-    "pinkhip_memcpy_h2d", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
+    "pinkhip_memcpy_h2d", "pinkhip_memcpy_h2d_overlapped", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
     "pinkhip_timer_stop",
 )
 
@@ -179,6 +179,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_malloc.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_int64]
     lib.pinkhip_free.argtypes = [vp, vp]
     lib.pinkhip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_memcpy_h2d_overlapped.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_d2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_sync.argtypes = [vp]

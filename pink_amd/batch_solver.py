@@ -275,6 +275,12 @@ class BatchSolver:
     def put(self, ptr: int, arr: np.ndarray) -> None:
         self._h2d(ptr, np.ascontiguousarray(arr))
 
+    def put_overlapped(self, ptr: int, arr: np.ndarray) -> None:
+        """Upload on the copy stream (``pinkhip_memcpy_h2d_overlapped``): does not wait for the kernels already
+        enqueued, which keep running while the bytes move."""
+        arr = np.ascontiguousarray(arr)
+        self._check(self._lib.pinkhip_memcpy_h2d_overlapped(self._h, ctypes.c_void_p(ptr), arr.ctypes.data, arr.nbytes))
+
     def get(self, arr: np.ndarray, ptr: int) -> None:
         self._d2h(arr, ptr)
 

@@ -1055,6 +1055,15 @@ int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t by
   return PINKHIP_OK;
 }
 
+int pinkhip_memcpy_h2d_overlapped(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice, h->copy_stream));
+  PH_HIP(h, hipStreamSynchronize(h->copy_stream));
+  return PINKHIP_OK;
+}
+
 int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
   if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
   if (bytes == 0) return PINKHIP_OK;

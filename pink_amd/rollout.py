@@ -360,8 +360,44 @@ class DeviceRollout:
                 a.integrate_checked(self.dmodel, B, self.d_q, self.d_dq, self.d_status, self.d_fail, self.steps_done)
         self.steps_done += 1
 
-    def _one_kernel_step(self, integrate: bool = True) -> bool:
-        """FK + FrameTask rows + limits + posture + stack + solve + integrate in one launch."""
+    def solve_pipelined(self, q0: np.ndarray, targets: Sequence[np.ndarray], q_posture: Optional[np.ndarray] = None,
+                        safety_break: bool = True, n_chunks: int = 4) -> bool:
+        """One differential-IK solve of new configurations ``q0`` (no integration), the batch cut into ``n_chunks``
+        ranges whose uploads (``q`` and one ``[B, 12]`` target array per frame task, on the copy stream) overlap the
+        whole-step kernel of the previous range.  Results through :meth:`last_step`.  ``False`` -- nothing enqueued --
+        when the whole-step kernel does not serve this model or the solver has no copy stream."""
+        a, B, nq, nf = self.api, self.B, self.nq, len(self.frames)
+        if self.fused != "kernel" or not hasattr(a, "put_overlapped") or len(targets) != nf or B < n_chunks:
+            return False
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        if q0.shape != (B, nq):
+            raise ValueError(f"q0 must have shape {(B, nq)}, got {q0.shape}")
+        tg = [np.ascontiguousarray(np.broadcast_to(t, (B, 12)), dtype=np.float64) for t in targets]
+        if self.n_post:
+            self._put_posture(q0, q_posture)
+        a.put(self.d_fail, np.zeros(B, dtype=np.int32))
+        self.steps_done, self._pending, self.targets_per_frame = 0, False, True
+        from .sharding import shard_bounds
+
+        for c in range(n_chunks):
+            lo, hi = shard_bounds(B, c, n_chunks)
+            a.put_overlapped(self.d_q + 8 * nq * lo, q0[lo:hi])
+            for f, t in enumerate(tg):
+                a.put_overlapped(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
+            if not self._one_kernel_step(False, lo, hi):
+                if c:
+                    raise RuntimeError("whole-step kernel refused a later range of the same batch")
+                return False
+        self.steps_done = 1
+        # Configuration.check_limits on the whole batch (pink/solve_ik.py:260), after the fact: the velocities of a
+        # batch that violates its limits are never handed out
+        self._check_limits_device(q0, safety_break)
+        return True
+
+    def _one_kernel_step(self, integrate: bool = True, lo: int = 0, hi: Optional[int] = None) -> bool:
+        """FK + FrameTask rows + limits + posture + stack + solve + integrate in one launch (robots ``lo .. hi``)."""
+        if hi is not None and (lo, hi) != (0, self.B):
+            return self._one_kernel_step_range(integrate, lo, hi)
         st = RolloutStep()
         st.q, st.cost, st.T_target, st.T_frames = self.d_q, self.d_cost, self.d_Tt, self.d_T
         st.q_target = self.d_qt if self.n_post else None
@@ -376,6 +412,28 @@ class DeviceRollout:
             st.root_box, st.limit_rows, st.limit_h = self.d_lim
             st.n_limit_rows = len(self.lim_h)
         return self.api.rollout_step(self.desc, self.dmodel, st)
+
+    def _one_kernel_step_range(self, integrate: bool, lo: int, hi: int) -> bool:
+        """The whole-step kernel on the robots ``lo .. hi`` of the resident batch (per-frame target arrays)."""
+        nf, nv, nq = len(self.frames), self.nv, self.nq
+        if not self.targets_per_frame or self.md:
+            raise ValueError("ranges of the batch are launched over per-frame target arrays, without dense rows")
+        st = RolloutStep()
+        st.q, st.cost = self.d_q + 8 * nq * lo, self.d_cost
+        st.T_target, st.T_frames = self.d_Tt + 8 * 12 * lo, self.d_T + 8 * 12 * max(nf, 1) * lo
+        st.q_target = (self.d_qt + (8 * nq * lo if self.qt_batched else 0)) if self.n_post else None
+        st.dq, st.status, st.iters = self.d_dq + 8 * nv * lo, self.d_status + 4 * lo, self.d_iters + 4 * lo
+        st.first_failure = self.d_fail + 4 * lo
+        st.config_limit_gain = self.config_limit_gain
+        st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
+        st.sT_b, st.sT_f = 12, 12 * self.B
+        if self.d_lim:
+            st.root_box = self.d_lim[0]
+        self.desc.B = hi - lo
+        try:
+            return self.api.rollout_step(self.desc, self.dmodel, st)
+        finally:
+            self.desc.B = self.B
 
     def flush(self) -> None:
         """Apply the displacement of the last enqueued step (the whole-step kernel integrates lazily, at the

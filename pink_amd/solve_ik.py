@@ -402,6 +402,7 @@ def _device_kinematics_plan_tasks(configurations, tasks):
 # kept per solver (= per device): model tables, buffers and descriptors are built once, a call only moves q and the
 # targets in and dq out.
 _ROLLOUT_CACHE_MAX = 4
+_PIPELINE_MIN_B = 16384  # batches from here on are uploaded and solved in four overlapping ranges
 _CACHED_APIS: list = []
 
 
@@ -440,6 +441,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
            float(model.configuration_limit.config_limit_gain), tuple(_barrier_key(b) for b in bars), fkey)
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
+    fresh = False
     if ro is None:
         kw = {}
         if posture is not None:
@@ -447,11 +449,16 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
-    else:
-        ro.reset(q, None if posture is None else posture[3], safety_break)
+        fresh = True
     try:
-        ro.set_targets(T)
-        ro.step(integrate=False)
+        # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
+        qp = None if posture is None else posture[3]
+        if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and not bars and ro.md == 0
+                and ro.solve_pipelined(q, T, qp, safety_break)):
+            if not fresh:
+                ro.reset(q, qp, safety_break)
+            ro.set_targets(T)
+            ro.step(integrate=False)
         api.sync()
         out = ro.last_step()
     except BaseException:

@@ -89,6 +89,8 @@ class EmuSolver:
         arr = np.ascontiguousarray(arr)
         ctypes.memmove(ptr, arr.ctypes.data, arr.nbytes)
 
+    put_overlapped = put  # (no streams here: the emulator runs every launch to completion)
+
     def get(self, arr, ptr):
         ctypes.memmove(arr.ctypes.data, ptr, arr.nbytes)
 

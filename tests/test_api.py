@@ -563,6 +563,59 @@ def test_solve_ik_batch_on_arrays_equals_the_list_of_configurations(backend):
         solve_ik_batch(ConfigurationBatch(m, q_bad), shared + [post], 5e-3, device_kinematics=True)
 
 
+def test_solve_ik_batch_pipelined_ranges_equal_the_single_launch(backend, monkeypatch):
+    """Large array batches are uploaded and solved in four overlapping ranges (``DeviceRollout.solve_pipelined``,
+    ``pinkhip_memcpy_h2d_overlapped``): same velocities, bit for bit, as the single launch; per-robot and shared
+    posture targets; the limit check still covers the whole batch."""
+    import sys
+
+    from pink_amd import ConfigurationBatch
+    from pink_amd.rollout import DeviceRollout
+
+    sik = sys.modules["pink_amd.solve_ik"]  # (the package re-exports the function under the module's name)
+
+    m, frames = build_chain(9, free_flyer=True, seed=3), ["tool0", "joint_4"]
+    rng = np.random.default_rng(15)
+    B = 11  # (ranges of 3, 3, 3, 2)
+    q = np.tile(m.neutral(), (B, 1))
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[:, j.idx_q] = rng.uniform(-0.9, 0.9, size=B)
+    tasks = []
+    for k, f in enumerate(frames):
+        ft = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+        R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+        for b in range(B):
+            T = Configuration(m, q[b]).get_transform_frame_to_world(f) * SE3(np.eye(3), 0.03 * rng.normal(size=3))
+            R[b], t[b] = T.rotation, T.translation
+        ft.set_target_poses(R, t)
+        tasks.append(ft)
+    calls = []
+    orig = DeviceRollout.solve_pipelined
+    monkeypatch.setattr(DeviceRollout, "solve_pipelined", lambda self, *a, **k: calls.append(1) or orig(self, *a, **k))
+    for batched_posture in (False, True):
+        post = PostureTask(cost=1e-2, gain=0.7)
+        if batched_posture:
+            post.set_target_batch(q + 0.05 * rng.normal(size=q.shape) * (np.arange(m.nq) >= 7))
+        else:
+            post.set_target(m.neutral())
+        pink_amd.clear_device_cache()
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 1 << 30)
+        V_one = solve_ik_batch(ConfigurationBatch(m, q), tasks + [post], 5e-3, device_kinematics=True)
+        assert not calls
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 4)
+        for _ in range(2):  # fresh device state, then the cached one
+            V_pipe = solve_ik_batch(ConfigurationBatch(m, q), tasks + [post], 5e-3, device_kinematics=True)
+            assert np.array_equal(V_pipe, V_one) and np.abs(V_one).max() > 1e-3
+        assert len(calls) == 2
+        calls.clear()
+    q_bad = q.copy()
+    q_bad[9, 7 + 2] = 9.0
+    with pytest.raises(NotWithinConfigurationLimits):
+        solve_ik_batch(ConfigurationBatch(m, q_bad), tasks + [post], 5e-3, device_kinematics=True)
+    pink_amd.clear_device_cache()
+
+
 def _biped():
     """Floating base with two 6-joint legs (a tree, not a chain) and frames at the pelvis and the ankles: the
     smallest model with the structure of the reference's JVRC / Upkie fixtures."""
