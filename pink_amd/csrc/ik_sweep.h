@@ -280,21 +280,25 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   // in the trip in which a group finds no violated constraint left: the product with T is the one every trip forms
   // anyway (with r in the place of the indicator of the entering column), and T never has to outlive the loop (when it
   // did, the register allocator kept two copies of it and moved one onto the other in every trip).
-  auto residual = [&]() -> double {
-    const double xl = in ? x : 0.0;
-    const BcT xb = bcast_prepare<W>(xl);
-    // row li of the stated KKT matrix times x: a coordinate lane reads H[li][j] = H[j][li] from the packed triangle,
-    // the lane of a dense row its row of G (= column entries the coordinate lanes parked)
+  // row li of the stated KKT matrix times a vector held one entry per coordinate lane: a coordinate lane reads
+  // H[li][j] = H[j][li] from the packed triangle, the lane of a dense row its row of G (= column entries the
+  // coordinate lanes parked)
+  auto krow_times = [&](double v) -> double {
+    const BcT vb = bcast_prepare<W>(v);
     const int base = (li < NV) ? SL::tri(li) : SL::oG + (dlane ? dr : 0) * W;
     double h0 = 0.0, h1 = 0.0;
     static_for<0, NV>([&](auto Jc) {
       constexpr int j = decltype(Jc)::value;
       const int ad = (li < NV && j > li) ? SL::tri(j) + li : base + j;
       const double hv_ = sm[ad];
-      if constexpr (j % 2 == 0) h0 = fma_bcast<W, j>(h0, xb, hv_);
-      else h1 = fma_bcast<W, j>(h1, xb, hv_);
+      if constexpr (j % 2 == 0) h0 = fma_bcast<W, j>(h0, vb, hv_);
+      else h1 = fma_bcast<W, j>(h1, vb, hv_);
     });
-    double r = in ? (h0 + h1) + sm[SL::oC + li] : 0.0;
+    return h0 + h1;
+  };
+  auto residual = [&]() -> double {
+    const double kx = krow_times(in ? x : 0.0);
+    double r = in ? kx + sm[SL::oC + li] : 0.0;
     if (state != 0) r = 0.0;  // fixed coordinates: nonbasic
     if constexpr (DENSE) {
       if (md > 0) {
@@ -307,7 +311,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
           gl = fma_bcast<W, NV + d>(gl, lamb, sm[SL::oG + d * W + li]);
         });
         if (in && state == 0) r += gl;
-        if (arow) r = (h0 + h1) - hv;  // residual of an active row
+        if (arow) r = kx - hv;  // residual of an active row
       }
     }
     return r;
@@ -466,10 +470,22 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     bool lin_dep = false;
     if constexpr (DENSE) {
       // an entering normal that depends on the active ones has no curvature left (a coordinate too, once dense rows
-      // are active).  The reduced curvature n^T Z n is what successive pivots leave of n^T H^-1 n: its round-off
-      // floor is ~1e-15 n^T H^-1 n (ik_kernels_packed.h forms it as a sum of squares and can test against 1e-24).
+      // are active).  The reduced curvature n^T Z n is what successive pivots leave of n^T H^-1 n: a difference, whose
+      // round-off floor is cond(K_BB) eps n^T H^-1 n (ik_kernels_packed.h forms it as a sum of squares).
+      // When little is left (under 1e-6 of it: rare), the curvature is formed again as a sum of squares: the free
+      // coordinates' part w of the column is the primal step direction, and w^T H w = n^T Z n (K_BB (w, mu) = n gives
+      // w^T H w = w^T n - (G_A w)^T mu = w^T n).  A direction that is pure round-off (relative size delta) then
+      // leaves delta^2 instead of delta: dependence shows as < 1e-12 of n^T H^-1 n whatever the conditioning
+      // (scripts/gpu_fuzz.py seed 12979: floor 6e-11, against a threshold of 1e-10 before).
       const double z0 = group_bcast<W>(zd0, src);
-      lin_dep = !(-pv * 1e10 > z0);
+      const bool little = act && !(-pv * 1e6 > z0);
+      if (wave_any(little)) {
+        const double w = (in && state == 0) ? col : 0.0;
+        const double hw = krow_times(w);
+        const double curv = group_sum<W>((li < NV) ? w * hw : 0.0);
+        if (little) pv = -curv;
+      }
+      lin_dep = !(-pv * 1e12 > z0);
     }
     // (a group without an entering constraint computes on garbage from here on: everything it could change is
     // masked by act / act2 below)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""One-off wide fuzz on the GPU box: tests/parity_suite.fuzz (status equality + velocity error against the C oracle) over
+many more seeds than the test suite runs, for both stack + solve kernels.   python scripts/gpu_fuzz.py [first] [count]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity_suite as ps  # noqa: E402
+
+from pink_amd.batch_solver import BatchSolver  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+s = BatchSolver(0)
+for solver in ("sweep", "packed"):
+    os.environ["PINKHIP_SOLVER"] = solver
+    t0 = time.time()
+    n, bad = 0, []
+    for sd in range(first, first + count):
+        try:
+            n += ps.fuzz(s, [sd])
+            if sd % 4 == 0:  # the wide instantiations: up to 60 coordinates, up to 12 dense rows
+                n += ps.fuzz(s, [sd], nv_lo=34, nv_hi=61, md_hi=13)
+        except AssertionError as exc:
+            bad.append(sd)
+            print("  seed", sd, "->", str(exc)[:200], flush=True)
+    print(f"  {len(bad)} failing seeds: {bad}", flush=True)
+    k = ps.kkt_certificate(s, range(first, first + count // 8))
+    print(f"{solver}: {count} seeds, {n} feasible instances within tolerance, statuses equal everywhere; "
+          f"KKT certificates {k}; {time.time() - t0:.1f} s", flush=True)

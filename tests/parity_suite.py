@@ -242,17 +242,17 @@ def equality_edge_cases(solver):
     assert (bad.status == 2).all()
 
 
-def fuzz(solver, seeds):
+def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5):
     """Random mixes of box bounds (some missing, some with lb == ub), dense inequality rows (some
     duplicated), equalities, LM damping and dimensions; infeasible draws must be reported as such
     by both sides."""
     n_checked = 0
     for sd in seeds:
         rng = np.random.default_rng(sd)
-        nv = int(rng.integers(1, 34))
+        nv = int(rng.integers(nv_lo, nv_hi))
         B = int(rng.integers(1, 7))
         neq = int(rng.integers(0, min(3, nv) + 1)) if rng.random() < 0.4 else 0
-        mdi = int(rng.integers(0, 5)) if rng.random() < 0.5 else 0
+        mdi = int(rng.integers(0, md_hi)) if rng.random() < 0.5 else 0
         k = int(rng.integers(1, 7))
         J = rng.normal(0, 0.5, size=(B, k, nv))
         e = 0.1 * rng.normal(size=(B, k))

@@ -89,6 +89,7 @@ def test_equality_edge_cases(emu):
 
 def test_fuzz(emu):
     assert ps.fuzz(emu, range(5000, 5060)) > 100
+    assert ps.fuzz(emu, [12979]) >= 3  # (see tests/test_gpu_parity.py::test_fuzz_wide)
 
 
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):

@@ -67,6 +67,16 @@ def test_fuzz(gpu_solver):
     assert ps.fuzz(gpu_solver, range(7000, 7400)) > 1000
 
 
+def test_fuzz_wide(gpu_solver):
+    """Eight thousand more draws (three seconds on the GPU), and the draw that showed what a dependence test on a
+    subtractively updated curvature misses: seed 12979's fourth instance is infeasible, the last entering bound
+    depends on the active set, and the tableau's diagonal entry was 6e-11 of its initial value -- pure round-off, on
+    either side of a 1e-10 threshold depending on how the compiler contracts the FMAs (emulator: infeasible, GPU:
+    "optimal" with an equality violated by 4e-3).  The kernel now forms small curvatures again as w^T H w."""
+    assert ps.fuzz(gpu_solver, [12979]) >= 3
+    assert ps.fuzz(gpu_solver, range(20000, 28000)) > 20000
+
+
 def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
     """Vectorised KKT check for box (+ dense) QPs; returns (stationarity, violation)."""
     g = np.einsum("bij,bj->bi", H, dq) + c
