@@ -270,6 +270,7 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
   bool need_sel = true;
   bool refined = false;  // the closing refinement step(s) of this group have been taken
   int nref = 0;
+  double dprev = 0.0;  // largest entry of the previous refinement step
 
   // ------------------------------------------------------------------ one step of iterative refinement
   // The tableau is an explicitly updated inverse: after ~60 pivots x carries cond(H) eps times a growth factor
@@ -448,9 +449,21 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         // calls for another step, at most three in all: every step shrinks the residual by the relative accuracy of T.
         const double dxv = (ref && in && state == 0) ? col + (tdiag - sdiag) * rres : 0.0;
         const bool more = group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
+        // ... as long as the steps contract.  Where T is no inverse any more (cond(H) ~ 1e13 and beyond: the relative
+        // error of T reaches one) the "correction" is as large as x or grows from step to step: it is not applied, x
+        // stays what the iteration left -- inside its box, by construction (scripts/gpu_fuzz_rollout.py seed 14:
+        // cond(H) = 4e13, a correction of 6e7 radians reported as optimal).
+        const double dmax = -group_min<W>(-fabs(dxv));
+        const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
+        const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
         if (ref) {
-          x += dxv;
-          refined = !(more && ++nref < 3);
+          if (sane) {
+            x += dxv;
+            dprev = dmax;
+            refined = !(more && ++nref < 3);
+          } else {
+            refined = true;
+          }
         }
         // (a closing trip that asks for another one falls through the rest of the body, everything masked off: a
         // second back edge -- `continue` -- makes the register allocator keep two copies of T and move one onto the
