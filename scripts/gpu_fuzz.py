@@ -24,6 +24,8 @@ for solver in ("sweep", "packed"):
             n += ps.fuzz(s, [sd])
             if sd % 4 == 0:  # the wide instantiations: up to 60 coordinates, up to 12 dense rows
                 n += ps.fuzz(s, [sd], nv_lo=34, nv_hi=61, md_hi=13)
+            if sd % 2 == 1:  # weakly regularised objectives
+                n += ps.fuzz(s, [sd], ill=True)
         except AssertionError as exc:
             bad.append(sd)
             print("  seed", sd, "->", str(exc)[:200], flush=True)

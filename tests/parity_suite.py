@@ -242,7 +242,7 @@ def equality_edge_cases(solver):
     assert (bad.status == 2).all()
 
 
-def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5):
+def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
     """Random mixes of box bounds (some missing, some with lb == ub), dense inequality rows (some
     duplicated), equalities, LM damping and dimensions; infeasible draws must be reported as such
     by both sides."""
@@ -273,7 +273,11 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5):
             Gi[:, 1], hi[:, 1] = Gi[:, 0], hi[:, 0] + 0.01
         lm = float(rng.choice([0.0, 0.5]))
         cost = rng.uniform(0.5, 2, size=k)
-        batch = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=cost, lm_damping=lm), DiagonalTaskTerm(col0=0, e=ep, cost=0.1)],
+        # ill: a weak regulariser (posture cost down to 1e-5: cond(H) up to ~1e11) -- the tolerance below follows cond(H)
+        dcost = float(10 ** rng.uniform(-5, -1)) if ill else 0.1
+        if ill:
+            lm = float(rng.choice([0.0, 1e-6]))
+        batch = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=cost, lm_damping=lm), DiagonalTaskTerm(col0=0, e=ep, cost=dcost)],
                            0.005, 1e-12, boxes=[(lb, ub)], dense_rows=[(Gi, hi)] if mdi else (),
                            equality_rows=[(A, bv)] if neq else (), batch_size=B)
         out = solver.solve(batch)
@@ -283,7 +287,7 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5):
         G = np.concatenate([A, np.broadcast_to(eye, (B, nv, nv)), np.broadcast_to(-eye, (B, nv, nv)), Gi], axis=1)
         h = np.concatenate([bv, hb, hi], axis=1)
         ref = c_oracle.solve_ik_batch(np.concatenate([J, np.broadcast_to(eye, (B, nv, nv))], axis=1),
-                                      np.concatenate([e, ep], axis=1), np.concatenate([cost, np.full(nv, 0.1)]),
+                                      np.concatenate([e, ep], axis=1), np.concatenate([cost, np.full(nv, dcost)]),
                                       np.ones(2), np.array([lm, 0.0]), np.array([0, k, k + nv], np.int32), 1e-12, G, h,
                                       meq=neq, want_Hc=True)
         assert np.array_equal(out.status, ref["status"]), (sd, out.status, ref["status"])
