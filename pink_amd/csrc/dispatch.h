@@ -84,10 +84,17 @@ inline bool prefer_sweep(int nv, int md, long long B) {
 // tu_sweep.hip): H packed, c, the columns of G.
 constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + 2 * W + MD * W; }
 
+// Doubles of LDS per QP of the Goldfarb-Idnani kernel (= LdsP<NV>::stride(md), checked at compile time in
+// tu_rollout.hip): the sweep-tableau kernels hand a group over to it when its result fails the certificate.
+constexpr int packed_lds_doubles(int NV, int md) {
+  return ((((NV * (NV + 3) / 2 + 1) & ~1) + 5 * NV + md * (NV + 1)) + 1) & ~1;
+}
+constexpr int max3(int a, int b, int c) { return (a > b ? a : b) > c ? (a > b ? a : b) : c; }
+
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger.
-constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles) {
-  return ((fk_doubles + 1) & ~1) > sweep_lds_doubles(NV, 0, W) ? ((fk_doubles + 1) & ~1) : sweep_lds_doubles(NV, 0, W);
+constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0) {
+  return max3((fk_doubles + 1) & ~1, sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD));
 }
 
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
@@ -97,8 +104,7 @@ constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles) {
 inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md) {
 #define PINKHIP_PICK(NV_, MD_, W_)                                                                          \
   if (nv <= NV_ && md <= MD_ && nj <= W_) {                                                                 \
-    const int need = ((fk_doubles + 1) & ~1) > sweep_lds_doubles(NV_, MD_, W_) ? ((fk_doubles + 1) & ~1)    \
-                                                                               : sweep_lds_doubles(NV_, MD_, W_); \
+    const int need = rollout_lds_doubles(NV_, W_, fk_doubles, MD_);                                         \
     if (8 * need * (64 / W_) + 16 <= 65536) return SweepChoice{NV_, MD_, W_};                               \
   }
   PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_PICK)

@@ -68,6 +68,10 @@ constexpr int STATUS_OPTIMAL = 0;
 constexpr int STATUS_MAX_ITER = 1;
 constexpr int STATUS_INFEASIBLE = 2;
 constexpr int STATUS_NOT_PD = 3;
+// internal to the sweep-tableau kernel: the solution it arrived at does not pass its own KKT certificate (the explicitly
+// updated inverse lost too much accuracy: weakly regularised objectives, cond(H) >~ 1e8) -- the Goldfarb-Idnani kernel
+// solves the instance again in the same launch, callers never see this value
+constexpr int STATUS_BREAKDOWN = 4;
 
 // Everything a launch needs; passed by value in the kernarg segment.
 struct KernelArgs {

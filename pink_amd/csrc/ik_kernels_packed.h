@@ -76,7 +76,9 @@ struct LdsP {
 // only, md = 0): every dense-row branch and its state (row slacks, row norms, equality bookkeeping)
 // folds away at compile time.
 template <int NV, int W, bool DENSE = true, class Src = HbmTerms>
-__device__ inline void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
+__device__ inline void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr, bool only = true) {
+  // only: this lane's group is to be solved (the sweep-tableau kernel hands over the groups whose result did not pass
+  // its certificate; the other groups of the wavefront go through the motions and write nothing)
   static_assert(W >= NV && NV % 2 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
@@ -100,8 +102,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   unsigned long long clock_prev = __builtin_readcyclecounter();
 #endif
   long long b = block * G + g;
-  const bool valid = b < a.B;
-  if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
+  const bool valid = b < a.B && only;
+  if (b >= a.B) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
 
   double *sm = shared_base() + (long long)g * (a.lds_pitch ? a.lds_pitch : S::stride(md));
   double *Ts = sm + S::oT;
@@ -229,7 +231,11 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
   constexpr int kGR = PINKHIP_GR;  // dense rows kept in registers
   if (md > 0) {
     wave_sync();
-    {
+    if constexpr (Src::kOnTheFly) {
+      // (whole-step kernel: barrier / limit rows formed from the kinematics, lane li = their entry in column li)
+      for (int r = 0; r < md; ++r)
+        if (li < nv) Gs[r * GP + li] = terms->dense_col(r);
+    } else {
       const double *src = a.Gd + b * (long long)md * nv;
       int r = li / nv, j = li - r * nv;
       const int dr = W / nv, dj = W - dr * nv;
@@ -262,7 +268,8 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
         n2 = group_bcast<W>(part, (li < md ? li : 0) << 3);
       }
       if (li < md) {  // dispatch.h guarantees md <= W: one lane per dense row
-        hv = a.hd[b * (long long)md + li];
+        if constexpr (Src::kOnTheFly) hv = terms->dense_h(li);
+        else hv = a.hd[b * (long long)md + li];
         if (md * 8 > W)
           for (int j = 0; j < nv; ++j) n2 += Gs[li * GP + j] * Gs[li * GP + j];
         ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
@@ -900,8 +907,10 @@ __device__ inline void ik_packed_instance(const KernelArgs &a, long long block, 
 
   // ------------------------------------------------------------------ write-out
   if constexpr (Src::kOnTheFly) {
-    terms->x = in ? x : 0.0;
-    terms->status = status;
+    if (only) {
+      terms->x = in ? x : 0.0;
+      terms->status = status;
+    }
   }
   if (valid) {
     if (in) late->dq[b * (long long)nv + li] = x;

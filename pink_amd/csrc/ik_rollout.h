@@ -118,7 +118,16 @@ __device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block
   }
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();
-  ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+  const int st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+  // a result that fails its KKT certificate is not integrated: the Goldfarb-Idnani code solves that robot's QP again
+  // (ik_sweep.h, ik_solve_sweep_body).  It forms the rows from the kinematics like the tableau did, and the tableau's
+  // parking area has overwritten the kinematics scratch meanwhile: the kinematics run once more (wave-uniform, rare).
+  if (wave_any(st_sweep == STATUS_BREAKDOWN)) {
+    wave_sync();
+    ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
+    wave_sync();
+    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(a.k, block, &t, st_sweep == STATUS_BREAKDOWN);
+  }
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
   const int st = t.status;  // group-uniform
   const bool isj = li < m.nj;

@@ -30,6 +30,7 @@
 #pragma once
 
 #include "ik_common.h"
+#include "ik_kernels_packed.h"
 #include "ik_stack_rows.h"
 
 #ifdef PINKHIP_SECTION_CLOCK
@@ -55,6 +56,11 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #define PINKHIP_SWEEP_COLUMN_CHAINS(NT) 2
 #endif
 
+// relative size of a gradient entry the KKT certificate of the closing trip accepts (a refined point leaves ~1e-15)
+#ifndef PINKHIP_SWEEP_CERT_TOL
+#define PINKHIP_SWEEP_CERT_TOL 1e-11
+#endif
+
 namespace pinkhip {
 
 // LDS of one QP (doubles): the stated problem, parked for the closing refinement step
@@ -68,7 +74,7 @@ struct SweepLds {
 };
 
 template <int NV, int MD, int W, class Src = HbmTerms>
-__device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
+__device__ inline int ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
   constexpr int NT = NV + MD;
   static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
   constexpr bool DENSE = MD > 0;
@@ -297,22 +303,49 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     });
     return h0 + h1;
   };
-  auto residual = [&]() -> double {
+  // ... and the same products are the KKT certificate of the point the iteration arrived at (`fails`: this lane's
+  // condition does not hold at x): stationarity on the free coordinates, the sign of the gradient on the fixed ones
+  // (their multipliers), the bounds of the free ones, active rows met, inactive rows not violated.  The problem is
+  // strictly convex: a point that passes IS the minimiser, whatever path led there; one that does not (the explicitly
+  // updated inverse loses cond(H)^2 eps when small pivots follow each other: weakly regularised objectives, cond(H)
+  // >~ 1e8, scripts/gpu_fuzz.py) is handed to the Goldfarb-Idnani kernel.
+  auto residual = [&](bool &fails) -> double {
     const double kx = krow_times(in ? x : 0.0);
-    double r = in ? kx + sm[SL::oC + li] : 0.0;
-    if (state != 0) r = 0.0;  // fixed coordinates: nonbasic
+    const double ci_ = in ? sm[SL::oC + li] : 0.0;
+    double grad = in ? kx + ci_ : 0.0;
+    bool arow = false;
     if constexpr (DENSE) {
       if (md > 0) {
-        const bool arow = dlane && state == 1;
-        // + G_A^T lambda_A on the free coordinates
+        arow = dlane && state == 1;
+        // + G_A^T lambda_A
         const BcT lamb = bcast_prepare<W>(arow ? u : 0.0);
         double gl = 0.0;
         static_for<0, MD>([&](auto Dc) {
           constexpr int d = decltype(Dc)::value;
           gl = fma_bcast<W, NV + d>(gl, lamb, sm[SL::oG + d * W + li]);
         });
-        if (in && state == 0) r += gl;
-        if (arow) r = kx - hv;  // residual of an active row
+        if (in) grad += gl;
+      }
+    }
+    // scale of a gradient entry: |c| + max H_ii max |x| over the group
+    const double hii = in ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
+    const double gsc = group_min<W>(-hii) * group_min<W>(in ? -fabs(x) : 0.0) - group_min<W>(-fabs(ci_));
+    const double gtol = PINKHIP_SWEEP_CERT_TOL * gsc;
+    fails = false;
+    if (in) {
+      if (state == 0) fails = fabs(grad) > gtol || x - lbv < 10.0 * thr_lo || ubv - x < 10.0 * thr_up;
+      else fails = (state == 1) ? grad < -gtol : grad > gtol;
+    }
+    double r = (in && state == 0) ? grad : 0.0;
+    if constexpr (DENSE) {
+      if (dlane) {
+        const double slack = (hv - kx) * ginv;  // (rows are g x <= h; normalised like the selection's threshold)
+        if (arow) {
+          r = kx - hv;  // residual of an active row
+          fails = fabs(slack) > -10.0 * thr_d;
+        } else if (state == 0 && dr >= n_eq) {
+          fails = slack < 10.0 * thr_d;
+        }
       }
     }
     return r;
@@ -427,8 +460,10 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
     if (!PINKHIP_SWEEP_LDS_COLUMN || closing) {
       BcT eb = bcast_indicator<W>(act ? src : -1);
       double rres = 0.0, sdiag = 0.0;
+      bool cert_fails = false;
       if (closing) {
-        rres = residual();
+        rres = residual(cert_fails);
+        cert_fails = group_first_lane<W>(cert_fails) < W;
         if (!ref || status != STATUS_OPTIMAL) rres = 0.0;
         // (the product below meets the unmaintained copy of the diagonal inside T: replaced by the maintained one)
 #pragma unroll
@@ -447,7 +482,11 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       if (closing) {
         // A correction that is not small (a nearly singular H: T is then a poor inverse, accurate to cond(H) eps)
         // calls for another step, at most three in all: every step shrinks the residual by the relative accuracy of T.
-        const double dxv = (ref && in && state == 0) ? col + (tdiag - sdiag) * rres : 0.0;
+        // (the multipliers of the active rows are basic variables too: corrected with x, so that the certificate's
+        // gradient is formed with multipliers as accurate as the point)
+        const bool arow_ = DENSE && dlane && state == 1;
+        const double dbv = (ref && ((in && state == 0) || arow_)) ? col + (tdiag - sdiag) * rres : 0.0;
+        const double dxv = in ? dbv : 0.0;
         const bool more = group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
         // ... as long as the steps contract.  Where T is no inverse any more (cond(H) ~ 1e13 and beyond: the relative
         // error of T reaches one) the "correction" is as large as x or grows from step to step: it is not applied, x
@@ -457,11 +496,18 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
         const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
         const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
         if (ref) {
-          if (sane) {
-            x += dxv;
+          if (status != STATUS_OPTIMAL) {
+            refined = true;  // (nothing to certify: infeasible, not positive definite, out of iterations)
+          } else if (!cert_fails && !more) {
+            if (sane) x += dxv;  // (below 1e-9 |x|: the certificate holds for the corrected point as well)
+            refined = true;
+          } else if (sane && nref < 3) {
+            x += dxv;  // ... and the next closing trip certifies the corrected point
+            if (arow_) u += dbv;
             dprev = dmax;
-            refined = !(more && ++nref < 3);
+            ++nref;
           } else {
+            status = STATUS_BREAKDOWN;
             refined = true;
           }
         }
@@ -619,11 +665,31 @@ __device__ inline void ik_sweep_instance(const KernelArgs &a, long long block, S
       if (late->iters) late->iters[b] = it;
     }
   }
+  return status;  // (of this lane's group)
+}
+
+// Doubles of LDS per QP of the kernel below: the sweep tableau's parking area or, for a group that is handed over, the
+// Goldfarb-Idnani kernel's working set -- whichever is larger (the host sets KernelArgs::lds_pitch to it).
+template <int NV, int MD, int W>
+__host__ __device__ constexpr int sweep_kernel_lds_doubles(int md) {
+  return SweepLds<NV, MD, W>::stride > LdsP<NV>::stride(MD > 0 ? md : 0) ? SweepLds<NV, MD, W>::stride : LdsP<NV>::stride(MD > 0 ? md : 0);
+}
+
+template <int NV, int MD, int W>
+__device__ inline void ik_solve_sweep_body(const KernelArgs &a, long long block) {
+  const int st = ik_sweep_instance<NV, MD, W>(a, block);
+  // a result that did not pass its KKT certificate (STATUS_BREAKDOWN: the explicitly updated inverse lost too much
+  // accuracy) is not handed out: the Goldfarb-Idnani kernel -- orthogonal factors, slower, stable -- solves that
+  // instance again, here, in the same wavefront (wave-uniform branch: rare, weakly regularised objectives)
+  if (wave_any(st == STATUS_BREAKDOWN)) {
+    wave_sync();
+    ik_packed_instance<NV, W, (MD > 0)>(a, block, static_cast<HbmTerms *>(nullptr), st == STATUS_BREAKDOWN);
+  }
 }
 
 template <int NV, int MD, int W>
 __global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_SWEEP(NV + MD) ik_solve_sweep_kernel(KernelArgs a) {
-  ik_sweep_instance<NV, MD, W>(a, block_id());
+  ik_solve_sweep_body<NV, MD, W>(a, block_id());
 }
 
 }  // namespace pinkhip

@@ -778,8 +778,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   if (desc->md > 0) {
     dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md);
     if (dc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation with barrier rows fits this model");
-    const int sl = pinkhip::sweep_lds_doubles(dc.NV, dc.MD, dc.W);
-    ra.k.lds_pitch = ((fkd + 1) & ~1) > sl ? ((fkd + 1) & ~1) : sl;
+    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD);
     ra.bar_frame = st->barrier_frame;
     ra.bar_axis = st->barrier_axis;
     ra.bar_sign = st->barrier_sign;

@@ -26,6 +26,7 @@ hipError_t PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKH
   constexpr int NV = PINKHIP_TU_NV, MD = PINKHIP_TU_MD, W = PINKHIP_TU_W, G = kWave / W;
   using SL = SweepLds<NV, MD, W>;
   static_assert(sweep_lds_doubles(NV, MD, W) == SL::stride, "dispatch.h restates the LDS layout");
+  static_assert(packed_lds_doubles(NV, MD) == LdsP<NV>::stride(MD), "dispatch.h restates the LDS layout");
   const size_t lds = 8 * static_cast<size_t>(a.k.lds_pitch) * G + 16;
   const dim3 grid(static_cast<unsigned>((a.k.B + G - 1) / G)), block(kWave);
   hipLaunchKernelGGL((ik_rollout_kernel<NV, MD, W>), grid, block, lds, stream, a);

@@ -20,8 +20,10 @@ hipError_t PINKHIP_LAUNCH_SWEEP_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKHIP_TU_W)
   // LDS: the stated problem (H packed, c, columns of G) parked for the closing refinement step
   using SL = SweepLds<NV, MD, W>;
   static_assert(sweep_lds_doubles(NV, MD, W) == SL::stride, "dispatch.h restates the LDS layout");
-  const size_t lds = 8 * static_cast<size_t>(SL::stride) * G + 16;
-  hipLaunchKernelGGL((ik_solve_sweep_kernel<NV, MD, W>), grid, block, lds, stream, a);
+  KernelArgs k = a;
+  k.lds_pitch = sweep_kernel_lds_doubles<NV, MD, W>(a.md);  // (room for the hand-over to the Goldfarb-Idnani kernel)
+  const size_t lds = 8 * static_cast<size_t>(k.lds_pitch) * G + 16;
+  hipLaunchKernelGGL((ik_solve_sweep_kernel<NV, MD, W>), grid, block, lds, stream, k);
   return hipGetLastError();
 }
 

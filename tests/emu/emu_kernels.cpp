@@ -32,7 +32,9 @@ void lane_main_packed(void *p) {
 
 template <int NV, int MD, int W>
 void lane_main_sweep(void *p) {
-  pinkhip::ik_sweep_instance<NV, MD, W>(*static_cast<const KernelArgs *>(p), pinkhip::block_id());
+  KernelArgs k = *static_cast<const KernelArgs *>(p);
+  k.lds_pitch = pinkhip::sweep_kernel_lds_doubles<NV, MD, W>(k.md);  // as tu_sweep.hip's launcher
+  pinkhip::ik_solve_sweep_body<NV, MD, W>(k, pinkhip::block_id());
 }
 
 template <int TP>
@@ -310,8 +312,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   pinkhip::PackedChoice pc{0, 0};
   if (d->md > 0) {
     const pinkhip::SweepChoice dc = pinkhip::select_rollout_dense(m->dev.nv, m->dev.nj, fkd, d->md);
-    const int sl = pinkhip::sweep_lds_doubles(dc.NV, dc.MD, dc.W);
-    a.lds_pitch = ((fkd + 1) & ~1) > sl ? ((fkd + 1) & ~1) : sl;
+    a.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD);
     ra.bar_frame = st->barrier_frame;
     ra.bar_axis = st->barrier_axis;
     ra.bar_sign = st->barrier_sign;
