@@ -76,7 +76,7 @@ struct LdsP {
 // only, md = 0): every dense-row branch and its state (row slacks, row norms, equality bookkeeping)
 // folds away at compile time.
 template <int NV, int W, bool DENSE = true, class Src = HbmTerms>
-__device__ inline void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr, bool only = true) {
+__device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr, bool only = true) {
   // only: this lane's group is to be solved (the sweep-tableau kernel hands over the groups whose result did not pass
   // its certificate; the other groups of the wavefront go through the motions and write nothing)
   static_assert(W >= NV && NV % 2 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "group width");

@@ -234,7 +234,7 @@ struct HbmSink {
 };
 
 template <int W, bool FUSED = false, bool STEP = false, class Sink = HbmSink>
-__device__ inline void ik_fk_instance(const FkArgs &a, long long block, Sink *sink = nullptr, double *lds = nullptr) {
+__device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block, Sink *sink = nullptr, double *lds = nullptr) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.m;
   const int lane = lane_id();

@@ -91,7 +91,7 @@ struct FkTerms {
 };
 
 template <int NV, int MD, int W>
-__device__ inline void ik_rollout_instance(const RolloutArgs &a, long long block) {
+__device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long long block) {
   constexpr int G = kWave / W;
   const ModelDev &m = a.fk.m;
   const int lane = lane_id();

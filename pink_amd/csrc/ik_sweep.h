@@ -74,7 +74,7 @@ struct SweepLds {
 };
 
 template <int NV, int MD, int W, class Src = HbmTerms>
-__device__ inline int ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
+__device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
   constexpr int NT = NV + MD;
   static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
   constexpr bool DENSE = MD > 0;
@@ -331,10 +331,11 @@ __device__ inline int ik_sweep_instance(const KernelArgs &a, long long block, Sr
     const double hii = in ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
     const double gsc = group_min<W>(-hii) * group_min<W>(in ? -fabs(x) : 0.0) - group_min<W>(-fabs(ci_));
     const double gtol = PINKHIP_SWEEP_CERT_TOL * gsc;
+    // (written so that a NaN -- an overflowed tableau -- fails)
     fails = false;
     if (in) {
-      if (state == 0) fails = fabs(grad) > gtol || x - lbv < 10.0 * thr_lo || ubv - x < 10.0 * thr_up;
-      else fails = (state == 1) ? grad < -gtol : grad > gtol;
+      if (state == 0) fails = !(fabs(grad) <= gtol && x - lbv >= 10.0 * thr_lo && ubv - x >= 10.0 * thr_up);
+      else fails = (state == 1) ? !(grad >= -gtol) : !(grad <= gtol);
     }
     double r = (in && state == 0) ? grad : 0.0;
     if constexpr (DENSE) {
@@ -342,9 +343,9 @@ __device__ inline int ik_sweep_instance(const KernelArgs &a, long long block, Sr
         const double slack = (hv - kx) * ginv;  // (rows are g x <= h; normalised like the selection's threshold)
         if (arow) {
           r = kx - hv;  // residual of an active row
-          fails = fabs(slack) > -10.0 * thr_d;
+          fails = !(fabs(slack) <= -10.0 * thr_d);
         } else if (state == 0 && dr >= n_eq) {
-          fails = slack < 10.0 * thr_d;
+          fails = !(slack >= 10.0 * thr_d);
         }
       }
     }
@@ -675,16 +676,25 @@ __host__ __device__ constexpr int sweep_kernel_lds_doubles(int md) {
   return SweepLds<NV, MD, W>::stride > LdsP<NV>::stride(MD > 0 ? md : 0) ? SweepLds<NV, MD, W>::stride : LdsP<NV>::stride(MD > 0 ? md : 0);
 }
 
+// (everything that touches the dynamic LDS must be inlined into the kernel: as a called function the body reached it
+// through a per-kernel offset table and faulted on the first access in the largest instantiations)
 template <int NV, int MD, int W>
-__device__ inline void ik_solve_sweep_body(const KernelArgs &a, long long block) {
+__device__ __forceinline__ void ik_solve_sweep_body(const KernelArgs &a, long long block) {
   const int st = ik_sweep_instance<NV, MD, W>(a, block);
   // a result that did not pass its KKT certificate (STATUS_BREAKDOWN: the explicitly updated inverse lost too much
   // accuracy) is not handed out: the Goldfarb-Idnani kernel -- orthogonal factors, slower, stable -- solves that
   // instance again, here, in the same wavefront (wave-uniform branch: rare, weakly regularised objectives)
-  if (wave_any(st == STATUS_BREAKDOWN)) {
+#ifndef PINKHIP_SWEEP_NO_HANDOVER  // (development: time / debug the tableau code alone)
+#ifdef PINKHIP_SWEEP_FORCE_HANDOVER  // (development: every instance takes the hand-over)
+  const bool over = true;
+#else
+  const bool over = st == STATUS_BREAKDOWN;
+#endif
+  if (wave_any(over)) {
     wave_sync();
-    ik_packed_instance<NV, W, (MD > 0)>(a, block, static_cast<HbmTerms *>(nullptr), st == STATUS_BREAKDOWN);
+    ik_packed_instance<NV, W, (MD > 0)>(a, block, static_cast<HbmTerms *>(nullptr), over);
   }
+#endif
 }
 
 template <int NV, int MD, int W>

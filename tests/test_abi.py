@@ -126,3 +126,35 @@ def test_headline_kernel_has_no_register_spills(built):
     # the hand-over was added, 0.667 -> 0.680 ms with the certificate's extra closing trip)
     assert vspill <= 16 and vgpr <= 168, row[0]
 
+
+def test_no_device_function_is_called(built):
+    """Everything that touches the dynamic LDS has to be inlined into its kernel: as a *called* function the body of
+    the sweep-tableau kernel reached the LDS through the per-kernel offset table LLVM builds for that case and faulted on
+    the first access (the largest instantiations, once the hand-over to the Goldfarb-Idnani code made the body too big
+    for the inliner).  No code object of the library may contain a call."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "pink_amd", "csrc", "libpinkhip.so")
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([f"{llvm}/llvm-objdump", "--offloading", local], check=True, capture_output=True)
+        objects = sorted(glob.glob(local + ".*gfx950*"))
+        assert objects
+        from concurrent.futures import ThreadPoolExecutor
+
+        def calls(co):  # (awk keeps the pipe small: the disassembly of one code object is tens of megabytes)
+            out = subprocess.run(f"{llvm}/llvm-objdump -d {co} | awk '/s_swappc/{{c++}} /v_/{{v++}} END{{print c+0, v+0}}'",
+                                 shell=True, capture_output=True, text=True).stdout.split()
+            return int(out[0]), int(out[1])
+
+        with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+            counts = list(pool.map(calls, objects))
+        assert sum(v for _, v in counts) > 100000  # (the disassembler did run)
+        assert all(c == 0 for c, _ in counts), [(os.path.basename(o), c) for o, (c, _) in zip(objects, counts) if c]
