@@ -102,20 +102,25 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
   // kinematics scratch at the start of this robot's share of LDS: the solve (which keeps stacking and the
   // factorisation in registers) first writes there after its last read of it; the share is the larger of the two
   double *sm = shared_base() + (long long)g * a.k.lds_pitch;
-  FkTerms<W> t;
-  t.es = sm + fk_lds_doubles(m.nj, m.nf);
-  t.UV = sm + 12 * (m.nj + m.nf) + ((m.nj + 1) & ~1);  // = Jls of ik_fk_instance
-  if constexpr (MD > 0) {
-    t.bar_frame = a.bar_frame, t.bar_axis = a.bar_axis;
-    t.bar_sign = a.bar_sign, t.bar_bound = a.bar_bound, t.bar_gain = a.bar_gain;
-    t.pfs = sm + 12 * m.nj;  // = fMo of ik_fk_instance
-    t.inv_dt = 1.0 / a.k.dt;
-    t.n_lim = a.n_lim, t.lim_rows = a.lim_rows, t.lim_h = a.lim_h;
-    if (a.n_lim > 0 && m.root_nv == 6) {  // (the free-flyer is the first joint after the universe: columns 0 .. 5)
-      const int jt = m.dof_joint[li < m.nv ? li : 0];
-      if (li < m.nv && m.jtype[jt] == JOINT_FREE_FLYER) t.root_sub = li - m.idx_v[jt];
+  auto make_terms = [&](const RolloutArgs &ra) {
+    const ModelDev &mm = ra.fk.m;
+    FkTerms<W> tt;
+    tt.es = sm + fk_lds_doubles(mm.nj, mm.nf);
+    tt.UV = sm + 12 * (mm.nj + mm.nf) + ((mm.nj + 1) & ~1);  // = Jls of ik_fk_instance
+    if constexpr (MD > 0) {
+      tt.bar_frame = ra.bar_frame, tt.bar_axis = ra.bar_axis;
+      tt.bar_sign = ra.bar_sign, tt.bar_bound = ra.bar_bound, tt.bar_gain = ra.bar_gain;
+      tt.pfs = sm + 12 * mm.nj;  // = fMo of ik_fk_instance
+      tt.inv_dt = 1.0 / ra.k.dt;
+      tt.n_lim = ra.n_lim, tt.lim_rows = ra.lim_rows, tt.lim_h = ra.lim_h;
+      if (ra.n_lim > 0 && mm.root_nv == 6) {  // (the free-flyer is the first joint after the universe: columns 0 .. 5)
+        const int jt = mm.dof_joint[li < mm.nv ? li : 0];
+        if (li < mm.nv && mm.jtype[jt] == JOINT_FREE_FLYER) tt.root_sub = li - mm.idx_v[jt];
+      }
     }
-  }
+    return tt;
+  };
+  FkTerms<W> t = make_terms(a);
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();
   const int st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
@@ -124,9 +129,13 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
   // parking area has overwritten the kinematics scratch meanwhile: the kinematics run once more (wave-uniform, rare).
   if (wave_any(st_sweep == STATUS_BREAKDOWN)) {
     wave_sync();
-    ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
+    // (arguments read again, terms built again: nothing of them is kept in registers through the tableau loop)
+    const RolloutArgs *again = kernarg_reload<RolloutArgs>(a);
+    FkTerms<W> t2 = make_terms(*again);
+    ik_fk_instance<W, true, true, FkTerms<W>>(again->fk, block, &t2, sm);
     wave_sync();
-    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(a.k, block, &t, st_sweep == STATUS_BREAKDOWN);
+    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, st_sweep == STATUS_BREAKDOWN);
+    if (st_sweep == STATUS_BREAKDOWN) t.x = t2.x, t.status = t2.status;
   }
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
   const int st = t.status;  // group-uniform

@@ -692,7 +692,10 @@ __device__ __forceinline__ void ik_solve_sweep_body(const KernelArgs &a, long lo
 #endif
   if (wave_any(over)) {
     wave_sync();
-    ik_packed_instance<NV, W, (MD > 0)>(a, block, static_cast<HbmTerms *>(nullptr), over);
+    // (the arguments are read again from the kernel-argument segment: kept in registers for this rare call they would
+    // be live through the whole tableau loop -- a dozen spilled registers in every wave's prologue, +30 % HBM traffic)
+    const KernelArgs *again = kernarg_reload<KernelArgs>(a);
+    ik_packed_instance<NV, W, (MD > 0)>(*again, block, static_cast<HbmTerms *>(nullptr), over);
   }
 #endif
 }
