@@ -567,12 +567,23 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     const bool stuck = !(tstep < BIG);
     double hs = 0.0;
     if constexpr (DENSE) {
-      if (wave_any(act && stuck)) hs = group_bcast<W>(hv, src);  // (cross-lane: wave-uniform control flow)
+      // (the bound / right-hand side of the entering constraint; cross-lane: wave-uniform control flow)
+      if (wave_any(act && stuck)) hs = group_bcast<W>((li < NV) ? (kind == 0 ? lbv : ubv) : hv, src);
     }
     if (act && stuck) {
-      if (DENSE && kind == 3 && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
+      const bool tiny = DENSE && fabs(num) <= 1e-9 * (1.0 + fabs(hs));
+      if (kind == 3 && tiny) {
         // equality implied by the active ones and already satisfied: nothing to add
         ++eq_next;
+        need_sel = true;
+      } else if (tiny) {
+        // an inequality that depends on the active ones, that no drop can help, and that is violated by round-off only:
+        // not "inconsistent" -- the bound moves to where the point is (ik_kernels_packed.h has the measurement)
+        if (li == src) {
+          if (li >= NV) hv -= u, u = 0.0;
+          else if (kind == 0) lbv = x;
+          else ubv = x;
+        }
         need_sel = true;
       } else {
         status = STATUS_INFEASIBLE;
