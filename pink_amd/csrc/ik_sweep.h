@@ -675,11 +675,20 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     terms->x = in ? x : 0.0;
     terms->status = status;
   }
-  if (valid) {
-    if (in) late->dq[b * (long long)nv + li] = x;
-    if (li == 0) {
-      late->status[b] = status;
-      if (late->iters) late->iters[b] = it;
+  {
+    // (the instance index is formed again from an opaque lane id: as a value kept from the start of the kernel it was
+    // the one register too many of the tableau loop -- spilled in every wave's prologue, +7 % HBM traffic)
+    int ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(ln));
+#endif
+    const long long bw = block * G + ln / W;
+    if (bw < late->B) {
+      if (in) late->dq[bw * (long long)nv + li] = x;
+      if (li == 0) {
+        late->status[bw] = status;
+        if (late->iters) late->iters[bw] = it;
+      }
     }
   }
   return status;  // (of this lane's group)
@@ -711,7 +720,11 @@ __device__ __forceinline__ void ik_solve_sweep_body(const KernelArgs &a, long lo
     // (the arguments are read again from the kernel-argument segment: kept in registers for this rare call they would
     // be live through the whole tableau loop -- a dozen spilled registers in every wave's prologue, +30 % HBM traffic)
     const KernelArgs *again = kernarg_reload<KernelArgs>(a);
-    ik_packed_instance<NV, W, (MD > 0)>(*again, block, static_cast<HbmTerms *>(nullptr), over);
+    long long blk = block;  // (opaque: or the instance index of the tableau code stays live for this call)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(blk));
+#endif
+    ik_packed_instance<NV, W, (MD > 0)>(*again, blk, static_cast<HbmTerms *>(nullptr), over);
   }
 #endif
 }
