@@ -456,7 +456,7 @@ def self_launch(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen(cmd, env=env))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=_RESULT_FD))  # (the ranks inherit the original stdout)
     rc = 0
     pending = set(range(n))
     while pending:
@@ -477,7 +477,32 @@ def self_launch(n: int) -> int:
     return rc
 
 
+_RESULT_FD = None
+
+
+def _keep_stdout_for_the_result() -> None:
+    """The contract is ONE JSON line on stdout.  Libraries loaded into the process print there too (RCCL's version
+    banner when the first communicator is created, flushed when the process exits): file descriptor 1 is pointed at
+    stderr for everything else and the result goes to a duplicate of the original."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(text: str) -> None:
+    data = (text + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
+        return
+    while data:
+        data = data[os.write(_RESULT_FD, data):]
+
+
 def main() -> None:
+    _keep_stdout_for_the_result()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -731,7 +756,7 @@ def main() -> None:
             base, _, _ = cpu_baseline(terms)
             line["cpu_baseline"] = base
             line["parity"] = full_parity(terms, batch, res)  # every instance of rank 0's batch
-        print(json.dumps(line), flush=True)
+        _emit(json.dumps(line))
     if abandoned:  # a thread of this process may still sit inside an RCCL call: no orderly teardown
         sys.stdout.flush()
         os._exit(0)
