@@ -728,7 +728,8 @@ def main() -> None:
                 "batch_per_gpu": B, "global_batch": global_batch, "nv": nv, "Kd": batch.Kd, "K": batch.K, "md": batch.md,
                 "parallelism": f"batch-sharded x{world}",
                 "solver": "dual active set (Goldfarb-Idnani logic) on a register-resident sweep tableau, HIP fp64, 64/W QPs per "
-                          "wavefront (W = 32 lanes per QP at nv = 30), closing iterative-refinement step",
+                          "wavefront (W = 32 lanes per QP at nv = 30), closing trips that refine the point and certify it against the KKT "
+                          "conditions (an instance that fails is solved again by the Goldfarb-Idnani kernel of round 2 in the same launch)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
