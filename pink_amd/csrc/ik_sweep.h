@@ -56,9 +56,11 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #define PINKHIP_SWEEP_COLUMN_CHAINS(NT) 2
 #endif
 
-// relative size of a gradient entry the KKT certificate of the closing trip accepts (a refined point leaves ~1e-15)
+// relative size of a gradient entry the KKT certificate of the closing trip accepts (a refined point leaves ~1e-15).
+// 1e-12 against 1e-11: free on the headline, +0.7 % on the JVRC shape, and three of the four draws in 20 000 weakly
+// regularised ones whose dq was off by 1e-3 .. 3e-2 behind a passed certificate take the hand-over (1e-13: +3 %).
 #ifndef PINKHIP_SWEEP_CERT_TOL
-#define PINKHIP_SWEEP_CERT_TOL 1e-11
+#define PINKHIP_SWEEP_CERT_TOL 1e-12
 #endif
 
 namespace pinkhip {
