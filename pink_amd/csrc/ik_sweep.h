@@ -499,13 +499,12 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
         const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
         if (ref) {
-          if (status == STATUS_INFEASIBLE || status == STATUS_MAX_ITER) {
-            // a verdict reached on a tableau that may have lost its accuracy is not handed out either: the
-            // Goldfarb-Idnani code confirms it or solves the instance (rare in practice: twice the work there)
+          if (status != STATUS_OPTIMAL) {
+            // a verdict -- inconsistent, out of iterations, a non-positive pivot in the first sweeps -- reached on a
+            // tableau that may have lost its accuracy is not handed out either: the Goldfarb-Idnani code (Cholesky
+            // factor, orthogonal updates) confirms it or solves the instance (rare in practice: twice the work there)
             status = STATUS_BREAKDOWN;
             refined = true;
-          } else if (status != STATUS_OPTIMAL) {
-            refined = true;  // (not positive definite: found by the first sweeps, nothing to certify)
           } else if (!cert_fails && !more) {
             if (sane) x += dxv;  // (below 1e-9 |x|: the certificate holds for the corrected point as well)
             refined = true;
