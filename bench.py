@@ -207,9 +207,17 @@ def full_parity(terms, batch, res) -> dict:
     return rep
 
 
-def measure_config(solver, name: str, B: int, steps: int, seed=None, **kw) -> dict:
+def solver_paths(res) -> dict:
+    """Which code solved the instances of a batch (include/pinkhip.h, PINKHIP_PATH_*): shares per path, and
+    `handover_frac` = the share that paid for BOTH solvers (tableau result failed its KKT certificate)."""
+    fr = res.path_fractions()
+    return {"paths": fr, "handover_frac": fr.get("handover", 0.0), "routed_frac": fr.get("routed", 0.0)}
+
+
+def measure_config(solver, name: str, B: int, steps: int, seed=None, ab_gi_alone: bool = False, **kw) -> dict:
     """One BASELINE configuration on the resident-batch path: kernel time, both rooflines, stack-only kernel,
-    parity of the whole batch against the oracle."""
+    parity of the whole batch against the oracle.  `ab_gi_alone`: also time the Goldfarb-Idnani kernel alone on the same
+    resident batch (PINKHIP_SOLVER=packed, read by the library per call) -- what an instance that skips the tableau costs."""
     from pink_amd import synthetic
 
     terms = synthetic.make_terms(name, B, seed=seed, **kw)
@@ -217,6 +225,22 @@ def measure_config(solver, name: str, B: int, steps: int, seed=None, **kw) -> di
     dev = solver.upload(batch)
     ms = kernel_ms_of(solver, dev, steps)
     res = solver.download(dev)
+    gi_alone = None
+    if ab_gi_alone:
+        old = os.environ.get("PINKHIP_SOLVER")
+        os.environ["PINKHIP_SOLVER"] = "packed"
+        try:
+            ms_gi = kernel_ms_of(solver, dev, steps)
+            r_gi = solver.download(dev)
+            gi_alone = {"kernel_ms": ms_gi, "ratio_default_over_gi_alone": ms / ms_gi, "failed": int((r_gi.status != 0).sum()),
+                        "max_abs_dq_difference_to_default": float(np.abs(r_gi.dq - res.dq)[(r_gi.status == 0) & (res.status == 0)].max(initial=0.0))}
+        finally:
+            if old is None:
+                del os.environ["PINKHIP_SOLVER"]
+            else:
+                os.environ["PINKHIP_SOLVER"] = old
+        solver.solve_device(dev)  # (leave the default kernel's result in the buffers)
+        solver.sync()
     stack_ms = kernel_ms_of(solver, dev, steps, stack=True)
     dev.free()
     parity = full_parity(terms, batch, res)
@@ -229,6 +253,7 @@ def measure_config(solver, name: str, B: int, steps: int, seed=None, **kw) -> di
         "hbm_GBs": batch.bytes_per_qp() * rate / 1e9, "hbm_frac": batch.bytes_per_qp() * rate / 1e9 / HBM_PEAK_GBS,
         "flops_per_qp": fl, "fp64_TFLOPs": fl * rate / 1e12, "fp64_frac": fl * rate / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
         "iters_mean": it, "iters_max": int(res.iters.max()), "failed": int((res.status != 0).sum()),
+        "solver_stats": solver_paths(res), "goldfarb_idnani_kernel_alone": gi_alone,
         "stack_only": {"kernel_ms": stack_ms, "bytes_per_qp": batch.bytes_per_stack(),
                        "achieved_GBs": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9,
                        "frac": batch.bytes_per_stack() * B / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -264,21 +289,70 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
         dt = 1.0 / 200.0
         v_dev = solve_ik_batch(cfgs, tasks, dt)
         t_dev = statistics.median(_timed(lambda: solve_ik_batch(cfgs, tasks, dt), 3))
-        n = 256
-        v_host = solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False)
-        t_host = statistics.median(_timed(lambda: solve_ik_batch(cfgs[:n], tasks[:n], dt, device_kinematics=False), 3, warmup=0))
+        v_host = solve_ik_batch(cfgs, tasks, dt, device_kinematics=False)
+        t_host = statistics.median(_timed(lambda: solve_ik_batch(cfgs, tasks, dt, device_kinematics=False), 3, warmup=0))
         out = {"workload": f"6-dof arm, FrameTask + PostureTask, {B} configurations, pink_amd {pink_amd.__version__}",
                "device_kinematics": {"ms": t_dev * 1e3, "solves_per_s": B / t_dev},
-               "host_evaluated_tasks": {"ms_for_sample": t_host * 1e3, "sample": n, "solves_per_s": n / t_host},
-               "max_abs_velocity_difference_on_sample": float(np.abs(v_dev[:n] - v_host).max())}
+               "host_evaluated_tasks_list_of_configurations": {
+                   "what": "the same list of Configuration objects and per-instance task objects with device_kinematics=False: tasks, "
+                           "limits evaluated on the host for the whole batch at once (pink_amd/batch_eval.py over one vectorised "
+                           "forward kinematics), QP on the device; what is left per instance is reading q and the target out of the "
+                           "Python objects",
+                   "ms": t_host * 1e3, "instances": B, "solves_per_s": B / t_host},
+               "max_abs_velocity_difference": float(np.abs(v_dev - v_host).max())}
+        out["host_evaluated_tasks"] = api_level_host_evaluated(m, B)
         out["headline_shape_arrays"] = api_level_arrays(Bh)
+        out["headline_shape_host_evaluated"] = api_level_arrays(Bh, extra_task="damping")
         return out
     finally:
         pink_amd.clear_device_cache()
         set_default_solver(None)
 
 
-def api_level_arrays(B: int) -> dict:
+def api_level_host_evaluated(m, B: int) -> dict:
+    """`solve_ik_batch(ConfigurationBatch, tasks, dt)` for a task stack the device-resident path does NOT form on chip --
+    FrameTask + PostureTask + DampingTask + a JointCouplingTask, under ConfigurationLimit + VelocityLimit +
+    AccelerationLimit passed explicitly -- i.e. the host-evaluated route: every task / limit evaluated for the whole
+    batch by pink_amd/batch_eval.py (vectorised NumPy over one batched forward kinematics), FrameTask rows finished by
+    the HIP frame-task kernel, the QP by the stack + solve kernel."""
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, DampingTask, FrameTask, PostureTask, solve_ik, solve_ik_batch
+    from pink_amd.lie import SE3
+    from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+    from pink_amd.tasks import JointCouplingTask
+
+    rng = np.random.default_rng(5)
+    q = np.tile(m.neutral(), (B, 1))
+    for j in m.joints:
+        q[:, j.idx_q] = rng.uniform(-0.9, 0.9, size=B)
+    cfgs = ConfigurationBatch(m, q)
+    ref = Configuration(m, q[0])
+    ft = FrameTask("tool0", 1.0, 1.0, lm_damping=1.0)
+    T0 = ref.get_transform_frame_to_world("tool0")
+    ft.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)))
+    po = PostureTask(cost=1e-3)
+    po.set_target(m.neutral())
+    tasks = [ft, po, DampingTask(cost=1e-2), JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 0.5, ref)]
+    acc = AccelerationLimit(m, np.full(m.nv, 50.0))
+    limits = [ConfigurationLimit(m), VelocityLimit(m), acc]
+    dt = 1.0 / 200.0
+    v = solve_ik_batch(cfgs, tasks, dt, limits=limits)
+    stats = pink_amd.last_solve_stats()
+    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, limits=limits), 5)
+    t_call = statistics.median(ts)
+    n = 8  # cross-check: Pink's own calling pattern, one solve_ik per configuration
+    v_ref = []
+    for b in range(n):
+        fb = FrameTask("tool0", 1.0, 1.0, lm_damping=1.0)
+        fb.set_target(SE3(ft.target_poses[b, :9].reshape(3, 3), ft.target_poses[b, 9:]))
+        v_ref.append(solve_ik(Configuration(m, q[b]), [fb, po, tasks[2], tasks[3]], dt, limits=limits))
+    return {"workload": f"6-dof arm, FrameTask + PostureTask + DampingTask + JointCouplingTask, ConfigurationLimit + VelocityLimit + "
+                        f"AccelerationLimit, B = {B} as ConfigurationBatch, targets as arrays",
+            "route": stats.get("route"), "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,
+            "max_abs_velocity_difference_vs_per_configuration_solve_ik_on_sample": float(np.abs(v[:n] - np.array(v_ref)).max()), "sample": n}
+
+
+def api_level_arrays(B: int, extra_task: str = "") -> dict:
     """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
     with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
     array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
@@ -304,15 +378,23 @@ def api_level_arrays(B: int) -> dict:
     post = PostureTask(cost=1e-1)
     post.set_target(m.neutral())
     tasks.append(post)
+    if extra_task == "damping":  # one task the whole-step kernel does not form on chip: the call takes the host-evaluated route
+        from pink_amd import DampingTask
+
+        tasks.append(DampingTask(cost=1e-2))
     cfgs = ConfigurationBatch(m, q)
     dt = 5e-3
+    import pink_amd
+
     v = solve_ik_batch(cfgs, tasks, dt)  # builds the device state
-    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt), 5)
+    stats = pink_amd.last_solve_stats()
+    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt), 5 if not extra_task else 2)
     t_call = statistics.median(ts)
     n = min(B, 16)
-    v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False)
-    return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask, default limits, "
-                        f"B = {B} as ConfigurationBatch, targets as arrays",
+    v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False)
+    return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask" + (" + DampingTask" if extra_task else "") +
+                        f", default limits, B = {B} as ConfigurationBatch, targets as arrays",
+            "route": stats.get("route"), "solver_paths": stats.get("paths"),
             "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,
             "bytes_in_per_call": int(q.nbytes + B * len(frames) * 12 * 8), "bytes_out_per_call": int(B * m.nv * 8 + 8 * B),
             "max_abs_velocity_difference_vs_host_evaluated_tasks_on_sample": float(np.abs(v[:n] - v_host).max()), "sample": n}
@@ -365,8 +447,10 @@ def closed_loop_figures(solver, B: int) -> dict:
                 ro.step()
             ms = solver.timer_stop() / steps
             _, st, it = ro.last_step()
+            n_path = np.bincount(ro.last_path.astype(np.int64), minlength=4)
             out[label] = {"nv": model.nv, "B": B, "ms_per_step": ms, "robot_steps_per_s": B / (ms * 1e-3), "launches_per_step": 1 if ro.fused == "kernel" else 2,
-                          "barrier_rows": ro.md, "qp_iters_mean": float(it.mean()), "failed": int((st != 0).sum())}
+                          "barrier_rows": ro.md, "qp_iters_mean": float(it.mean()), "failed": int((st != 0).sum()),
+                          "handover_frac": float(n_path[1]) / B, "routed_frac": float(n_path[2]) / B}
         finally:
             ro.free()
     return out
@@ -660,7 +744,7 @@ def main() -> None:
                 r2 = solver.download(d2)
                 b2 = synthetic.pack(t2)
                 regimes[label] = {"kernel_ms": ms2, "solves_per_s": B / (ms2 * 1e-3), "iters_mean": float(r2.iters.mean()),
-                                  "failed": int((r2.status != 0).sum()),
+                                  "failed": int((r2.status != 0).sum()), "solver_stats": solver_paths(r2),
                                   "parity": None if args.no_cpu_baseline else full_parity(t2, b2, r2)}
                 d2.free()
                 del b2
@@ -669,6 +753,15 @@ def main() -> None:
             extra["configs"] = {
                 "ur5_B4096": measure_config(solver, "ur5", 4096 if B >= 4096 else B, 20, bounds="tight", jacobians="dense"),
                 "jvrc_B65536": measure_config(solver, "jvrc", 65536 if B >= 4096 else B, 5, bounds="tight", jacobians="dense"),
+                # the weakly regularised regime: examples/humanoid_jvrc.py:69-81,112-114 as it is -- nv = 50, four
+                # FrameTasks, NO posture task, damping = 1e-12: cond(H) ~ 1e13-1e14.  dq is only determined to
+                # cond(H) eps there (two correct solvers differ by far more than 1e-8 along the flat directions): the
+                # parity entry certifies the point by its KKT residuals and its objective against the oracle's
+                "jvrc_noposture_weakly_regularised_B65536": measure_config(
+                    solver, "jvrc_noposture", 65536 if B >= 4096 else B, 5, ab_gi_alone=True, bounds="tight", jacobians="dense"),
+                "jvrc_noposture_weakly_regularised_tracking_B65536": measure_config(
+                    solver, "jvrc_noposture", 65536 if B >= 4096 else B, 5, ab_gi_alone=True, bounds="kinematic", jacobians="kinematic",
+                    error_scale=0.05),
             }
             # C-ABI call from host buffers: H2D + kernel + D2H (pinkhip_solve_host), and a batch of one (config 1)
             bytes_in = int(sum(a.nbytes for _, a in dev.args.streams()))
@@ -744,7 +837,7 @@ def main() -> None:
                 "model": "Kd nv (nv+1) + 2 Kd nv + nv^3/3 + 2 nv^2 + iters (4 nv^2 + 2 md nv), SURVEY.md 8(d); useful flops, not issued lanes",
             },
             "roofline_valu_issue": _valu_issue(kernel_ms, int(info.get("compute_units") or 256)),
-            "solver_stats": {"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())},
+            "solver_stats": dict({"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())}, **solver_paths(res)),
             "per_rank_kernel_ms": kernel_ms_ranks,
             "per_rank_end_to_end_ms": e2e_ranks,
             "end_to_end_solves_per_s_all_ranks": None if not e2e_ranks else global_batch / (max(e2e_ranks) * 1e-3),

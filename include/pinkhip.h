@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PINKHIP_VERSION 100
+#define PINKHIP_VERSION 110 /* 110: iters[b] carries the solver path in its high bits (PINKHIP_ITERS_*) */
 
 /* API-level error codes (negative). */
 #define PINKHIP_OK 0
@@ -46,6 +46,21 @@ extern "C" {
 #define PINKHIP_STATUS_MAX_ITER 1
 #define PINKHIP_STATUS_INFEASIBLE 2 /* quadprog: "constraints are inconsistent"        */
 #define PINKHIP_STATUS_NOT_PD 3     /* quadprog: "matrix G is not positive definite"   */
+
+/* iters[b]: active-set iterations in bits 0..23; bits 24..26 say which code solved the instance, so that a caller can
+ * tell a batch that ran on the fast path from one where part of the instances paid for both solvers:
+ *   TABLEAU   sweep-tableau kernel, result certified by its KKT check (the common case)
+ *   HANDOVER  the tableau's result failed the certificate (explicitly updated inverse, cond(H) >~ 1e8): solved again
+ *             by the Goldfarb-Idnani code (Cholesky + orthogonal updates) inside the same launch
+ *   ROUTED    sent to that code BEFORE the tableau iteration by the conditioning estimate max_i H_ii (H^-1)_ii > 1e10
+ *             (a rank-deficient task stack made positive definite by `damping` alone, pink/solve_ik.py:55)
+ *   GI        the Goldfarb-Idnani kernel by dispatch (shapes the tableau kernel does not serve, PINKHIP_SOLVER=packed) */
+#define PINKHIP_ITERS_COUNT(x) ((x) & 0xFFFFFF)
+#define PINKHIP_ITERS_PATH(x) (((x) >> 24) & 7)
+#define PINKHIP_PATH_TABLEAU 0
+#define PINKHIP_PATH_HANDOVER 1
+#define PINKHIP_PATH_ROUTED 2
+#define PINKHIP_PATH_GI 3
 
 #define PINKHIP_TASK_DENSE 0    /* rows of J stored                                      */
 #define PINKHIP_TASK_DIAGONAL 1 /* J = eye(nv)[col0:col0+k] (pink/tasks/posture_task.py:128-129) */
@@ -111,7 +126,8 @@ typedef struct pinkhip_problem {
 } pinkhip_problem;
 
 /* Results.  dq [B,nv] is the QP minimiser (pink/solve_ik.py:271; the caller
- * divides by dt for the velocity, :274).  status [B]; iters [B] may be NULL. */
+ * divides by dt for the velocity, :274).  status [B]; iters [B] may be NULL
+ * (PINKHIP_ITERS_COUNT / PINKHIP_ITERS_PATH above). */
 typedef struct pinkhip_result {
   double *dq;
   int32_t *status;

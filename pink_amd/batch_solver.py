@@ -19,6 +19,18 @@ from ._lib import PackedArgs, PinkHipError, Problem, Result
 from .batch import IKBatch
 
 
+PATH_NAMES = ("tableau", "handover", "routed", "goldfarb_idnani")  # PINKHIP_PATH_* of include/pinkhip.h
+_PATH_SHIFT = 24
+
+
+def split_iters(raw: np.ndarray) -> np.ndarray:
+    """``iters[b]`` as the library writes it carries the code that solved the instance in its high bits
+    (``PINKHIP_ITERS_PATH``): returns that code per instance and leaves the iteration count in ``raw`` (in place)."""
+    path = (raw >> _PATH_SHIFT).astype(np.int8)
+    np.bitwise_and(raw, (1 << _PATH_SHIFT) - 1, out=raw)
+    return path
+
+
 @dataclass
 class BatchResult:
     """Output of one batched solve."""
@@ -26,6 +38,7 @@ class BatchResult:
     dq: np.ndarray  # [B, nv] displacement (divide by dt for the velocity, solve_ik.py:274)
     status: np.ndarray  # [B] int32, 0 = optimal (see include/pinkhip.h)
     iters: np.ndarray  # [B] int32 active-set iterations
+    path: Optional[np.ndarray] = None  # [B] int8: which code solved the instance (index into PATH_NAMES)
 
     @property
     def all_found(self) -> bool:
@@ -33,6 +46,16 @@ class BatchResult:
 
     def failed_indices(self) -> np.ndarray:
         return np.nonzero(self.status != 0)[0]
+
+    def path_fractions(self) -> Dict[str, float]:
+        """Share of the batch per solver path: ``tableau`` (sweep-tableau kernel, KKT-certified), ``handover`` (its
+        result failed the certificate: solved again by the Goldfarb-Idnani code in the same launch -- the instance paid
+        both), ``routed`` (sent there before the tableau iteration by the conditioning estimate), ``goldfarb_idnani``
+        (that kernel by dispatch)."""
+        if self.path is None or self.path.size == 0:
+            return {}
+        n = np.bincount(self.path.astype(np.int64), minlength=len(PATH_NAMES))
+        return {name: float(n[k]) / self.path.size for k, name in enumerate(PATH_NAMES)}
 
 
 class DeviceBatch:
@@ -160,7 +183,7 @@ class BatchSolver:
         r.dq, r.status, r.iters = dq.ctypes.data, status.ctypes.data, iters.ctypes.data
         p = a.host_problem()
         self._check(self._lib.pinkhip_solve_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r)))
-        return BatchResult(dq, status, iters)
+        return BatchResult(dq, status, iters, split_iters(iters))
 
     def pinned_result(self, B: int, nv: int) -> BatchResult:
         """Result arrays in page-locked memory, for ``solve(..., out=)``."""
@@ -253,7 +276,7 @@ class BatchSolver:
             self._d2h(dq, dev.d_dq)
             self._d2h(status, dev.d_status)
             self._d2h(iters, dev.d_iters)
-        return BatchResult(dq, status, iters)
+        return BatchResult(dq, status, iters, split_iters(iters))
 
     def download_stack(self, dev: DeviceBatch) -> Tuple[np.ndarray, np.ndarray]:
         b = dev.args.batch

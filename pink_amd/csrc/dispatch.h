@@ -91,20 +91,24 @@ constexpr int packed_lds_doubles(int NV, int md) {
 }
 constexpr int max3(int a, int b, int c) { return (a > b ? a : b) > c ? (a > b ? a : b) : c; }
 
+// World positions of the nf task frames, kept BEHIND the area the kinematics and the two solvers share: the rows of
+// position barriers are formed from them while the Goldfarb-Idnani code (hand-over) is already writing its staged rows.
+constexpr int rollout_tail_doubles(int nf) { return (3 * nf + 1) & ~1; }
+
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
-// LDS, whichever is larger.
-constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0) {
-  return max3((fk_doubles + 1) & ~1, sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD));
+// LDS, whichever is larger (+ the frame positions behind it when dense rows are formed on chip).
+constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0, int nf = 0) {
+  return max3((fk_doubles + 1) & ~1, sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD)) + (MD > 0 ? rollout_tail_doubles(nf) : 0);
 }
 
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
 // kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the 64 / W
 // robots of a wavefront must fit the 64 KiB of LDS a workgroup may ask for.
 // ... with md > 0 rows of position barriers: {NV, MD, W} from PINKHIP_ROLLOUT_DENSE_TABLE
-inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md) {
+inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md, int nf) {
 #define PINKHIP_PICK(NV_, MD_, W_)                                                                          \
   if (nv <= NV_ && md <= MD_ && nj <= W_) {                                                                 \
-    const int need = rollout_lds_doubles(NV_, W_, fk_doubles, MD_);                                         \
+    const int need = rollout_lds_doubles(NV_, W_, fk_doubles, MD_, nf);                                     \
     if (8 * need * (64 / W_) + 16 <= 65536) return SweepChoice{NV_, MD_, W_};                               \
   }
   PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_PICK)

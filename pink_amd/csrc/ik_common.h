@@ -19,6 +19,18 @@
 #define PINKHIP_GROUP_SMALL 4  // NV <= 16
 #endif
 
+// Development trace: compiled in only by the CPU wave emulator built with -DPINKHIP_TRACE (a printf per traced
+// event); the HIP build never defines it.
+#if defined(PINKHIP_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#define PINKHIP_TRACEF(cond, ...)        \
+  do {                                   \
+    if (cond) std::printf(__VA_ARGS__);  \
+  } while (0)
+#else
+#define PINKHIP_TRACEF(cond, ...)
+#endif
+
 namespace pinkhip {
 
 template <int NV>
@@ -72,6 +84,12 @@ constexpr int STATUS_NOT_PD = 3;
 // updated inverse lost too much accuracy: weakly regularised objectives, cond(H) >~ 1e8) -- the Goldfarb-Idnani kernel
 // solves the instance again in the same launch, callers never see this value
 constexpr int STATUS_BREAKDOWN = 4;
+// ... or the conditioning estimate after the start-up sweeps says that it would not: the instance goes to the
+// Goldfarb-Idnani code before the tableau iteration instead of after it
+constexpr int STATUS_ROUTED = 5;
+// Which code solved an instance: bits 24.. of iters[b] (include/pinkhip.h, PINKHIP_PATH_*)
+constexpr int PATH_TABLEAU = 0, PATH_HANDOVER = 1, PATH_ROUTED = 2, PATH_GI = 3;
+constexpr int kPathShift = 24;
 
 // Everything a launch needs; passed by value in the kernarg segment.
 struct KernelArgs {

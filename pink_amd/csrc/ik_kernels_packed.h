@@ -76,9 +76,11 @@ struct LdsP {
 // only, md = 0): every dense-row branch and its state (row slacks, row norms, equality bookkeeping)
 // folds away at compile time.
 template <int NV, int W, bool DENSE = true, class Src = HbmTerms>
-__device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr, bool only = true) {
+__device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long long block, Src *terms = nullptr, bool only = true,
+                                                   int path = PATH_GI) {
   // only: this lane's group is to be solved (the sweep-tableau kernel hands over the groups whose result did not pass
   // its certificate; the other groups of the wavefront go through the motions and write nothing)
+  // path: why this code runs the instance (PATH_*), reported in the high bits of iters[b]
   static_assert(W >= NV && NV % 2 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "group width");
   using S = LdsP<NV>;
   constexpr int GP = S::GP, G = kWave / W, kG = group_size<NV>();
@@ -739,8 +741,11 @@ __device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long lon
     double bnd = 0.0;
     if (wave_any(act && !(t < INF)))
       bnd = group_bcast<W>((DENSE && kind >= 2) ? hv : (kind == 0 ? lbv : ubv), src & (W - 1));
+    PINKHIP_TRACEF(li == 0 && act, "[packed g%d it%d] enter src %d kind %d sp %.3e d2n %.3e dd %.3e lin_dep %d t1 %.3e t2 %.3e q %d\n", g, it,
+                   src, kind, sp, d2n, dd, (int)lin_dep, t1, t2, q);
     if (act && !(t < INF)) {
       const bool tiny = fabs(sp) <= 1e-9 * (1.0 + fabs(bnd));
+      PINKHIP_TRACEF(li == 0, "[packed g%d it%d] stuck: src %d kind %d sp %.3e bnd %.3e tiny %d\n", g, it, src, kind, sp, bnd, (int)tiny);
       if ((DENSE && kind >= 2) && src < n_eq && tiny) {
         // equality implied by the active ones and already satisfied: nothing to add
         ++eq_next;
@@ -931,7 +936,7 @@ __device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long lon
     if (in) late->dq[b * (long long)nv + li] = x;
     if (li == 0) {
       late->status[b] = status;
-      if (late->iters) late->iters[b] = it;
+      if (late->iters) late->iters[b] = it | (path << kPathShift);
     }
   }
 }

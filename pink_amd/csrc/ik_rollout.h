@@ -11,6 +11,7 @@
 // kernel's LDS (the stated problem parked for its closing refinement step, written after stacking) overlay each other.
 #pragma once
 
+#include "dispatch.h"
 #include "ik_kinematics.h"
 #include "ik_sweep.h"
 
@@ -68,7 +69,11 @@ struct FkTerms {
   // joint is an ancestor of the frame) = column li of R J_lin (position_barrier.py:136-145).
   const int *bar_frame = nullptr, *bar_axis = nullptr;
   const double *bar_sign = nullptr, *bar_bound = nullptr, *bar_gain = nullptr;
-  const double *pfs = nullptr;  // LDS: frame f's world position at pfs[12 f + 9 .. 11]
+  // LDS: frame f's world position at pfs[3 f .. 3 f + 2] -- a copy behind the area the kinematics scratch shares with
+  // the solvers' working sets (dispatch.h, rollout_tail_doubles): the Goldfarb-Idnani code of the hand-over forms the
+  // barrier rows while it is already writing its staged copy of them (its Gs overlaid the frame poses: the right-hand
+  // side of a barrier row read back an entry of G -- scripts/gpu_fuzz_rollout.py seed 24680, "inconsistent")
+  const double *pfs = nullptr;
   double inv_dt = 0.0;
   int n_lim = 0, root_sub = -1;  // constant rows of the floating-base limit; this lane's coordinate of the root joint
   const double *lim_rows = nullptr, *lim_h = nullptr;
@@ -76,7 +81,7 @@ struct FkTerms {
     if (d < n_lim) return root_sub >= 0 ? lim_rows[6 * d + root_sub] : 0.0;
     d -= n_lim;
     const int f = bar_frame[d], i = bar_axis[d];
-    const double *pf = pfs + 12 * f + 9;
+    const double *pf = pfs + 3 * f;
     const double v0 = lin[0] + ang[1] * pf[2] - ang[2] * pf[1];
     const double v1 = lin[1] + ang[2] * pf[0] - ang[0] * pf[2];
     const double v2 = lin[2] + ang[0] * pf[1] - ang[1] * pf[0];
@@ -86,7 +91,7 @@ struct FkTerms {
   __device__ __forceinline__ double dense_h(int d) const {
     if (d < n_lim) return lim_h[d];
     d -= n_lim;
-    return bar_gain[d] * bar_sign[d] * (pfs[12 * bar_frame[d] + 9 + bar_axis[d]] - bar_bound[d]);
+    return bar_gain[d] * bar_sign[d] * (pfs[3 * bar_frame[d] + bar_axis[d]] - bar_bound[d]);
   }
 };
 
@@ -110,7 +115,7 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     if constexpr (MD > 0) {
       tt.bar_frame = ra.bar_frame, tt.bar_axis = ra.bar_axis;
       tt.bar_sign = ra.bar_sign, tt.bar_bound = ra.bar_bound, tt.bar_gain = ra.bar_gain;
-      tt.pfs = sm + 12 * mm.nj;  // = fMo of ik_fk_instance
+      tt.pfs = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
       tt.inv_dt = 1.0 / ra.k.dt;
       tt.n_lim = ra.n_lim, tt.lim_rows = ra.lim_rows, tt.lim_h = ra.lim_h;
       if (ra.n_lim > 0 && mm.root_nv == 6) {  // (the free-flyer is the first joint after the universe: columns 0 .. 5)
@@ -120,22 +125,34 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     }
     return tt;
   };
+  // (frame positions out of the shared area: fMo of ik_fk_instance holds frame f's pose at sm[12 (nj + f) ..])
+  auto keep_frame_positions = [&](const RolloutArgs &ra) {
+    if constexpr (MD > 0) {
+      const ModelDev &mm = ra.fk.m;
+      double *tail = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
+      for (int i = li; i < 3 * mm.nf; i += W) tail[i] = sm[12 * (mm.nj + i / 3) + 9 + i % 3];
+      wave_sync();
+    }
+  };
   FkTerms<W> t = make_terms(a);
   ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
   wave_sync();
+  keep_frame_positions(a);
   const int st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
   // a result that fails its KKT certificate is not integrated: the Goldfarb-Idnani code solves that robot's QP again
   // (ik_sweep.h, ik_solve_sweep_body).  It forms the rows from the kinematics like the tableau did, and the tableau's
   // parking area has overwritten the kinematics scratch meanwhile: the kinematics run once more (wave-uniform, rare).
-  if (wave_any(st_sweep == STATUS_BREAKDOWN)) {
+  const bool over = st_sweep == STATUS_BREAKDOWN || st_sweep == STATUS_ROUTED;
+  if (wave_any(over)) {
     wave_sync();
     // (arguments read again, terms built again: nothing of them is kept in registers through the tableau loop)
     const RolloutArgs *again = kernarg_reload<RolloutArgs>(a);
     FkTerms<W> t2 = make_terms(*again);
     ik_fk_instance<W, true, true, FkTerms<W>>(again->fk, block, &t2, sm);
     wave_sync();
-    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, st_sweep == STATUS_BREAKDOWN);
-    if (st_sweep == STATUS_BREAKDOWN) t.x = t2.x, t.status = t2.status;
+    keep_frame_positions(*again);
+    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, over, st_sweep == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER);
+    if (over) t.x = t2.x, t.status = t2.status;
   }
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)
   const int st = t.status;  // group-uniform

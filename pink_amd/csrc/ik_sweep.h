@@ -62,6 +62,10 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #ifndef PINKHIP_SWEEP_CERT_TOL
 #define PINKHIP_SWEEP_CERT_TOL 1e-12
 #endif
+// conditioning estimate max_i H_ii (H^-1)_ii beyond which an instance skips the tableau iteration
+#ifndef PINKHIP_SWEEP_ROUTE_COND
+#define PINKHIP_SWEEP_ROUTE_COND 1e10
+#endif
 
 namespace pinkhip {
 
@@ -241,6 +245,16 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // n^T H^-1 n (the unreduced curvature along a constraint normal): the reference of the linear-dependence test.
   // Box-only problems never need it: a free coordinate always has curvature left.
   const double zd0 = -tdiag;
+  // Conditioning estimate  max_i H_ii (H^-1)_ii <= cond(H)  (both diagonals are at hand).  Beyond the threshold the
+  // explicitly updated inverse is not expected to certify its result (weakly regularised objectives: a rank-deficient
+  // task stack made positive definite by `damping` alone, pink/solve_ik.py:55, examples/humanoid_jvrc.py:69-81): the
+  // group skips the tableau iteration and goes to the Goldfarb-Idnani code right away instead of paying both.
+  {
+    const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
+    const double kest = -group_min<W>(-(hii0 * zd0));
+    PINKHIP_TRACEF(li == 0, "[sweep g%d] kest %.3e\n", g, kest);
+    if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;  // (NaN: routed)
+  }
   PINKHIP_TICK(2);  // x0
 
   // ------------------------------------------------------------------ dual active set on the tableau
@@ -276,7 +290,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   double uplus = 0.0;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
-  bool refined = false;  // the closing refinement step(s) of this group have been taken
+  bool refined = (status == STATUS_ROUTED);  // the closing refinement step(s) of this group have been taken
   int nref = 0;
   double dprev = 0.0;  // largest entry of the previous refinement step
 
@@ -552,6 +566,8 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         if (little) pv = -curv;
       }
       lin_dep = !(-pv * 1e12 > z0);
+      PINKHIP_TRACEF(li == 0 && act, "[sweep g%d it%d] enter src %d kind %d num %.3e pv %.3e z0 %.3e little %d lin_dep %d\n", g, it, src, kind,
+                     num, pv, z0, (int)little, (int)lin_dep);
     }
     // (a group without an entering constraint computes on garbage from here on: everything it could change is
     // masked by act / act2 below)
@@ -578,6 +594,8 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     }
     if (act && stuck) {
       const bool tiny = DENSE && fabs(num) <= 1e-9 * (1.0 + fabs(hs));
+      PINKHIP_TRACEF(li == 0, "[sweep g%d it%d] stuck: src %d kind %d num %.3e hs %.3e pv %.3e lin_dep %d k1 %.3e full %.3e tiny %d\n",
+                     g, it, src, kind, num, hs, pv, (int)lin_dep, k1, full, (int)tiny);
       if (kind == 3 && tiny) {
         // equality implied by the active ones and already satisfied: nothing to add
         ++eq_next;
@@ -688,10 +706,11 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       if (in) late->dq[bw * (long long)nv + li] = x;
       if (li == 0) {
         late->status[bw] = status;
-        if (late->iters) late->iters[bw] = it;
+        if (late->iters) late->iters[bw] = it;  // (PATH_TABLEAU = 0; a group handed over is written again)
       }
     }
   }
+  PINKHIP_TRACEF(li == 0, "[sweep g%d] exit status %d it %d nref %d\n", g, status, it, nref);
   return status;  // (of this lane's group)
 }
 
@@ -714,7 +733,7 @@ __device__ __forceinline__ void ik_solve_sweep_body(const KernelArgs &a, long lo
 #ifdef PINKHIP_SWEEP_FORCE_HANDOVER  // (development: every instance takes the hand-over)
   const bool over = true;
 #else
-  const bool over = st == STATUS_BREAKDOWN;
+  const bool over = st == STATUS_BREAKDOWN || st == STATUS_ROUTED;
 #endif
   if (wave_any(over)) {
     wave_sync();
@@ -725,7 +744,7 @@ __device__ __forceinline__ void ik_solve_sweep_body(const KernelArgs &a, long lo
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(blk));
 #endif
-    ik_packed_instance<NV, W, (MD > 0)>(*again, blk, static_cast<HbmTerms *>(nullptr), over);
+    ik_packed_instance<NV, W, (MD > 0)>(*again, blk, static_cast<HbmTerms *>(nullptr), over, st == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER);
   }
 #endif
 }

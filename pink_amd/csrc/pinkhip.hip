@@ -776,9 +776,9 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   pinkhip::PackedChoice pc{0, 0};
   pinkhip::SweepChoice dc{0, 0, 0};
   if (desc->md > 0) {
-    dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md);
+    dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md, md.nf);
     if (dc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation with barrier rows fits this model");
-    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD);
+    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD, md.nf);
     ra.bar_frame = st->barrier_frame;
     ra.bar_axis = st->barrier_axis;
     ra.bar_sign = st->barrier_sign;

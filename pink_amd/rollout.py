@@ -28,10 +28,15 @@ import numpy as np
 
 from ._lib import Desc, Problem, Result, RolloutStep, Step, c_double_p, c_int32_p
 from .configuration import Model
-from .exceptions import NoSolutionFound, NotWithinConfigurationLimits
+from .exceptions import NoSolutionFound, NotWithinConfigurationLimits, PinkError
 from .utils import get_root_joint_dim
 
 _JT = {"revolute": 0, "prismatic": 1, "free_flyer": 2}
+
+
+class NoWholeStepKernel(PinkError):
+    """No instantiation of the whole-step kernel holds this model with its dense rows (``dispatch.h``:
+    ``PINKHIP_ROLLOUT_DENSE_TABLE``); ``solve_ik_batch`` then evaluates the batch on the host-evaluated path."""
 
 
 class ModelDesc(ctypes.Structure):
@@ -320,9 +325,7 @@ class DeviceRollout:
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             if self.md:
-                from .exceptions import PinkError
-
-                raise PinkError("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
+                raise NoWholeStepKernel("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
             self.fused = True  # no instantiation for this model: two launches from now on
             if self.targets_per_frame:  # those kernels read [B, nf, 12]: restack what was uploaded frame by frame
                 t = np.zeros((nf, B, 12))
@@ -487,13 +490,17 @@ class DeviceRollout:
         return q
 
     def last_step(self):
-        """``(dq, status, iters)`` of the most recent step."""
+        """``(dq, status, iters)`` of the most recent step; the code that solved each robot's QP (index into
+        ``pink_amd.batch_solver.PATH_NAMES``) is kept as ``self.last_path``."""
+        from .batch_solver import split_iters
+
         dq = np.empty((self.B, self.nv))
         st = np.empty(self.B, np.int32)
         it = np.empty(self.B, np.int32)
         self.api.get(dq, self.d_dq)
         self.api.get(st, self.d_status)
         self.api.get(it, self.d_iters)
+        self.last_path = split_iters(it)
         return dq, st, it
 
     def frame_poses(self) -> np.ndarray:

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from .batch import IKBatch
-from .batch_solver import BatchResult
+from .batch_solver import BatchResult, split_iters
 from .comm import RcclComm
 
 
@@ -36,7 +36,8 @@ def _assemble(parts, sizes, nv) -> BatchResult:
     dq = np.concatenate([np.asarray(p[0]).reshape(-1, nv)[: h - l] for p, (l, h) in zip(parts, sizes)], axis=0)
     st = np.concatenate([np.asarray(p[1])[: h - l] for p, (l, h) in zip(parts, sizes)])
     it = np.concatenate([np.asarray(p[2])[: h - l] for p, (l, h) in zip(parts, sizes)])
-    return BatchResult(np.ascontiguousarray(dq), np.ascontiguousarray(st, dtype=np.int32), np.ascontiguousarray(it, dtype=np.int32))
+    it = np.array(it, dtype=np.int32)  # (raw: iteration count + the solver path in the high bits, as the library writes it)
+    return BatchResult(np.ascontiguousarray(dq), np.ascontiguousarray(st, dtype=np.int32), it, split_iters(it))
 
 
 def solve_sharded(batch: IKBatch, solver, comm, gather_to: Optional[int] = 0) -> Optional[BatchResult]:
@@ -94,6 +95,8 @@ def solve_sharded(batch: IKBatch, solver, comm, gather_to: Optional[int] = 0) ->
     st = np.zeros(nmax, dtype=np.int32)
     it = np.zeros(nmax, dtype=np.int32)
     dq[:n], st[:n], it[:n] = local.dq, local.status, local.iters
+    if local.path is not None:  # (travels the way the library encodes it)
+        it[:n] |= local.path.astype(np.int32) << 24
     parts = comm.gather_arrays([dq, st, it], gather_to)
     return _assemble(parts, sizes, nv) if receiver else None
 
@@ -126,12 +129,32 @@ class MultiDeviceSolver:
     def solve(self, batch: IKBatch, max_iter: int = 0) -> BatchResult:
         world = len(self.solvers)
         bounds = [shard_bounds(batch.B, r, world) for r in range(world)]
-        parts = self.map(lambda r, s: s.solve(batch.slice(*bounds[r]), max_iter=max_iter) if bounds[r][1] > bounds[r][0] else None)
-        parts = [p for p in parts if p is not None]
+        import time
+
+        def one(r, s):
+            if bounds[r][1] <= bounds[r][0]:
+                return None
+            t0 = time.perf_counter()
+            out = s.solve(batch.slice(*bounds[r]), max_iter=max_iter)
+            return out, 1e3 * (time.perf_counter() - t0)
+
+        t_all = time.perf_counter()
+        done = self.map(one)
+        # per-device breakdown of the last call (kernel-only and end-to-end scaling reported separately):
+        # end-to-end = H2D + kernel + D2H of that device's shard as seen by its host thread; kernel = the HIP-event time of
+        # the shard's solve kernel(s) where the per-device solver reports it
+        self.last_timing = {
+            "wall_ms": 1e3 * (time.perf_counter() - t_all),
+            "per_device": [None if d is None else {"device_id": self.device_ids[r], "instances": bounds[r][1] - bounds[r][0],
+                                                   "end_to_end_ms": d[1], "kernel_ms": getattr(self.solvers[r], "last_kernel_ms", None)}
+                           for r, d in enumerate(done)],
+        }
+        parts = [d[0] for d in done if d is not None]
         if not parts:
             return self.solvers[0].solve(batch, max_iter=max_iter)
+        path = None if any(p.path is None for p in parts) else np.concatenate([p.path for p in parts])
         return BatchResult(np.concatenate([p.dq for p in parts]), np.concatenate([p.status for p in parts]),
-                           np.concatenate([p.iters for p in parts]))
+                           np.concatenate([p.iters for p in parts]), path)
 
     def stack(self, batch: IKBatch):
         return self.solvers[0].stack(batch)

@@ -174,19 +174,111 @@ def _pose12(T) -> np.ndarray:
 _PAD_ROW_H = 1e30  # right-hand side of the padding rows  0 dq <= PAD
 
 
+class _SharedSlot:
+    """One task object shared by the ``B`` instances of a batch (a sequence of ``B`` references to it)."""
+
+    shared = True
+
+    def __init__(self, task, B: int):
+        self.task, self.B = task, B
+
+    def __len__(self) -> int:
+        return self.B
+
+    def __getitem__(self, b):
+        return self.task
+
+    def __iter__(self):
+        return (self.task for _ in range(self.B))
+
+
+def _task_slots(tasks, B: int):
+    """``tasks`` (one list for all instances, or one list per instance) as a list of slots; slot ``k`` holds the
+    ``k``-th task of every instance."""
+    per_instance = B > 0 and len(tasks) == B and isinstance(tasks[0], (list, tuple))
+    if per_instance:
+        _check_same_length(tasks)
+        return [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))]
+    return [_SharedSlot(t, B) for t in tasks]
+
+
+def _batch_kinematics(configurations):
+    """:class:`~pink_amd.kinematics_batch.BatchKinematics` of ``configurations`` (a ``ConfigurationBatch`` or a list
+    of ``Configuration`` objects of one model), or ``None`` when the list mixes models."""
+    from .configuration import ConfigurationBatch
+    from .kinematics_batch import BatchKinematics
+
+    if isinstance(configurations, ConfigurationBatch):
+        return configurations.kinematics()
+    model = configurations[0].model
+    if not hasattr(model, "joints") or any(c.model is not model for c in configurations):
+        return None
+    kin = BatchKinematics(model, np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations]))
+    kin._cfgs = dict(enumerate(configurations))  # (evaluators that fall back to per-instance methods use the caller's objects)
+    return kin
+
+
 def pack_configurations(configurations: Sequence, tasks: Sequence, dt: float, damping: float = 1e-12, limits=None,
                         barriers=None, solver_handle=None, gpu_frame_tasks: bool = True, constraints=None) -> IKBatch:
     """Evaluate the same task / limit / barrier objects at every configuration and
     pack the batch.  The task list may also be a list of per-instance lists (one
     target per instance): ``tasks[b]`` is then used for ``configurations[b]``.
 
-    FrameTasks are evaluated for the whole batch by the HIP frame-task kernel
-    (``log6`` / ``Jlog6`` / ``-Jlog6 J_body``, ``pink/tasks/frame_task.py:176-227``) when
-    ``gpu_frame_tasks`` is set: the host only gathers poses and body Jacobians.
+    Everything is evaluated for the whole batch at once (:mod:`pink_amd.batch_eval` over one vectorised forward
+    kinematics, :mod:`pink_amd.kinematics_batch`): no ``Configuration`` object and no Python loop per instance for the
+    task, limit and barrier classes the package ships; user subclasses fall back to their own per-configuration
+    methods.  FrameTasks are finished by the HIP frame-task kernel (``log6`` / ``Jlog6`` / ``-Jlog6 J_body``,
+    ``pink/tasks/frame_task.py:176-227``) when ``gpu_frame_tasks`` is set.
 
     ``constraints`` (tasks enforced as equalities, ``pink/solve_ik.py:125-149``) follows the same convention
     as ``tasks``: one list for all instances or one list per instance.
     """
+    from . import batch_eval as be
+
+    B = len(configurations)
+    if B == 0:
+        return pack_terms(0, [], dt, damping, batch_size=0)
+    kin = _batch_kinematics(configurations)
+    if kin is None:
+        return _pack_configurations_per_instance(configurations, tasks, dt, damping, limits, barriers, solver_handle,
+                                                 gpu_frame_tasks, constraints)
+    model, nv = kin.model, kin.model.nv
+    ft_solver = None
+    if gpu_frame_tasks:
+        from .runtime import default_solver
+
+        ft_solver = solver_handle or default_solver()
+    merged = [be.task_term(kin, col, ft_solver) for col in _task_slots(tasks, B)]
+    if limits is None:  # model defaults, pink/solve_ik.py:94-105
+        model.ensure_limits()
+        limits = [model.configuration_limit, model.velocity_limit]
+        if getattr(model, "floating_base_velocity_limit", None) is not None:
+            limits.append(model.floating_base_velocity_limit)
+    lb = np.full((B, nv), -np.inf)
+    ub = np.full((B, nv), np.inf)
+    dense_rows = []
+    for limit in limits:
+        rows = be.limit_rows(kin, limit, dt, lb, ub)
+        if rows is not None:
+            dense_rows.append(rows)
+    barrier_terms = [be.barrier_term(kin, bar) for bar in (barriers or [])]
+    equality_rows = []
+    if constraints:  # pink/solve_ik.py:125-149: A = J, b = -gain e of each task to enforce strictly
+        for col in _task_slots(constraints, B):
+            t = be.task_term(kin, col, None)
+            if isinstance(t, DiagonalTaskTerm):
+                k = t.e.shape[1]
+                A = np.broadcast_to(np.eye(nv)[t.col0:t.col0 + k], (B, k, nv))
+            else:
+                A = t.J
+            equality_rows.append((A, -t.gain * t.e))
+    return pack_terms(nv, merged, dt, damping, boxes=[(lb, ub)], dense_rows=dense_rows, barriers=barrier_terms,
+                      batch_size=B, equality_rows=equality_rows)
+
+
+def _pack_configurations_per_instance(configurations, tasks, dt, damping, limits, barriers, solver_handle, gpu_frame_tasks,
+                                      constraints) -> IKBatch:
+    """:func:`pack_configurations` one configuration at a time (configurations of different model objects)."""
     from .tasks.frame_task import FrameTask
 
     B = len(configurations)
@@ -289,7 +381,11 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     from .barriers.position_barrier import PositionBarrier
 
     B = len(configurations)
-    if B == 0 or constraints or limits is not None:
+    if B == 0 or constraints:
+        return None
+    model = configurations.model if hasattr(configurations, "model") else configurations[0].model
+    gain = _default_limits_gain(model, limits)
+    if gain is None:
         return None
     for bar in barriers or ():
         # position barriers with the default class-K function and no safe displacement of their own are formed on chip
@@ -301,10 +397,35 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         frames = [sp[0] for sp in plan[2]]
         if any(bar.frame not in frames for bar in barriers):
             return None
-        plan = plan + (tuple(barriers),)
+        plan = plan + (tuple(barriers), gain)
     elif plan is not None:
-        plan = plan + ((),)
+        plan = plan + ((), gain)
     return plan
+
+
+def _default_limits_gain(model, limits) -> Optional[float]:
+    """``config_limit_gain`` when ``limits`` amounts to the model's default limits (``pink/solve_ik.py:94-105``) --
+    ``None`` itself, or an explicit list holding exactly one ConfigurationLimit and one VelocityLimit of this model
+    with the model's velocity vector (plus the model's floating-base limit if it has one): what the device kernels
+    form from the model tables -- else ``None``."""
+    from .limits import ConfigurationLimit, VelocityLimit
+
+    if not hasattr(model, "ensure_limits"):
+        return None
+    model.ensure_limits()
+    if limits is None:
+        return float(model.configuration_limit.config_limit_gain)
+    fb = getattr(model, "floating_base_velocity_limit", None)
+    cl = [l for l in limits if type(l) is ConfigurationLimit]
+    vl = [l for l in limits if type(l) is VelocityLimit]
+    rest = [l for l in limits if type(l) not in (ConfigurationLimit, VelocityLimit)]
+    if len(cl) != 1 or len(vl) != 1 or cl[0].model is not model or vl[0].model is not model:
+        return None
+    if rest != ([] if fb is None else [fb]):
+        return None
+    if not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
+        return None
+    return float(cl[0].config_limit_gain)
 
 
 def _barrier_key(bar):
@@ -320,7 +441,16 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     from .tasks.posture_task import PostureTask
 
     B = len(configurations)
-    if isinstance(configurations, ConfigurationBatch):
+    as_arrays = isinstance(configurations, ConfigurationBatch)
+    if not as_arrays and not (len(tasks) == B and isinstance(tasks[0], (list, tuple))):
+        # a list of Configuration objects with ONE task list for all of them: the tasks are shared objects, their
+        # targets one for all or per instance as arrays (set_target_poses / set_target_batch) -- same rules as below
+        model = configurations[0].model
+        if any(c.model is not model for c in configurations):
+            return None
+        configurations = ConfigurationBatch(model, np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations]))
+        as_arrays = True
+    if as_arrays:
         # arrays in, arrays out: the tasks are shared objects carrying per-instance targets as arrays
         model, q = configurations.model, configurations.q
         specs, targets, posture = [], [], None
@@ -359,10 +489,8 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     model = configurations[0].model
     if any(c.model is not model for c in configurations):
         return None
-    per_instance = len(tasks) == B and isinstance(tasks[0], (list, tuple))
-    if per_instance:
-        _check_same_length(tasks)
-    slots = [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))] if per_instance else [[t] * B for t in tasks]
+    _check_same_length(tasks)
+    slots = [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))]
     specs, targets, posture = [], [], None
     for col in slots:
         t0 = col[0]
@@ -427,18 +555,30 @@ def clear_device_cache() -> None:
         cache.clear()
 
 
+def _model_fingerprint(model, frames) -> int:
+    """Content hash of what a cached device state bakes in from the model: joint limits, velocity limits and the
+    placements of the task frames (edits to them must not be served from the cache)."""
+    parts = [model.lowerPositionLimit.tobytes(), model.upperPositionLimit.tobytes(), model.velocityLimit.tobytes()]
+    for name in frames:
+        f = model.frames[model.getFrameId(name)]
+        parts.append(np.asarray(f.placement.rotation, dtype=float).tobytes() + np.asarray(f.placement.translation, dtype=float).tobytes())
+        parts.append(str(f.joint).encode())
+    parts.append(str(len(model.joints)).encode())
+    return hash(b"".join(parts))
+
+
 def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
     """FK, task rows, limits and the QP for the whole batch in device kernels (one launch where the whole-step
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, bars = plan
+    model, q, specs, T, posture, bars, limit_gain = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
-    fb = getattr(model, "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
+    fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
     fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
-    key = (id(model), B, tuple(specs), float(dt), float(damping), pkey, int(max_iter),
-           float(model.configuration_limit.config_limit_gain), tuple(_barrier_key(b) for b in bars), fkey)
+    key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
+           int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey)
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     fresh = False
@@ -446,7 +586,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
         kw = {}
         if posture is not None:
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
-        ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=model.configuration_limit.config_limit_gain,
+        ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
         fresh = True
@@ -460,7 +600,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
             ro.set_targets(T)
             ro.step(integrate=False)
         api.sync()
-        out = ro.last_step()
+        out = ro.last_step() + (ro.last_path,)
     except BaseException:
         ro.free()
         raise
@@ -470,42 +610,12 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
     return out
 
 
-def _expand_batched_targets(tasks, B):
-    """Host-evaluated path: a shared task carrying per-instance targets as arrays (``FrameTask.set_target_poses``,
-    ``PostureTask.set_target_batch``) becomes one task object per instance, as the list form expects."""
-    import copy
-
-    from .lie import SE3
-
-    if B == 0 or (len(tasks) == B and isinstance(tasks[0], (list, tuple))):
-        return tasks
-    if not any(getattr(t, "target_poses", None) is not None or getattr(t, "target_q_batch", None) is not None for t in tasks):
-        return tasks
-    out = [[] for _ in range(B)]
-    for t in tasks:
-        poses, qb = getattr(t, "target_poses", None), getattr(t, "target_q_batch", None)
-        if poses is not None and poses.shape[0] != B or qb is not None and qb.shape[0] != B:
-            raise PinkError(f"{type(t).__name__}: per-instance targets for {(poses if poses is not None else qb).shape[0]} instances, batch of {B}")
-        for b in range(B):
-            c = t
-            if poses is not None:
-                c = copy.copy(t)
-                c.target_poses = None
-                c.transform_target_to_world = SE3(poses[b, :9].reshape(3, 3).copy(), poses[b, 9:].copy())
-            elif qb is not None:
-                c = copy.copy(t)
-                c.target_q_batch = None
-                c.target_q = qb[b].copy()
-            out[b].append(c)
-    return out
-
-
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, bars = plan
+    model, q, specs, T, posture, bars, limit_gain = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, bars
+    return model, q[lo:hi], specs, T, posture, bars, limit_gain
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
@@ -547,32 +657,66 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
                             "and no barriers other than PositionBarriers (default class-K function) on the task frames")
     if plan is not None:
         from .batch_solver import BatchResult
+        from .rollout import NoWholeStepKernel
 
-        if pool is not None:
-            from .sharding import shard_bounds
+        try:
+            if pool is not None:
+                from .sharding import shard_bounds
 
-            bounds = [shard_bounds(len(configurations), r, len(pool)) for r in range(len(pool))]
-            parts = solver_handle.map(lambda r, api: _solve_on_device(_slice_plan(plan, *bounds[r]), dt, damping, safety_break, api, max_iter)
-                                      if bounds[r][1] > bounds[r][0] else None)
-            parts = [p for p in parts if p is not None]
-            dq, status, iters = (np.concatenate([p[k] for p in parts]) for k in range(3))
+                bounds = [shard_bounds(len(configurations), r, len(pool)) for r in range(len(pool))]
+                parts = solver_handle.map(lambda r, api: _solve_on_device(_slice_plan(plan, *bounds[r]), dt, damping, safety_break, api, max_iter)
+                                          if bounds[r][1] > bounds[r][0] else None)
+                parts = [p for p in parts if p is not None]
+                dq, status, iters, path = (np.concatenate([p[k] for p in parts]) for k in range(4))
+            else:
+                dq, status, iters, path = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter)
+        except NoWholeStepKernel:
+            # no instantiation of the whole-step kernel holds this model's rows (more barrier rows / joints than the
+            # tables of dispatch.h carry): the host-evaluated path below serves it, unless the caller insisted
+            if device_kinematics:
+                raise
+            plan = None
         else:
-            dq, status, iters = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter)
-        if status.any():
-            result = BatchResult(dq, status, iters)
-            raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
-        return np.divide(dq, dt, out=dq)  # v = dq / dt (pink/solve_ik.py:274), in place: dq is this call's own array
-    tasks = _expand_batched_targets(tasks, len(configurations))
-    if hasattr(configurations, "check_limits"):
+            result = BatchResult(dq, status, iters, path)
+            _record_stats(result, "device")
+            if status.any():
+                raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
+            return np.divide(dq, dt, out=dq)  # v = dq / dt (pink/solve_ik.py:274), in place: dq is this call's own array
+    B = len(configurations)
+    if B and hasattr(configurations, "check_limits"):
         configurations.check_limits(safety_break=safety_break)
-        configurations = list(configurations)
-    else:
-        for cfg in configurations:
-            cfg.check_limits(safety_break=safety_break)
+    elif B:
+        from .configuration import ConfigurationBatch
+
+        model = configurations[0].model
+        if hasattr(model, "joints") and all(c.model is model for c in configurations):  # (one vectorised check, solve_ik.py:260)
+            ConfigurationBatch(model, np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])).check_limits(safety_break=safety_break)
+        else:
+            for cfg in configurations:
+                cfg.check_limits(safety_break=safety_break)
     api = solver_handle or default_solver()
     batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, pool[0] if pool else solver_handle,
                                 gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)), constraints=constraints)
     result = api.solve(batch, max_iter=max_iter)
+    _record_stats(result, "host-evaluated")
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])
     return result.dq / dt
+
+
+_LAST_STATS: dict = {}
+
+
+def _record_stats(result, route: str) -> None:
+    _LAST_STATS.clear()
+    _LAST_STATS.update(route=route, instances=int(result.status.shape[0]), failed=int((result.status != 0).sum()),
+                       iters_mean=float(result.iters.mean()) if result.iters.size else 0.0,
+                       paths=result.path_fractions())
+
+
+def last_solve_stats() -> dict:
+    """What the last :func:`solve_ik_batch` call of this process did: ``route`` (``"device"``: kinematics, rows and QP
+    formed on the device from ``q``; ``"host-evaluated"``: tasks / limits / barriers evaluated on the host, QP on the
+    device), ``instances``, ``failed``, ``iters_mean`` and ``paths`` -- the share of the batch per solver path
+    (:meth:`pink_amd.batch_solver.BatchResult.path_fractions`; ``handover`` is the share that paid for both solvers)."""
+    return dict(_LAST_STATS)

@@ -38,6 +38,12 @@ CONFIGS: Dict[str, dict] = {
     "jvrc": dict(config_id=4, nv=50, root_nv=6, dt=5e-3,
                  frame_costs=[(1.0, 3.0), (1.0, 0.0), (1.0, 3.0), (1.0, 3.0)], frame_lm=0.0,
                  posture_cost=1e-1, n_barriers=2),
+    # examples/humanoid_jvrc.py:69-81,112-114 AS IT IS: four FrameTasks (lm_damping 0, the pelvis without orientation
+    # cost), NO posture task, damping = 1e-12 -- 21 weighted rows on 50 coordinates: H is positive definite through
+    # `damping` alone (pink/solve_ik.py:55), cond(H) ~ 1e13.  The weakly regularised regime.
+    "jvrc_noposture": dict(config_id=6, nv=50, root_nv=6, dt=5e-3,
+                           frame_costs=[(1.0, 3.0), (1.0, 0.0), (1.0, 3.0), (1.0, 3.0)], frame_lm=0.0,
+                           posture_cost=None, n_barriers=0),
 }
 
 
@@ -146,6 +152,8 @@ def make_terms(
     n_act = nv - root_nv
     e_post = error_scale * rng.uniform(-1.0, 1.0, size=(B, n_act)) * (1.0 if name == "ur5" else 0.5)
     diag = [DiagonalTaskTerm(col0=root_nv, e=e_post, cost=cfg["posture_cost"], gain=1.0, lm_damping=0.0)]
+    if cfg["posture_cost"] is None:
+        diag = []
 
     idx = root_nv + np.arange(n_act)
     if bounds == "tight":

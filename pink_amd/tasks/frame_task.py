@@ -45,7 +45,10 @@ class FrameTask(Task):
         return self.cost[3:6]
 
     def set_target(self, transform_target_to_world: SE3) -> None:
+        """One target for every configuration the task is evaluated at (``frame_task.py:129-137``); replaces per-instance
+        targets set earlier (one target source is live at a time)."""
         self.transform_target_to_world = transform_target_to_world.copy()
+        self.target_poses = None
 
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.get_transform_frame_to_world(self.frame))
@@ -59,6 +62,7 @@ class FrameTask(Task):
         if R.ndim != 3 or R.shape[1:] != (3, 3) or t.shape != (R.shape[0], 3):
             raise TaskDefinitionError(f"rotations [B, 3, 3] and translations [B, 3] expected, got {R.shape} and {t.shape}")
         self.target_poses = np.ascontiguousarray(np.concatenate([R.reshape(-1, 9), t], axis=1))
+        self.transform_target_to_world = None  # (replaces a single target set earlier)
 
     def compute_error(self, configuration) -> np.ndarray:
         """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``

@@ -33,6 +33,7 @@ class PostureTask(_ActuatedIdentityTask):
 
     def set_target(self, target_q: np.ndarray) -> None:
         self.target_q = np.array(target_q, dtype=float)
+        self.target_q_batch = None  # (one target source is live at a time)
 
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.q)
@@ -41,6 +42,7 @@ class PostureTask(_ActuatedIdentityTask):
         """One reference posture per instance of a batch, ``[B, nq]`` (for ``solve_ik_batch`` on a
         :class:`pink_amd.ConfigurationBatch`)."""
         self.target_q_batch = np.ascontiguousarray(target_q, dtype=np.float64)
+        self.target_q = None
 
     def compute_error(self, configuration) -> np.ndarray:
         """``q (-) q*`` on the actuated coordinates (``posture_task.py:100-107``; the code,

@@ -45,7 +45,7 @@ class EmuSolver:
 
     def solve(self, batch, max_iter=0):
         from pink_amd._lib import PackedArgs, Result
-        from pink_amd.batch_solver import BatchResult
+        from pink_amd.batch_solver import BatchResult, split_iters
 
         a = PackedArgs(batch, max_iter)
         dq = np.zeros((batch.B, batch.nv))
@@ -57,7 +57,7 @@ class EmuSolver:
         rc = self.lib.pinkhip_emu_solve_host(ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r))
         if rc != 0:
             raise RuntimeError(self.lib.pinkhip_emu_last_error().decode())
-        return BatchResult(dq, st, it)
+        return BatchResult(dq, st, it, split_iters(it))
 
     def frame_task_terms(self, T_frame, T_target, J_body):
         Tf = np.ascontiguousarray(T_frame, dtype=np.float64).reshape(-1, 12)

@@ -296,9 +296,34 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
             cond = np.linalg.cond(ref["H"][ok])
             xmax = np.abs(ref["dq"][ok]).max(axis=1)
             err = np.abs(out.dq[ok] - ref["dq"][ok]).max(axis=1)
-            assert (err <= np.maximum(TOL_DQ, 100 * np.finfo(float).eps * cond * xmax)).all(), (sd, err.max())
+            within = err <= np.maximum(TOL_DQ, 100 * np.finfo(float).eps * cond * xmax)
+            # An instance beyond that tolerance is not waved through: along the flat directions of a weakly regularised
+            # H two correct solvers may differ by more than cond(H) eps |x|, but then the point must CERTIFY itself --
+            # KKT residuals of the QP as stated and an objective no worse than the oracle's -- or the draw fails.
+            for k in np.nonzero(~within)[0]:
+                b = int(np.nonzero(ok)[0][k])
+                certify_point(ref["H"][b], ref["c"][b], G[b, neq:], h[b, neq:], out.dq[b], ref["dq"][b],
+                              A[b] if neq else None, bv[b] if neq else None, tag=(sd, b, float(err[k])))
+                CERTIFIED.append((sd, b, float(err[k]), float(cond[k])))
             n_checked += int(ok.sum())
     return n_checked
+
+
+CERTIFIED = []  # (seed, instance, |dq - dq_ref|, cond(H)) of the draws accepted on their certificate instead of on dq
+
+
+def certify_point(P, q, G, h, x, x_ref, A=None, b=None, tag=None):
+    """``x`` is the minimiser of  min 1/2 x'Px + q'x, Gx <= h, Ax = b  as far as fp64 can tell: primal feasible to
+    1e-9 (1 + |h|), stationary with non-negative multipliers to 1e-9 (|q| + |P| |x|), and an objective not above the
+    oracle's by more than 1e-12 (1 + |f|).  Independent of how far x is from x_ref."""
+    stat, viol, _ = po.kkt_residuals(P, q, G, h, x, A=A, b=b)
+    scale = max(1.0, float(np.abs(q).max()), float(np.abs(P).max() * np.abs(x).max()))
+    f = lambda v: 0.5 * v @ P @ v + q @ v  # noqa: E731
+    gap = (f(x) - f(x_ref)) / (1.0 + abs(f(x_ref)))
+    hf = np.abs(h)[np.abs(h) < 1e29]  # (rows  x_i <= 1e30  stand for missing bounds)
+    assert viol <= 1e-9 * (1.0 + float(hf.max(initial=0.0))), ("violation", tag, viol)
+    assert stat <= 1e-9 * scale, ("stationarity", tag, stat, scale)
+    assert gap <= 1e-12, ("objective above the oracle's", tag, gap)
 
 
 def kkt_certificate(solver, seeds):

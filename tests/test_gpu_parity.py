@@ -67,28 +67,19 @@ def test_fuzz(gpu_solver):
     assert ps.fuzz(gpu_solver, range(7000, 7400)) > 1000
 
 
-def _ill_fuzz(solver, seeds):
-    """Weakly regularised draws (posture cost down to 1e-5: cond(H) up to ~1e11), one by one: returns the draws whose
-    statuses differ from the oracle's and those whose dq is beyond 100 eps cond(H) max|x|."""
-    status, accuracy = [], []
-    for sd in seeds:
-        try:
-            ps.fuzz(solver, [sd], ill=True)
-        except AssertionError as exc:
-            (status if "array" in str(exc) else accuracy).append(sd)
-    return status, accuracy
-
-
 @pytest.mark.parametrize("kernel", ["sweep", "packed"])
 def test_fuzz_weakly_regularised(gpu_solver, kernel, monkeypatch):
     """The regime where the explicitly updated inverse of the sweep tableau loses its accuracy (DESIGN.md 3.1 "What an
-    explicit inverse cannot do"): its results are certified or handed over to the Goldfarb-Idnani code, verdicts
-    included -- statuses equal the oracle's on every draw, and dq is within the conditioning's tolerance on all but a
-    few per thousand (flat directions at cond(H) ~ 1e10: objective values equal to 1e-15)."""
+    explicit inverse cannot do"): its results are certified, handed over or routed to the Goldfarb-Idnani code, verdicts
+    included.  ZERO uncertified draws: statuses equal the oracle's on every draw, and every instance is either within
+    100 eps cond(H) max|x| of the oracle's dq or -- flat directions at cond(H) ~ 1e10 -- passes the KKT + objective
+    certificate of parity_suite.certify_point (computed here, on the QP as stated); anything else fails the test.
+    The range holds seed 415035 (off by 1.3e-6 on both kernels in round 3's wide fuzz)."""
     monkeypatch.setenv("PINKHIP_SOLVER", kernel)
-    status, accuracy = _ill_fuzz(gpu_solver, range(200001, 204001, 2))
-    assert not status, status
-    assert len(accuracy) <= 6, accuracy
+    del ps.CERTIFIED[:]
+    n = ps.fuzz(gpu_solver, list(range(200001, 204001, 2)) + [415035], ill=True)
+    assert n > 5000
+    print(f"{kernel}: {n} feasible instances, {len(ps.CERTIFIED)} accepted on their KKT / objective certificate: {ps.CERTIFIED[:8]}")
 
 
 def test_fuzz_wide(gpu_solver):
@@ -177,6 +168,37 @@ def test_full_size_properties(gpu_solver, name, B, kw):
         setattr(sub_batch, f, np.ascontiguousarray(getattr(batch, f)[perm]))
     out3 = s.solve(sub_batch)
     assert np.array_equal(out3.dq, out.dq[perm])
+
+
+@pytest.mark.parametrize("kw", [dict(bounds="tight", jacobians="dense"), dict(bounds="kinematic", jacobians="kinematic", error_scale=0.05)],
+                         ids=["tight", "tracking"])
+def test_full_size_weakly_regularised(gpu_solver, kw):
+    """examples/humanoid_jvrc.py:69-81,112-114 as it is -- nv = 50, four FrameTasks, NO posture task, damping = 1e-12
+     -- at B = 65 536: cond(H) ~ 1e13-1e14, so dq is determined to cond(H) eps only along the
+    21 weighted directions' complement and the north-star 1e-8 on dq is not a property two correct solvers can share.
+    Every instance is held to what IS determined: statuses equal to the oracle's, KKT residuals of the QP as stated,
+    an objective not above the oracle's, and dq on the weighted rows (W J dq: what the tasks see).  Every instance must
+    take the `routed` path: the conditioning estimate sends it to the Goldfarb-Idnani code before the tableau iterates."""
+    from oracle.parity_report import parity_report
+    from pink_amd import synthetic
+
+    s, B = gpu_solver, 65536
+    terms = synthetic.make_terms("jvrc_noposture", B, **kw)
+    batch = synthetic.pack(terms)
+    out = s.solve(batch)
+    assert (out.status == 0).all()
+    fr = out.path_fractions()
+    assert fr["routed"] == 1.0 and fr["handover"] == 0.0, fr
+    rep = parity_report(lambda lo, hi: synthetic.pink_form(terms.slice(lo, hi)), batch, out.dq, out.status)
+    assert rep["instances_compared"] == B and rep["status_mismatch"] == 0, rep
+    assert rep["kkt_stationarity_max"] < 1e-9 and rep["kkt_violation_max"] < 1e-11 and rep["kkt_multiplier_sign_max"] < 1e-8, rep
+    assert rep["objective_gap_rel_max"] <= 1e-12, rep
+    # what the tasks see: the weighted task rows of the step, against the oracle's
+    n = 4096
+    ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms.slice(0, n)), nthreads=16)
+    Jw = batch.J[:n] * batch.cost[None, :batch.Kd, None]
+    d_task = np.abs(np.einsum("bkj,bj->bk", Jw, out.dq[:n] - ref["dq"])).max()
+    assert d_task < 1e-8, d_task
 
 
 def test_rccl_gather_single_rank(gpu_solver):

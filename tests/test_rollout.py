@@ -465,3 +465,25 @@ def test_device_path_against_host_path_on_random_robots(api, request):
         assert note in (None, "same failure"), (sd, note)
         assert err <= 1e-8, (sd, err)
         pink_amd.clear_device_cache()
+
+
+def test_hand_over_with_barrier_rows_reads_the_frame_positions_it_needs(api):
+    """Round 3's open item: the whole-step kernel reported "inconsistent" on one or two
+    of 6 000 random robots where the host-evaluated path solves -- seeds 24680 and 14626 of scripts/gpu_fuzz_rollout.py
+    (cond(H) = 2e13: no posture task, a PositionBarrier row at dt = 1e-3).  Cause: a group handed over to the
+    Goldfarb-Idnani code formed the barrier rows from the frame positions the kinematics left in LDS while its own staged
+    copy of those rows already overlaid them (12 joints + 3 frames, nv = 12: Gs starts inside frame 0's pose), so the
+    right-hand side of the barrier row read back an entry of G.  The positions now live behind the shared area
+    (dispatch.h: rollout_tail_doubles).  Reproduced on the emulator once the conditioning estimate routed the instance
+    to that code."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_fuzz_rollout as fz
+
+    for sd in (24680, 14626):
+        note, err = fz.one(sd)
+        assert note is None, (sd, note)
+        assert err <= 1e-8, (sd, err)
+        pink_amd.clear_device_cache()

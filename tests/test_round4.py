@@ -1,0 +1,233 @@
+"""Round 4: the host-evaluated route of solve_ik_batch for every task / limit / barrier class the package ships
+(vectorised over the batch) against Pink's calling pattern -- one solve_ik per configuration (pink/solve_ik.py:206-275);
+which solver path an instance took (include/pinkhip.h PINKHIP_PATH_*); explicit default limits on the device route;
+the regressions the round-3 advisor reproduced.  Emulator here, MI355X under -m gpu."""
+import numpy as np
+import pytest
+
+import pink_amd
+from pink_amd import (Configuration, ConfigurationBatch, DampingTask, FrameTask, PostureTask, build_chain, solve_ik,
+                      solve_ik_batch)
+from pink_amd.barriers import BodySphericalBarrier, PositionBarrier
+from pink_amd.batch import DenseTaskTerm, DiagonalTaskTerm, pack_terms
+from pink_amd.lie import SE3, exp6
+from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+from pink_amd.runtime import set_default_solver
+from pink_amd.tasks import JointCouplingTask, JointVelocityTask, LowAccelerationTask, RelativeFrameTask
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    s = request.getfixturevalue("emu" if request.param == "emu" else "gpu_solver")
+    set_default_solver(s)
+    yield request.param
+    pink_amd.clear_device_cache()
+    set_default_solver(None)
+
+
+def _draw_q(m, B, rng, spread=0.8):
+    q = np.tile(m.neutral(), (B, 1))
+    for j in m.joints:
+        if j.kind == "free_flyer":
+            from pink_amd.configuration import _rot_to_quat
+
+            for b in range(B):
+                M = exp6(0.4 * rng.normal(size=6))
+                q[b, j.idx_q:j.idx_q + 3], q[b, j.idx_q + 3:j.idx_q + 7] = M.translation, _rot_to_quat(M.rotation)
+        else:
+            q[:, j.idx_q] = rng.uniform(-spread, spread, size=B)
+    return q
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_host_evaluated_stacks_equal_one_solve_ik_per_configuration(backend, free_flyer):
+    """Task stacks the device-resident route does not form on chip -- RelativeFrameTask, DampingTask, LowAccelerationTask,
+    JointVelocityTask, JointCouplingTask next to FrameTask + PostureTask; an explicit limit list with an AccelerationLimit;
+    a BodySphericalBarrier next to a PositionBarrier; an equality constraint -- as ONE batched call (ConfigurationBatch
+    and list of Configuration objects) against Pink's loop: one solve_ik per configuration."""
+    m = build_chain(8, free_flyer=free_flyer, seed=7, limit=2.6, velocity=4.0)
+    m.add_frame("mid", m.getJointId("joint_4"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    rng = np.random.default_rng(11)
+    B, dt = 70, 5e-3  # (>= 64: the automatic choice of route is exercised too)
+    q = _draw_q(m, B, rng)
+    j5, j6 = (m.joints[m.getJointId(n)].idx_q for n in ("joint_5", "joint_6"))
+    q[:, j6] = -2.0 * q[:, j5] + 0.002 * rng.normal(size=B)  # (the equality below is then within reach of one step)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    ft = FrameTask("tool0", 1.0, 0.6, lm_damping=1e-3)
+    rt = RelativeFrameTask("tool0", "mid", 0.8, 0.2, lm_damping=1e-3, gain=0.8)
+    R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    for b, c in enumerate(cfgs):
+        T = c.get_transform_frame_to_world("tool0") * exp6(0.05 * rng.normal(size=6))
+        R[b], t[b] = T.rotation, T.translation
+    ft.set_target_poses(R, t)
+    rt.set_target(cfgs[0].get_transform("tool0", "mid") * exp6(0.05 * rng.normal(size=6)))
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    la = LowAccelerationTask(cost=0.05)
+    la.set_last_integration(0.2 * rng.normal(size=m.nv), dt)
+    jv = JointVelocityTask(cost=0.05)
+    jv.set_target(0.3 * rng.normal(size=m.nv - (6 if free_flyer else 0)), dt)
+    jc = JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 2.0, cfgs[0])
+    eq = JointCouplingTask(["joint_5", "joint_6"], [1.0, 0.5], 1.0, cfgs[0])
+    tasks = [ft, rt, po, DampingTask(cost=1e-2), la, jv, jc]
+    acc = AccelerationLimit(m, np.r_[np.full(6 if free_flyer else 0, np.inf), np.full(8, 400.0)])
+    limits = [ConfigurationLimit(m, 0.6), VelocityLimit(m), acc]
+    p_tool = np.array([c.get_transform_frame_to_world("tool0").translation for c in cfgs])
+    bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[:, 2].max() + 0.02]), gain=np.array([50.0]), safe_displacement_gain=1.0),
+            BodySphericalBarrier(("tool0", "joint_2"), d_min=0.02, gain=10.0)]
+    kw = dict(limits=limits, barriers=bars, constraints=[eq])
+    V_arr = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt, **kw)
+    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+    V_list = solve_ik_batch(cfgs, tasks, dt, **kw)
+    V_np = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt, gpu_frame_tasks=False, **kw)
+    assert np.array_equal(V_arr, V_list) and np.abs(V_arr - V_np).max() < 1e-9 * max(1.0, np.abs(V_np).max())
+    n = 12 if backend == "emu" else B
+    for b in range(n):
+        fb = FrameTask("tool0", 1.0, 0.6, lm_damping=1e-3)
+        fb.set_target(SE3(R[b], t[b]))
+        v = solve_ik(cfgs[b], [fb] + tasks[1:], dt, **kw)
+        assert np.abs(V_arr[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
+    assert np.abs(V_arr).max() > 1e-3
+
+
+def test_explicit_default_limits_take_the_device_route(backend):
+    """limits=[ConfigurationLimit(model, gain), VelocityLimit(model)] is what limits=None installs (pink/solve_ik.py:94-105):
+    the device kernels form both from the model tables -- same velocities as the host-evaluated route, the limit's own
+    gain honoured; a list that is NOT the defaults (one limit missing, another velocity vector) stays host-evaluated."""
+    m = build_chain(7, seed=2, limit=1.2, velocity=50.0)
+    rng = np.random.default_rng(3)
+    B, dt = 66, 1e-2
+    q = _draw_q(m, B, rng, spread=1.15)  # close to the joint limits: the configuration limit binds
+    ft = FrameTask("tool0", 1.0, 0.3, lm_damping=1e-2)
+    ft.set_target(Configuration(m, q[0]).get_transform_frame_to_world("tool0") * exp6(0.5 * rng.normal(size=6)))
+    po = PostureTask(cost=1e-2)
+    po.set_target(m.neutral())
+    batch = ConfigurationBatch(m, q)
+    for gain in (0.5, 0.9):
+        lim = [ConfigurationLimit(m, gain), VelocityLimit(m)]
+        V_dev = solve_ik_batch(batch, [ft, po], dt, limits=lim)
+        assert pink_amd.last_solve_stats()["route"] == "device"
+        V_host = solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=False)
+        assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+        assert np.abs(V_dev - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
+    V_none = solve_ik_batch(batch, [ft, po], dt)
+    V_half = solve_ik_batch(batch, [ft, po], dt, limits=[ConfigurationLimit(m, 0.5), VelocityLimit(m)])
+    assert np.array_equal(V_none, V_half)
+    assert np.abs(V_none - V_dev).max() > 1e-6  # (the gain matters on this batch)
+    for lim in ([ConfigurationLimit(m)], [ConfigurationLimit(m), VelocityLimit(m, np.full(m.nv, 0.7))]):
+        solve_ik_batch(batch, [ft, po], dt, limits=lim)
+        assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+        with pytest.raises(pink_amd.PinkError):
+            solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=True)
+
+
+def test_one_target_source_is_live_and_both_routes_agree(backend):
+    """Round-3 advisor: set_target_from_configuration followed by set_target_poses -- the device route used the single
+    target, the host route the per-instance ones (max |dv| = 475).  The setters now replace each other, and a list of
+    Configuration objects with shared tasks follows the same rules as the array form."""
+    m = build_chain(6, seed=1)
+    rng = np.random.default_rng(8)
+    B, dt = 65, 5e-3
+    q = _draw_q(m, B, rng)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    ft = FrameTask("tool0", 1.0, 1.0, lm_damping=1e-2)
+    ft.set_target_from_configuration(cfgs[0])
+    R = np.array([c.get_transform_frame_to_world("tool0").rotation for c in cfgs])
+    t = np.array([c.get_transform_frame_to_world("tool0").translation for c in cfgs]) + 0.05 * rng.normal(size=(B, 3))
+    ft.set_target_poses(R, t)
+    assert ft.transform_target_to_world is None
+    po = PostureTask(cost=1e-2)
+    po.set_target_from_configuration(cfgs[0])
+    po.set_target_batch(q + 0.1 * rng.normal(size=q.shape))
+    assert po.target_q is None
+    V = {(src, dev): solve_ik_batch(cfgs if src == "list" else ConfigurationBatch(m, q), [ft, po], dt, device_kinematics=dev)
+         for src in ("list", "array") for dev in (True, False)}
+    ref = V["array", False]
+    for key, v in V.items():
+        assert np.abs(v - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), key
+    ft.set_target(cfgs[0].get_transform_frame_to_world("tool0"))
+    assert ft.target_poses is None
+    po.set_target(q[0])
+    assert po.target_q_batch is None
+
+
+def test_auto_route_falls_back_when_no_whole_step_kernel_fits(backend):
+    """Round-3 advisor: a 9-dof arm with three PositionBarriers on p_min and p_max (18 rows) at B = 64 raised in auto
+    mode (no whole-step instantiation holds 18 barrier rows at nv = 9) while device_kinematics=False solved it."""
+    m = build_chain(9, seed=4)
+    rng = np.random.default_rng(5)
+    B, dt = 64, 5e-3
+    q = _draw_q(m, B, rng, spread=0.5)
+    frames = ["tool0", "joint_6", "joint_3"]
+    tasks = []
+    for f in frames:
+        ft = FrameTask(f, 1.0, 0.0, lm_damping=1e-2)
+        ft.set_target(Configuration(m, q[0]).get_transform_frame_to_world(f))
+        tasks.append(ft)
+    po = PostureTask(cost=1e-2)
+    po.set_target(m.neutral())
+    bars = [PositionBarrier(f, p_min=np.full(3, -5.0), p_max=np.full(3, 5.0), gain=np.full(6, 10.0)) for f in frames]
+    batch = ConfigurationBatch(m, q)
+    V_auto = solve_ik_batch(batch, tasks + [po], dt, barriers=bars)
+    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+    V_host = solve_ik_batch(batch, tasks + [po], dt, barriers=bars, device_kinematics=False)
+    assert np.array_equal(V_auto, V_host)
+    with pytest.raises(pink_amd.PinkError):
+        solve_ik_batch(batch, tasks + [po], dt, barriers=bars, device_kinematics=True)
+
+
+def test_configuration_batch_on_a_model_that_never_built_a_configuration(backend):
+    """Round-3 advisor: the array route read model.configuration_limit, which only Configuration.__init__ attached."""
+    m = build_chain(6, seed=9)
+    assert not hasattr(m, "configuration_limit")
+    q = _draw_q(m, 64, np.random.default_rng(1))
+    ft = FrameTask("tool0", 1.0, 1.0, lm_damping=1e-2)
+    ft.set_target(SE3(np.eye(3), [0.3, 0.1, 0.4]))
+    for dev in (True, False, None):
+        v = solve_ik_batch(ConfigurationBatch(m, q), [ft], 5e-3, device_kinematics=dev)
+        assert v.shape == (64, 6) and np.isfinite(v).all()
+
+
+def test_a_model_edit_is_not_served_from_the_cached_device_state(backend):
+    """Round-3 advisor (low): the cache key held id(model) only; joint limits edited between two calls were ignored."""
+    m = build_chain(6, seed=3, limit=2.0, velocity=80.0)
+    q = _draw_q(m, 64, np.random.default_rng(2), spread=1.0)
+    ft = FrameTask("tool0", 1.0, 1.0, lm_damping=1e-2)
+    ft.set_target(SE3(np.eye(3), [0.5, 0.2, 0.3]))
+    batch = ConfigurationBatch(m, q)
+    v1 = solve_ik_batch(batch, [ft], 1e-2, device_kinematics=True)
+    m._upper = [1.05] * m.nq  # tighter upper limits: the configuration-limit rows change
+    v2 = solve_ik_batch(batch, [ft], 1e-2, device_kinematics=True)
+    v2_host = solve_ik_batch(batch, [ft], 1e-2, device_kinematics=False)
+    assert np.abs(v2 - v2_host).max() < 1e-8 * max(1.0, np.abs(v2_host).max())
+    assert np.abs(v1 - v2).max() > 1e-6
+
+
+def _solver_of(backend, request):
+    return request.getfixturevalue("emu" if backend == "emu" else "gpu_solver")
+
+
+def test_solver_path_is_reported_per_instance(backend, request, monkeypatch):
+    """iters[b] carries the code that solved the instance (PINKHIP_ITERS_PATH): the sweep tableau on a well conditioned
+    batch, `routed` where `damping` alone makes H positive definite (no posture task: examples/humanoid_jvrc.py:69-81),
+    the Goldfarb-Idnani kernel when it is forced; the iteration counts stay what they were."""
+    s = _solver_of(backend, request)
+    rng = np.random.default_rng(4)
+    nv, B = 12, 6
+    J = rng.normal(0, 0.5, size=(B, 6, nv))
+    e = 0.1 * rng.normal(size=(B, 6))
+    box = [(-0.05 * np.ones((B, nv)), 0.05 * np.ones((B, nv)))]
+    good = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0), DiagonalTaskTerm(col0=0, e=0.1 * rng.normal(size=(B, nv)), cost=0.1)],
+                      5e-3, 1e-12, boxes=box, batch_size=B)
+    weak = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0)], 5e-3, 1e-12, boxes=box, batch_size=B)
+    r = s.solve(good)
+    assert (r.status == 0).all() and (r.path == 0).all() and r.iters.max() < 100 and r.path_fractions()["tableau"] == 1.0
+    rw = s.solve(weak)
+    assert (rw.status == 0).all() and (rw.path == 2).all() and rw.iters.max() < 200
+    assert rw.path_fractions() == {"tableau": 0.0, "handover": 0.0, "routed": 1.0, "goldfarb_idnani": 0.0}
+    monkeypatch.setenv("PINKHIP_SOLVER", "packed")
+    rp = s.solve(good)
+    assert (rp.path == 3).all() and np.abs(rp.dq - r.dq).max() < 1e-10
+    rwp = s.solve(weak)
+    # the routed instances ran the same Goldfarb-Idnani code on the same stacked problem
+    assert np.abs(rwp.dq - rw.dq).max() < 1e-9 * max(1.0, np.abs(rw.dq).max())
