@@ -201,6 +201,16 @@ def full_parity(terms, batch, res) -> dict:
     rep = parity_report(lambda lo, hi: synthetic.pink_form(terms.slice(lo, hi)), batch, res.dq, res.status,
                         nthreads=min(usable_cores(), 64))
     rep["max_abs_dq_err_vs_oracle"] = rep["max_abs_err"]
+    # what the tasks see: the weighted rows of the dense tasks, W J (dq - dq_ref), on a sample -- the quantity that stays
+    # within the tolerance where dq itself is only weakly determined (flat directions of a weakly regularised H)
+    from oracle import c_oracle
+
+    n = min(batch.B, 4096)
+    ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms.slice(0, n)), nthreads=min(usable_cores(), 64))
+    okk = (ref["status"] == 0) & (res.status[:n] == 0)
+    cost = batch.cost[:n, :batch.Kd] if batch.cost.ndim == 2 else batch.cost[None, :batch.Kd]
+    rep["max_abs_weighted_task_row_err_on_sample"] = float(np.abs(np.einsum("bkj,bj->bk", batch.J[:n] * cost[:, :, None], res.dq[:n] - ref["dq"]))[okk].max(initial=0.0))
+    rep["task_row_sample"] = n
     rep["tolerance"] = 1e-8
     rep["checker_seconds"] = time.perf_counter() - t0
     rep["note"] = "oracle = restated Goldfarb-Idnani; QP half parity-unpinned against quadprog (DESIGN.md 4)"
