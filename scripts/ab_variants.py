@@ -42,7 +42,8 @@ def main():
         r = s.download(dev)
         err = float(np.abs(r.dq[:n] - ref["dq"]).max())
         print(f"{os.path.basename(path):28s} min {min(ms):.4f} ms  median {statistics.median(ms):.4f} ms  "
-              f"{B / min(ms) / 1e3:.1f} M/s  iters {r.iters.mean():.2f}  failed {(r.status != 0).sum()}  err {err:.2e}", flush=True)
+              f"{B / min(ms) / 1e3:.1f} M/s  iters {r.iters.mean():.2f}  failed {(r.status != 0).sum()}  err {err:.2e}  "
+              f"paths {' '.join(f'{k}={v:.3f}' for k, v in r.path_fractions().items() if v)}", flush=True)
         dev.free()
         s.close()
 
