@@ -312,6 +312,8 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
                "max_abs_velocity_difference": float(np.abs(v_dev - v_host).max())}
         out["host_evaluated_tasks"] = api_level_host_evaluated(m, B)
         out["headline_shape_arrays"] = api_level_arrays(Bh)
+        if hasattr(solver, "pinned_empty"):
+            out["headline_shape_arrays_page_locked"] = api_level_arrays(Bh, pinned=True)
         out["headline_shape_host_evaluated"] = api_level_arrays(Bh, extra_task="damping")
         return out
     finally:
@@ -362,7 +364,7 @@ def api_level_host_evaluated(m, B: int) -> dict:
             "max_abs_velocity_difference_vs_per_configuration_solve_ik_on_sample": float(np.abs(v[:n] - np.array(v_ref)).max()), "sample": n}
 
 
-def api_level_arrays(B: int, extra_task: str = "") -> dict:
+def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False) -> dict:
     """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
     with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
     array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
@@ -370,10 +372,16 @@ def api_level_arrays(B: int, extra_task: str = "") -> dict:
     from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
     from pink_amd.lie import SE3
 
+    import pink_amd
+
     m = build_chain(24, free_flyer=True, seed=2)
     frames = ["tool0", "joint_8", "joint_16", "joint_20"]
     rng = np.random.default_rng(1)
-    q = np.tile(m.neutral(), (B, 1))
+    # pinned: q, the per-frame target arrays and the output live in page-locked memory (pink_amd.pinned_empty), the way a
+    # control loop that refills them in place would hold them
+    alloc = pink_amd.pinned_empty if pinned else (lambda shape: np.empty(shape))
+    q = alloc((B, m.nq))
+    q[:] = m.neutral()
     for j in m.joints:
         if j.kind != "free_flyer":
             q[:, j.idx_q] = rng.uniform(-0.8, 0.8, size=B)
@@ -383,7 +391,7 @@ def api_level_arrays(B: int, extra_task: str = "") -> dict:
         t = FrameTask(f, 1.0, 1.0 if k == 0 else 0.0, lm_damping=1e-3)
         T0 = ref.get_transform_frame_to_world(f)
         # every robot's target: the reference robot's frame pose displaced by a few centimetres
-        t.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)))
+        t.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=alloc((B, 12)))
         tasks.append(t)
     post = PostureTask(cost=1e-1)
     post.set_target(m.neutral())
@@ -394,11 +402,10 @@ def api_level_arrays(B: int, extra_task: str = "") -> dict:
         tasks.append(DampingTask(cost=1e-2))
     cfgs = ConfigurationBatch(m, q)
     dt = 5e-3
-    import pink_amd
-
-    v = solve_ik_batch(cfgs, tasks, dt)  # builds the device state
+    v_out = alloc((B, m.nv)) if pinned else None
+    v = solve_ik_batch(cfgs, tasks, dt, out=v_out)  # builds the device state
     stats = pink_amd.last_solve_stats()
-    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt), 5 if not extra_task else 2)
+    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, out=v_out), 5 if not extra_task else 2)
     t_call = statistics.median(ts)
     n = min(B, 16)
     v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False)

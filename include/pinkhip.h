@@ -163,6 +163,12 @@ int pinkhip_get_device_info(const pinkhip_handle *h, pinkhip_device_info *info);
  */
 int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_problem *host_in,
                        const pinkhip_result *host_out);
+/* Device time of the solve kernel(s) of the LAST pinkhip_solve_host call on this handle, in ms: from the start of the
+ * first to the end of the last launch on the compute stream (a batch sent in several chunks: the waits for the uploads
+ * in between included) -- next to the caller's own clock around the call this is the kernel-only / end-to-end breakdown
+ * a batch sharded over several handles reports per device.  -1 when the call was not timed (batches
+ * that go through the small-batch staging buffer). */
+int pinkhip_last_kernel_ms(pinkhip_handle *h, float *ms);
 /* Device variant: enqueue on the handle's stream; pointers stay owned by the
  * caller and must remain valid until pinkhip_sync(). */
 int pinkhip_solve_device(pinkhip_handle *h, const pinkhip_desc *desc,
@@ -362,6 +368,17 @@ int pinkhip_memcpy_h2d(pinkhip_handle *h, void *dst, const void *src, int64_t by
  * source has been consumed and the data is on the device: a kernel launched afterwards sees it.  The caller keeps the
  * destination disjoint from what enqueued kernels still read or write. */
 int pinkhip_memcpy_h2d_overlapped(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+/* Fully asynchronous pieces of a pipelined call (a batch cut into ranges: upload of range c + 1, kernels of range c and
+ * the results of range c - 1 going home all in flight at once -- PCIe is full duplex):
+ *   pinkhip_memcpy_h2d_async    enqueue on the COPY stream and return (page-locked source -- pinkhip_host_alloc --: true
+ *                               DMA, the source must stay untouched until pinkhip_sync; pageable source: the runtime
+ *                               stages it before returning, correct but not overlapped)
+ *   pinkhip_stream_wait_copies  what is enqueued on the compute stream from now on starts after the copies enqueued so far
+ *   pinkhip_memcpy_d2h_async    enqueue on the RESULT stream, ordered after the kernels enqueued so far, and return
+ *   pinkhip_sync                waits for all three streams */
+int pinkhip_memcpy_h2d_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
+int pinkhip_stream_wait_copies(pinkhip_handle *h);
+int pinkhip_memcpy_d2h_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes); /* stream-ordered, asynchronous */
 int pinkhip_sync(pinkhip_handle *h);

@@ -12,11 +12,11 @@ from .batch_solver import BatchResult, BatchSolver
 from .configuration import Configuration, ConfigurationBatch, Model, build_chain, load_urdf
 from .exceptions import NoSolutionFound, NotWithinConfigurationLimits, PinkError, TargetNotSet
 from .sharding import MultiDeviceSolver
-from .solve_ik import build_ik, clear_device_cache, last_solve_stats, pack_configurations, solve_ik, solve_ik_batch
+from .solve_ik import build_ik, clear_device_cache, last_solve_stats, pack_configurations, pinned_empty, solve_ik, solve_ik_batch
 from .tasks import DampingTask, FrameTask, PostureTask, Task
 
 __all__ = [
     "BatchResult", "BatchSolver", "Configuration", "ConfigurationBatch", "DampingTask", "FrameTask", "IKBatch", "Model", "MultiDeviceSolver", "NoSolutionFound",
     "NotWithinConfigurationLimits", "PinkError", "PostureTask", "TargetNotSet", "Task", "build_chain", "build_ik", "clear_device_cache",
-    "last_solve_stats", "load_urdf", "pack_configurations", "pack_terms", "solve_ik", "solve_ik_batch",
+    "last_solve_stats", "load_urdf", "pack_configurations", "pinned_empty", "pack_terms", "solve_ik", "solve_ik_batch",
 ]

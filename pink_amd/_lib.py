@@ -116,7 +116,7 @@ class RolloutStep(ctypes.Structure):
 # every symbol include/pinkhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "pinkhip_version", "pinkhip_device_count", "pinkhip_create", "pinkhip_destroy",
-    "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_solve_device",
+    "pinkhip_last_error", "pinkhip_get_device_info", "pinkhip_solve_host", "pinkhip_last_kernel_ms", "pinkhip_solve_device",
     "pinkhip_stack_host", "pinkhip_stack_device", "pinkhip_frame_task_host", "pinkhip_frame_task_device",
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
     "pinkhip_fk_frame_tasks_device", "pinkhip_step_device", "pinkhip_rollout_step_device",
@@ -124,7 +124,8 @@ ABI_SYMBOLS = (
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_host_alloc", "pinkhip_host_free", "pinkhip_malloc", "pinkhip_free",
-    "pinkhip_memcpy_h2d", "pinkhip_memcpy_h2d_overlapped", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
+    "pinkhip_memcpy_h2d", "pinkhip_memcpy_h2d_overlapped", "pinkhip_memcpy_h2d_async", "pinkhip_stream_wait_copies",
+    "pinkhip_memcpy_d2h_async", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
     "pinkhip_timer_stop",
 )
 
@@ -152,6 +153,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_get_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
     for name in ("pinkhip_solve_host", "pinkhip_solve_device"):
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)]
+    lib.pinkhip_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     for name in ("pinkhip_stack_host", "pinkhip_stack_device"):
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(Desc), ctypes.POINTER(Problem), vp, vp]
     for name in ("pinkhip_frame_task_host", "pinkhip_frame_task_device"):
@@ -181,6 +183,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_h2d_overlapped.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_memcpy_h2d_async.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_memcpy_d2h_async.argtypes = [vp, vp, vp, ctypes.c_int64]
+    lib.pinkhip_stream_wait_copies.argtypes = [vp]
     lib.pinkhip_memcpy_d2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_sync.argtypes = [vp]
     lib.pinkhip_timer_start.argtypes = [vp]

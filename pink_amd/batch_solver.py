@@ -183,6 +183,9 @@ class BatchSolver:
         r.dq, r.status, r.iters = dq.ctypes.data, status.ctypes.data, iters.ctypes.data
         p = a.host_problem()
         self._check(self._lib.pinkhip_solve_host(self._h, ctypes.byref(a.desc), ctypes.byref(p), ctypes.byref(r)))
+        ms = ctypes.c_float(-1.0)
+        self._check(self._lib.pinkhip_last_kernel_ms(self._h, ctypes.byref(ms)))
+        self.last_kernel_ms = float(ms.value) if ms.value >= 0.0 else None  # (device time of this call's solve kernels)
         return BatchResult(dq, status, iters, split_iters(iters))
 
     def pinned_result(self, B: int, nv: int) -> BatchResult:
@@ -303,6 +306,25 @@ class BatchSolver:
         enqueued, which keep running while the bytes move."""
         arr = np.ascontiguousarray(arr)
         self._check(self._lib.pinkhip_memcpy_h2d_overlapped(self._h, ctypes.c_void_p(ptr), arr.ctypes.data, arr.nbytes))
+
+    def put_async(self, ptr: int, arr: np.ndarray) -> None:
+        """Enqueue an upload on the copy stream and return (``pinkhip_memcpy_h2d_async``).  ``arr`` must be C-contiguous
+        and stay untouched until :meth:`sync`; from page-locked memory (:meth:`pinned_empty`) it is a DMA the host does
+        not wait for."""
+        if not arr.flags.c_contiguous:
+            raise ValueError("put_async needs a C-contiguous array")
+        self._check(self._lib.pinkhip_memcpy_h2d_async(self._h, ctypes.c_void_p(ptr), arr.ctypes.data, arr.nbytes))
+
+    def wait_copies(self) -> None:
+        """Kernels enqueued from now on start after the uploads enqueued so far (``pinkhip_stream_wait_copies``)."""
+        self._check(self._lib.pinkhip_stream_wait_copies(self._h))
+
+    def get_async(self, arr: np.ndarray, ptr: int) -> None:
+        """Enqueue a download ordered after the kernels enqueued so far and return (``pinkhip_memcpy_d2h_async``);
+        ``arr`` is valid after :meth:`sync`."""
+        if not arr.flags.c_contiguous or not arr.flags.writeable:
+            raise ValueError("get_async needs a C-contiguous, writable array")
+        self._check(self._lib.pinkhip_memcpy_d2h_async(self._h, arr.ctypes.data, ctypes.c_void_p(ptr), arr.nbytes))
 
     def get(self, arr: np.ndarray, ptr: int) -> None:
         self._d2h(arr, ptr)

@@ -82,7 +82,7 @@ inline bool prefer_sweep(int nv, int md, long long B) {
 
 // Doubles of LDS per QP of the sweep-tableau kernel (= SweepLds<NV, MD, W>::stride, checked at compile time in
 // tu_sweep.hip): H packed, c, the columns of G.
-constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + 2 * W + MD * W; }
+constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + 2 * W + MD * (W + 2); }
 
 // Doubles of LDS per QP of the Goldfarb-Idnani kernel (= LdsP<NV>::stride(md), checked at compile time in
 // tu_rollout.hip): the sweep-tableau kernels hand a group over to it when its result fails the certificate.

@@ -89,4 +89,19 @@ inline std::string build_tables(const pinkhip_desc &d, HostTables &t) {
   return std::string();
 }
 
+// A task stack that cannot make H positive definite by itself: fewer task rows than tangent coordinates, no
+// Levenberg-Marquardt term (task.py:160), no barrier regulariser (barrier.py:193-200) -- H = J^T W^2 J + damping I is
+// then positive definite through `damping` alone (pink/solve_ik.py:55; examples/humanoid_jvrc.py:69-81 with the default
+// 1e-12: cond(H) ~ 1e13).  The explicitly updated inverse of the sweep tableau has nothing to offer there (its
+// conditioning estimate would route every instance to the Goldfarb-Idnani code after stacking and sweeping in vain):
+// such a batch goes to that kernel by dispatch.
+inline bool rank_deficient_by_construction(const pinkhip_desc &d) {
+  if (!(d.K < d.nv) || !(d.damping <= 1e-9)) return false;
+  for (int t = 0; t < d.T; ++t)
+    if (d.lm_damping[t] != 0.0) return false;
+  for (int b = 0; b < d.n_barriers; ++b)
+    if (d.barrier_safe_gain[b] > 1e-6) return false;
+  return true;
+}
+
 }  // namespace pinkhip

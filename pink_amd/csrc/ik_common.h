@@ -101,6 +101,7 @@ struct KernelArgs {
   int cost_batched;
   int max_iter;
   int lds_pitch;     // doubles of LDS per QP (0: LdsP<NV>::stride(md)); the whole-step kernel may need more for its kinematics
+  int rank_deficient;  // host_tables.h rank_deficient_by_construction(): the Goldfarb-Idnani code by dispatch
   double damping, dt;
   // per-instance streams
   const double *J, *e, *cost, *lb, *ub, *Gd, *hd, *c_extra;

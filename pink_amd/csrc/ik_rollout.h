@@ -134,11 +134,18 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
       wave_sync();
     }
   };
+  // A task stack that is rank deficient by construction (host_tables.h: FrameTasks alone on more coordinates than they
+  // have rows, examples/humanoid_jvrc.py:69-81) goes to the Goldfarb-Idnani code right away (kernel argument:
+  // wave-uniform; its kinematics pass is the one below); everything else through the sweep tableau.
+  const bool direct = a.k.rank_deficient != 0;
   FkTerms<W> t = make_terms(a);
-  ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
-  wave_sync();
-  keep_frame_positions(a);
-  const int st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+  int st_sweep = STATUS_ROUTED;
+  if (!direct) {
+    ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
+    wave_sync();
+    keep_frame_positions(a);
+    st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+  }
   // a result that fails its KKT certificate is not integrated: the Goldfarb-Idnani code solves that robot's QP again
   // (ik_sweep.h, ik_solve_sweep_body).  It forms the rows from the kinematics like the tableau did, and the tableau's
   // parking area has overwritten the kinematics scratch meanwhile: the kinematics run once more (wave-uniform, rare).
@@ -151,7 +158,8 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     ik_fk_instance<W, true, true, FkTerms<W>>(again->fk, block, &t2, sm);
     wave_sync();
     keep_frame_positions(*again);
-    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, over, st_sweep == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER);
+    ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, over,
+                                                     again->k.rank_deficient ? PATH_GI : (st_sweep == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER));
     if (over) t.x = t2.x, t.status = t2.status;
   }
   // integration: lane = joint fetches its dq entries from the lanes that hold them (lane = tangent coordinate)

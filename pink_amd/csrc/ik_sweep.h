@@ -74,8 +74,12 @@ template <int NV, int MD, int W>
 struct SweepLds {
   static __host__ __device__ constexpr int tri(int i) { return i * (i + 1) / 2; }  // H[i][0..i]
   static constexpr int oC = (NV * (NV + 1) / 2 + 1) & ~1;                            // c, one entry per lane
-  static constexpr int oG = oC + W;                                                  // G[d][li] at d W + li
-  static constexpr int oR = oG + MD * W;                                             // one row of T in transit (W entries)
+  // G[d][li] at d GP + li.  The pitch is W + 2, not W: the lane of dense row d reads its row G[d][.] while the products
+  // with the stated problem run (krow_times), all dense lanes at the same column -- at a pitch of W = 64 doubles every
+  // one of those reads fell into the same LDS bank (profiles/sq_counters_jvrc_r03.txt: 7.1 M address conflicts)
+  static constexpr int GP = W + 2;
+  static constexpr int oG = oC + W;
+  static constexpr int oR = oG + MD * GP;                                            // one row of T in transit (W entries)
   static constexpr int stride = oR + W;
 };
 
@@ -190,7 +194,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   if constexpr (DENSE) {
     static_for<0, MD>([&](auto Dc) {
       constexpr int d = decltype(Dc)::value;
-      sm[SL::oG + d * W + li] = (li < NV) ? T[NV + d] : 0.0;
+      sm[SL::oG + d * SL::GP + li] = (li < NV) ? T[NV + d] : 0.0;
     });
   }
   PINKHIP_TICK(0);  // stacking
@@ -308,7 +312,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // coordinate lanes parked)
   auto krow_times = [&](double v) -> double {
     const BcT vb = bcast_prepare<W>(v);
-    const int base = (li < NV) ? SL::tri(li) : SL::oG + (dlane ? dr : 0) * W;
+    const int base = (li < NV) ? SL::tri(li) : SL::oG + (dlane ? dr : 0) * SL::GP;
     double h0 = 0.0, h1 = 0.0;
     static_for<0, NV>([&](auto Jc) {
       constexpr int j = decltype(Jc)::value;
@@ -338,7 +342,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         double gl = 0.0;
         static_for<0, MD>([&](auto Dc) {
           constexpr int d = decltype(Dc)::value;
-          gl = fma_bcast<W, NV + d>(gl, lamb, sm[SL::oG + d * W + li]);
+          gl = fma_bcast<W, NV + d>(gl, lamb, sm[SL::oG + d * SL::GP + li]);
         });
         if (in) grad += gl;
       }

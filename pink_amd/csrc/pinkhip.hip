@@ -43,8 +43,12 @@ struct pinkhip_handle {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of the chunked *_host path (overlaps the kernels on `stream`)
+  hipStream_t d2h_stream = nullptr;   // results going home while later kernels run (pinkhip_memcpy_d2h_async)
+  hipEvent_t ev_copy = nullptr, ev_kernels = nullptr;  // copy stream -> compute stream, compute stream -> d2h stream
   std::vector<hipEvent_t> chunk_events;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evk0 = nullptr, evk1 = nullptr;  // around the solve kernel(s) of the last pinkhip_solve_host call
+  bool evk_valid = false;
   std::string err;
   char *d_tables = nullptr;          // device copy of the broadcast tables
   std::vector<char> h_tables;        // what d_tables currently holds
@@ -122,7 +126,8 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   // (ik_kernels_packed.h, tu_packed.hip) the rest: 8-lane groups (nv <= 8), more dense rows than lanes are left.
   const char *solver_env = std::getenv("PINKHIP_SOLVER");  // development / tests: "packed" / "sweep" force one kernel
   const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
-  const bool sweep = solver_env ? (std::strcmp(solver_env, "packed") != 0 && sc.NV != 0) : pinkhip::prefer_sweep(a.nv, a.md, a.B);
+  const bool sweep = solver_env ? (std::strcmp(solver_env, "packed") != 0 && sc.NV != 0)
+                                : (pinkhip::prefer_sweep(a.nv, a.md, a.B) && !a.rank_deficient);
   if (sweep) {
     hipError_t es = hipErrorInvalidValue;
     switch (sc.NV * 100 + sc.MD) {
@@ -160,6 +165,7 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   pinkhip::HostTables t;
   const std::string why = pinkhip::build_tables(*d, t);
   if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
+  a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
   PH_HIP(h, hipSetDevice(h->device));
 
   // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
@@ -321,8 +327,13 @@ int pinkhip_create(pinkhip_handle **out, int device_id) {
   }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_kernels, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e == hipSuccess) e = hipEventCreate(&h->evk0);
+  if (e == hipSuccess) e = hipEventCreate(&h->evk1);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_tables), kTableBytes);
   if (e != hipSuccess) {
     const std::string msg = std::string("pinkhip_create: ") + hipGetErrorString(e);
@@ -343,7 +354,12 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->evk0) (void)hipEventDestroy(h->evk0);
+  if (h->evk1) (void)hipEventDestroy(h->evk1);
   for (hipEvent_t ev : h->chunk_events) (void)hipEventDestroy(ev);
+  if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
+  if (h->ev_kernels) (void)hipEventDestroy(h->ev_kernels);
+  if (h->d2h_stream) (void)hipStreamDestroy(h->d2h_stream);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -452,6 +468,7 @@ int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
     a.dq = reinterpret_cast<double *>(dbase + p.out_off);
     a.status = reinterpret_cast<int *>(dbase + p.out_off + n_dq);
     a.iters = reinterpret_cast<int *>(dbase + p.out_off + n_dq + n_st);
+    h->evk_valid = false;  // (the point of this path is to spare API calls: not timed)
     if ((rc = launch(h, a, true))) return rc;
     PH_HIP(h, hipStreamSynchronize(h->stream));
     const char *o = h->stage + p.out_off;
@@ -507,12 +524,24 @@ int pinkhip_solve_host(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhi
     ac.dq = d_dq + c0 * nv;
     ac.status = d_st + c0;
     ac.iters = d_it + c0;
+    if (c == 0) PH_HIP(h, hipEventRecord(h->evk0, h->stream));
     if ((rc = launch(h, ac, true))) return rc;
+    if (c + 1 == n_chunks) PH_HIP(h, hipEventRecord(h->evk1, h->stream));
     PH_HIP(h, hipMemcpyAsync(host_out->dq + c0 * nv, ac.dq, 8 * cb * nv, hipMemcpyDeviceToHost, h->stream));
     PH_HIP(h, hipMemcpyAsync(host_out->status + c0, ac.status, 4 * cb, hipMemcpyDeviceToHost, h->stream));
     if (host_out->iters) PH_HIP(h, hipMemcpyAsync(host_out->iters + c0, ac.iters, 4 * cb, hipMemcpyDeviceToHost, h->stream));
   }
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  h->evk_valid = true;
+  return PINKHIP_OK;
+}
+
+int pinkhip_last_kernel_ms(pinkhip_handle *h, float *ms) {
+  if (!h || !ms) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  *ms = -1.0f;
+  if (!h->evk_valid) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipEventElapsedTime(ms, h->evk0, h->evk1));
   return PINKHIP_OK;
 }
 
@@ -1083,7 +1112,35 @@ int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t by
 int pinkhip_sync(pinkhip_handle *h) {
   if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
   PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipStreamSynchronize(h->copy_stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  PH_HIP(h, hipStreamSynchronize(h->d2h_stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_memcpy_h2d_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice, h->copy_stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_stream_wait_copies(pinkhip_handle *h) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipEventRecord(h->ev_copy, h->copy_stream));
+  PH_HIP(h, hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+  return PINKHIP_OK;
+}
+
+int pinkhip_memcpy_d2h_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, PINKHIP_E_INVALID, "bad argument");
+  if (bytes == 0) return PINKHIP_OK;
+  PH_HIP(h, hipSetDevice(h->device));
+  PH_HIP(h, hipEventRecord(h->ev_kernels, h->stream));
+  PH_HIP(h, hipStreamWaitEvent(h->d2h_stream, h->ev_kernels, 0));
+  PH_HIP(h, hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, h->d2h_stream));
   return PINKHIP_OK;
 }
 

@@ -114,25 +114,34 @@ class BatchKinematics:
 
     def _jacobian_at(self, Rf: np.ndarray, pf: np.ndarray, joint: int, rotate: bool) -> np.ndarray:
         """``[B, 6, nv]`` Jacobian of the point ``pf`` / frame carried by ``joint``: columns in the world's axes, or
-        (``rotate``) in the axes ``Rf`` of the frame (= the body Jacobian, ``pin.LOCAL``)."""
+        (``rotate``) in the axes ``Rf`` of the frame (= the body Jacobian, ``pin.LOCAL``).  All ancestors of one kind
+        are formed at once (one cross product / one rotation for the whole chain)."""
         m, B = self.model, self.B
         J = np.zeros((B, 6, m.nv))
         aw = self._axes_world()
-        for a in self._chain(joint):
+        chain = self._chain(joint)
+        rev = [a for a in chain if m.joints[a].kind == "revolute"]
+        pri = [a for a in chain if m.joints[a].kind == "prismatic"]
+        rot = (lambda v: v @ Rf) if rotate else (lambda v: v)  # rows v_i -> (Rf^T v_i)^T
+        if rev:
+            cols = [m.joints[a].idx_v for a in rev]
+            ang = aw[:, rev]  # [B, n, 3]
+            lin = np.cross(ang, pf[:, None, :] - self.p[:, rev])  # omega x (p_f - p_a)
+            J[:, :3, cols] = np.swapaxes(rot(lin), 1, 2)
+            J[:, 3:, cols] = np.swapaxes(rot(ang), 1, 2)
+        if pri:
+            cols = [m.joints[a].idx_v for a in pri]
+            J[:, :3, cols] = np.swapaxes(rot(aw[:, pri]), 1, 2)
+        for a in chain:
             jt = m.joints[a]
-            if jt.kind == "revolute":
-                J[:, 3:, jt.idx_v] = aw[:, a]
-                J[:, :3, jt.idx_v] = np.cross(aw[:, a], pf - self.p[:, a])  # omega x (p_f - p_a)
-            elif jt.kind == "prismatic":
-                J[:, :3, jt.idx_v] = aw[:, a]
-            else:  # the free flyer's tangent is its body twist: world columns are [R_a, [p_a - p_f]x R_a; 0, R_a]
+            if jt.kind == "free_flyer":
+                # the free flyer's tangent is its body twist: world columns are [R_a, [p_a - p_f]x R_a; 0, R_a]
                 Ra = self.R[:, a]
-                J[:, :3, jt.idx_v:jt.idx_v + 3] = Ra
-                J[:, 3:, jt.idx_v + 3:jt.idx_v + 6] = Ra
-                J[:, :3, jt.idx_v + 3:jt.idx_v + 6] = lb.hat(self.p[:, a] - pf) @ Ra
-        if rotate:
-            Rt = np.swapaxes(Rf, 1, 2)
-            J = np.concatenate([Rt @ J[:, :3], Rt @ J[:, 3:]], axis=1)
+                Rt = np.swapaxes(Rf, 1, 2) if rotate else None
+                top = lb.hat(self.p[:, a] - pf) @ Ra
+                J[:, :3, jt.idx_v:jt.idx_v + 3] = Rt @ Ra if rotate else Ra
+                J[:, 3:, jt.idx_v + 3:jt.idx_v + 6] = Rt @ Ra if rotate else Ra
+                J[:, :3, jt.idx_v + 3:jt.idx_v + 6] = Rt @ top if rotate else top
         return J
 
     # -- pink/configuration.py:203-236 ------------------------------------------------------------------

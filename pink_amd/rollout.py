@@ -323,6 +323,7 @@ class DeviceRollout:
         """Enqueue one IK step for every robot (asynchronous).  ``integrate=False`` only solves (dq, status and
         iteration counts of ``last_step`` are those of the current configurations, which stay as they are)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
+        self._pipelined = None
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             if self.md:
                 raise NoWholeStepKernel("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
@@ -364,12 +365,15 @@ class DeviceRollout:
         self.steps_done += 1
 
     def solve_pipelined(self, q0: np.ndarray, targets: Sequence[np.ndarray], q_posture: Optional[np.ndarray] = None,
-                        safety_break: bool = True, n_chunks: int = 4) -> bool:
+                        safety_break: bool = True, n_chunks: int = 4, out: Optional[np.ndarray] = None) -> bool:
         """One differential-IK solve of new configurations ``q0`` (no integration), the batch cut into ``n_chunks``
-        ranges whose uploads (``q`` and one ``[B, 12]`` target array per frame task, on the copy stream) overlap the
-        whole-step kernel of the previous range.  Results through :meth:`last_step`.  ``False`` -- nothing enqueued --
-        when the whole-step kernel does not serve this model or the solver has no copy stream."""
-        a, B, nq, nf = self.api, self.B, self.nq, len(self.frames)
+        ranges: the upload of one range (``q`` and one ``[B, 12]`` target array per frame task, copy stream), the
+        whole-step kernel of the previous one (compute stream) and the results of the one before going home (result
+        stream) are in flight together; nothing blocks the host until the closing synchronisation when the arrays are
+        page-locked (``pink_amd.pinned_empty``; pageable arrays are staged by the runtime: correct, less overlap).
+        ``out [B, nv]`` receives ``dq``.  Results through :meth:`last_step`.  ``False`` -- nothing enqueued -- when the
+        whole-step kernel does not serve this model or the solver has no copy stream."""
+        a, B, nq, nv, nf = self.api, self.B, self.nq, self.nv, len(self.frames)
         if self.fused != "kernel" or not hasattr(a, "put_overlapped") or len(targets) != nf or B < n_chunks:
             return False
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
@@ -382,16 +386,34 @@ class DeviceRollout:
         self.steps_done, self._pending, self.targets_per_frame = 0, False, True
         from .sharding import shard_bounds
 
+        asyn = hasattr(a, "put_async")
+        put = a.put_async if asyn else a.put_overlapped
+        res = None
+        if asyn:
+            if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
+                raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
+            if getattr(self, "_h_status", None) is None:  # page-locked landing buffers of the small result arrays
+                self._h_status, self._h_iters = a.pinned_empty((B,), np.int32), a.pinned_empty((B,), np.int32)
+            res = (out if out is not None else np.empty((B, nv)), self._h_status, self._h_iters)
         for c in range(n_chunks):
             lo, hi = shard_bounds(B, c, n_chunks)
-            a.put_overlapped(self.d_q + 8 * nq * lo, q0[lo:hi])
+            put(self.d_q + 8 * nq * lo, q0[lo:hi])
             for f, t in enumerate(tg):
-                a.put_overlapped(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
+                put(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
+            if asyn:
+                a.wait_copies()
             if not self._one_kernel_step(False, lo, hi):
                 if c:
                     raise RuntimeError("whole-step kernel refused a later range of the same batch")
+                if asyn:
+                    a.sync()
                 return False
+            if asyn:
+                a.get_async(res[0][lo:hi], self.d_dq + 8 * nv * lo)
+                a.get_async(res[1][lo:hi], self.d_status + 4 * lo)
+                a.get_async(res[2][lo:hi], self.d_iters + 4 * lo)
         self.steps_done = 1
+        self._pipelined = res
         # Configuration.check_limits on the whole batch (pink/solve_ik.py:260), after the fact: the velocities of a
         # batch that violates its limits are never handed out
         self._check_limits_device(q0, safety_break)
@@ -494,6 +516,13 @@ class DeviceRollout:
         ``pink_amd.batch_solver.PATH_NAMES``) is kept as ``self.last_path``."""
         from .batch_solver import split_iters
 
+        res = getattr(self, "_pipelined", None)
+        if res is not None:  # the results of a pipelined solve are on their way (or here): wait, hand them out once
+            self._pipelined = None
+            self.api.sync()
+            it = res[2].copy()
+            self.last_path = split_iters(it)
+            return res[0], res[1].copy(), it
         dq = np.empty((self.B, self.nv))
         st = np.empty(self.B, np.int32)
         it = np.empty(self.B, np.int32)

@@ -567,7 +567,7 @@ def _model_fingerprint(model, frames) -> int:
     return hash(b"".join(parts))
 
 
-def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
+def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     """FK, task rows, limits and the QP for the whole batch in device kernels (one launch where the whole-step
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
@@ -594,7 +594,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter):
         # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
         qp = None if posture is None else posture[3]
         if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and not bars and ro.md == 0
-                and ro.solve_pipelined(q, T, qp, safety_break)):
+                and ro.solve_pipelined(q, T, qp, safety_break, out=out)):
             if not fresh:
                 ro.reset(q, qp, safety_break)
             ro.set_targets(T)
@@ -620,7 +620,8 @@ def _slice_plan(plan, lo, hi):
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
                    limits=None, barriers=None, constraints=None, safety_break: bool = True, solver_handle=None,
-                   device_kinematics: Optional[bool] = None, device_ids: Optional[Sequence[int]] = None, **kwargs) -> np.ndarray:
+                   device_kinematics: Optional[bool] = None, device_ids: Optional[Sequence[int]] = None,
+                   out: Optional[np.ndarray] = None, **kwargs) -> np.ndarray:
     """Batched ``solve_ik``: velocities ``[B, nv]`` for ``B`` configurations.
 
     ``configurations`` is a list of :class:`Configuration` objects or a :class:`ConfigurationBatch` (one array
@@ -634,6 +635,10 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     forward kinematics, task errors / Jacobians and limits can be evaluated by the device kernels from ``q`` alone
     instead of per configuration on the host (``None``: do so for batches of 64 and more; ``True``: require it).
     Device buffers of the last few call shapes are kept (:func:`clear_device_cache`).
+
+    ``out``: a ``[B, nv]`` float64 array that receives the velocities (like NumPy's ``out=``).  Allocated through
+    :func:`pink_amd.pinned_empty` (page-locked), together with ``q`` and the per-instance target arrays, the device
+    route moves every byte of the call by DMA while the kernels of the neighbouring ranges run.
 
     ``device_ids``: shard the batch contiguously over these GPUs from this one process (one handle, stream and staging
     area per device, a thread each): no collective, results concatenated on the host.
@@ -669,7 +674,8 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
                 parts = [p for p in parts if p is not None]
                 dq, status, iters, path = (np.concatenate([p[k] for p in parts]) for k in range(4))
             else:
-                dq, status, iters, path = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter)
+                dq, status, iters, path = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter,
+                                                           out=out if out is not None and out.shape == (len(configurations), plan[0].nv) else None)
         except NoWholeStepKernel:
             # no instantiation of the whole-step kernel holds this model's rows (more barrier rows / joints than the
             # tables of dispatch.h carry): the host-evaluated path below serves it, unless the caller insisted
@@ -681,6 +687,8 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             _record_stats(result, "device")
             if status.any():
                 raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
+            if out is not None and dq is not out:
+                return np.divide(dq, dt, out=out)
             return np.divide(dq, dt, out=dq)  # v = dq / dt (pink/solve_ik.py:274), in place: dq is this call's own array
     B = len(configurations)
     if B and hasattr(configurations, "check_limits"):
@@ -701,7 +709,17 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     _record_stats(result, "host-evaluated")
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])
-    return result.dq / dt
+    return np.divide(result.dq, dt, out=out) if out is not None else result.dq / dt
+
+
+def pinned_empty(shape, dtype=np.float64, solver_handle=None) -> np.ndarray:
+    """Uninitialised array in page-locked host memory of the (default) solver's device (``pinkhip_host_alloc``): arrays
+    a caller fills in place and hands to :func:`solve_ik_batch` -- ``ConfigurationBatch(model, q)``,
+    ``FrameTask.set_target_poses(..., out=)``, ``out=`` -- then move by DMA at the PCIe rate, overlapped with the
+    kernels, instead of being staged by the runtime."""
+    from .runtime import default_solver
+
+    return (solver_handle or default_solver()).pinned_empty(shape, dtype)
 
 
 _LAST_STATS: dict = {}

@@ -53,15 +53,23 @@ class FrameTask(Task):
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.get_transform_frame_to_world(self.frame))
 
-    def set_target_poses(self, rotations: np.ndarray, translations: np.ndarray) -> None:
+    def set_target_poses(self, rotations: np.ndarray, translations: np.ndarray, out: Optional[np.ndarray] = None) -> None:
         """One target per instance of a batch, as arrays: ``rotations [B, 3, 3]``, ``translations [B, 3]``
         (target frame to world).  Used by :func:`pink_amd.solve_ik_batch` with a
-        :class:`pink_amd.ConfigurationBatch`; instance ``b`` then plays ``set_target(SE3(R[b], p[b]))``."""
+        :class:`pink_amd.ConfigurationBatch`; instance ``b`` then plays ``set_target(SE3(R[b], p[b]))``.
+        ``out [B, 12]`` (e.g. from :func:`pink_amd.pinned_empty`) receives the packed poses and is kept as the task's
+        target array: a control loop refills it in place."""
         R = np.asarray(rotations, dtype=np.float64)
         t = np.asarray(translations, dtype=np.float64)
         if R.ndim != 3 or R.shape[1:] != (3, 3) or t.shape != (R.shape[0], 3):
             raise TaskDefinitionError(f"rotations [B, 3, 3] and translations [B, 3] expected, got {R.shape} and {t.shape}")
-        self.target_poses = np.ascontiguousarray(np.concatenate([R.reshape(-1, 9), t], axis=1))
+        if out is None:
+            out = np.empty((R.shape[0], 12))
+        elif out.shape != (R.shape[0], 12) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise TaskDefinitionError(f"out must be a C-contiguous float64 array of shape {(R.shape[0], 12)}")
+        out[:, :9] = R.reshape(-1, 9)
+        out[:, 9:] = t
+        self.target_poses = out
         self.transform_target_to_world = None  # (replaces a single target set earlier)
 
     def compute_error(self, configuration) -> np.ndarray:

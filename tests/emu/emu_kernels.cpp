@@ -113,7 +113,8 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   } else {  // the dispatch rule of the library (dispatch.h, pinkhip.hip launch())
     const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
     const char *force = std::getenv("PINKHIP_SOLVER");  // "packed" / "sweep": one kernel for every problem it serves
-    const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : pinkhip::prefer_sweep(a.nv, a.md, d->B);
+    a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
+    const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : (pinkhip::prefer_sweep(a.nv, a.md, d->B) && !a.rank_deficient);
     if (sweep) {
       switch (sc.NV * 100 + sc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
@@ -278,6 +279,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   a.max_iter = d->max_iter;
   a.damping = d->damping;
   a.dt = d->dt;
+  a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;  // (as prepare() of pinkhip.hip)
   a.cost = st->cost;
   a.row_gain = t.row_gain.data();
   a.row_lm = t.row_lm.data();

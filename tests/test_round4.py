@@ -209,8 +209,10 @@ def _solver_of(backend, request):
 
 def test_solver_path_is_reported_per_instance(backend, request, monkeypatch):
     """iters[b] carries the code that solved the instance (PINKHIP_ITERS_PATH): the sweep tableau on a well conditioned
-    batch, `routed` where `damping` alone makes H positive definite (no posture task: examples/humanoid_jvrc.py:69-81),
-    the Goldfarb-Idnani kernel when it is forced; the iteration counts stay what they were."""
+    batch; the Goldfarb-Idnani kernel by dispatch where the stack is rank deficient by construction (fewer task rows
+    than coordinates, no LM term: examples/humanoid_jvrc.py:69-81) or when it is forced; `routed` where the stack has
+    rows enough but `damping` alone makes H positive definite (a posture task of cost 1e-7); the iteration counts stay
+    what they were."""
     s = _solver_of(backend, request)
     rng = np.random.default_rng(4)
     nv, B = 12, 6
@@ -219,9 +221,13 @@ def test_solver_path_is_reported_per_instance(backend, request, monkeypatch):
     box = [(-0.05 * np.ones((B, nv)), 0.05 * np.ones((B, nv)))]
     good = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0), DiagonalTaskTerm(col0=0, e=0.1 * rng.normal(size=(B, nv)), cost=0.1)],
                       5e-3, 1e-12, boxes=box, batch_size=B)
-    weak = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0)], 5e-3, 1e-12, boxes=box, batch_size=B)
+    deficient = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0)], 5e-3, 1e-12, boxes=box, batch_size=B)
+    weak = pack_terms(nv, [DenseTaskTerm(J=J, e=e, cost=1.0), DiagonalTaskTerm(col0=0, e=0.1 * rng.normal(size=(B, nv)), cost=1e-7)],
+                      5e-3, 1e-12, boxes=box, batch_size=B)
     r = s.solve(good)
     assert (r.status == 0).all() and (r.path == 0).all() and r.iters.max() < 100 and r.path_fractions()["tableau"] == 1.0
+    rd = s.solve(deficient)
+    assert (rd.status == 0).all() and (rd.path == 3).all()
     rw = s.solve(weak)
     assert (rw.status == 0).all() and (rw.path == 2).all() and rw.iters.max() < 200
     assert rw.path_fractions() == {"tableau": 0.0, "handover": 0.0, "routed": 1.0, "goldfarb_idnani": 0.0}
