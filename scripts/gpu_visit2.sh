@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, second visit: GPU tests, the bench line, A/B of the two solve kernels
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/gputest.txt 2>&1; tail -5 gpurun_out/gputest.txt
+timeout 700 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err
+bash scripts/ab_solvers.sh > gpurun_out/ab_solvers.txt 2>&1; grep "jvrc\|draco3b" gpurun_out/ab_solvers.txt
