@@ -235,8 +235,21 @@ class BatchSolver:
         lib, h, addr = self._lib, self._h, p.value
         import weakref
 
-        weakref.finalize(buf, lambda: h.value is not None and lib.pinkhip_host_free(h, ctypes.c_void_p(addr)))
+        ranges = self.__dict__.setdefault("_pinned_ranges", {})
+        ranges[addr] = nbytes
+
+        def release():
+            ranges.pop(addr, None)
+            if h.value is not None:
+                lib.pinkhip_host_free(h, ctypes.c_void_p(addr))
+
+        weakref.finalize(buf, release)
         return arr
+
+    def is_pinned(self, arr: np.ndarray) -> bool:
+        """``arr`` lies inside a block handed out by :meth:`pinned_empty` (copies to / from it are asynchronous DMA)."""
+        a = arr.ctypes.data
+        return any(base <= a and a + arr.nbytes <= base + n for base, n in self.__dict__.get("_pinned_ranges", {}).items())
 
     def pin(self, batch: IKBatch) -> IKBatch:
         """Copy of ``batch`` whose per-instance streams live in page-locked memory (for repeated ``solve`` calls

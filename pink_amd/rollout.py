@@ -386,15 +386,20 @@ class DeviceRollout:
         self.steps_done, self._pending, self.targets_per_frame = 0, False, True
         from .sharding import shard_bounds
 
-        asyn = hasattr(a, "put_async")
+        if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
+            raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
+        # Fully asynchronous ranges need page-locked memory on both ends: a pageable source is staged by the runtime
+        # before the call returns (no harm), a pageable destination makes the download wait for its kernel on the host
+        # thread -- the uploads of the next range would queue behind it.  Without a page-locked `out` the results come
+        # home in one piece at the end, as before.
+        asyn = hasattr(a, "put_async") and hasattr(a, "is_pinned") and a.is_pinned(q0)
+        back = asyn and out is not None and a.is_pinned(out)
         put = a.put_async if asyn else a.put_overlapped
         res = None
-        if asyn:
-            if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
-                raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
+        if back:
             if getattr(self, "_h_status", None) is None:  # page-locked landing buffers of the small result arrays
                 self._h_status, self._h_iters = a.pinned_empty((B,), np.int32), a.pinned_empty((B,), np.int32)
-            res = (out if out is not None else np.empty((B, nv)), self._h_status, self._h_iters)
+            res = (out, self._h_status, self._h_iters)
         for c in range(n_chunks):
             lo, hi = shard_bounds(B, c, n_chunks)
             put(self.d_q + 8 * nq * lo, q0[lo:hi])
@@ -408,7 +413,7 @@ class DeviceRollout:
                 if asyn:
                     a.sync()
                 return False
-            if asyn:
+            if back:
                 a.get_async(res[0][lo:hi], self.d_dq + 8 * nv * lo)
                 a.get_async(res[1][lo:hi], self.d_status + 4 * lo)
                 a.get_async(res[2][lo:hi], self.d_iters + 4 * lo)
