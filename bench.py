@@ -439,6 +439,7 @@ def closed_loop_figures(solver, B: int) -> dict:
 
     out = {}
     for label, model, frames, nbar in (("nv30_4frames_posture", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"], 0),
+                                       ("nv30_4frames_posture_2barriers", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"], 2),
                                        ("jvrc_shape_nv50_4frames_posture_2barriers", build_chain(44, free_flyer=True, seed=4), ["tool0", "joint_10", "joint_20", "joint_30"], 2)):
         rng = np.random.default_rng(1)
         q0 = np.tile(model.neutral(), (B, 1))
@@ -478,12 +479,12 @@ def traffic_from_profiles():
     pass was collected on exactly these kernel sources (content hash), else null."""
     import __graft_entry__ as g
 
-    path = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    path = os.path.join(ROOT, "profiles", "traffic_r04.json")
     try:
         t = json.load(open(path))
         if t.get("source_hash") == g._source_hash(g.HIP_DEPS):
-            return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
-        return None, "profiles/traffic_r03.json is from other kernel sources: not reported"
+            return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/traffic_r04.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
+        return None, "profiles/traffic_r04.json is from other kernel sources: not reported"
     except (OSError, ValueError, KeyError):
         return None, "no PMC pass committed for these sources"
 
@@ -496,7 +497,7 @@ def _valu_issue(kernel_ms: float, n_cu: int):
     import __graft_entry__ as g
 
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))
         if t.get("source_hash") != g._source_hash(g.HIP_DEPS) or "solve_kernel_valu_instructions_per_launch" not in t:
             return None
     except (OSError, ValueError):
@@ -506,7 +507,7 @@ def _valu_issue(kernel_ms: float, n_cu: int):
     achieved = insts / (kernel_ms * 1e-3) / 1e9
     return {"bound": "valu issue", "achieved": achieved, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": achieved / peak,
             "valu_instructions_per_launch": insts, "fma_f64_share": t.get("solve_kernel_fma_f64_instructions_per_launch", 0.0) / insts,
-            "source": "SQ_INSTS_VALU of profiles/sq_counters_r03.txt (rocprofv3 --pmc, same kernel sources) / kernel_ms measured here"}
+            "source": "SQ_INSTS_VALU of profiles/sq_counters_r04.txt (rocprofv3 --pmc, same kernel sources) / kernel_ms measured here"}
 
 
 def _with_timeout(fn, seconds: float, what: str):
@@ -770,6 +771,10 @@ def main() -> None:
             extra["configs"] = {
                 "ur5_B4096": measure_config(solver, "ur5", 4096 if B >= 4096 else B, 20, bounds="tight", jacobians="dense"),
                 "jvrc_B65536": measure_config(solver, "jvrc", 65536 if B >= 4096 else B, 5, bounds="tight", jacobians="dense"),
+                # the headline stack with two position barriers: 30 coordinates + 6 dense rows = 36 tableau rows on a
+                # 32-lane group (ik_sweepx.h); the Goldfarb-Idnani kernel alone beside it
+                "draco3_2barriers_B65536": measure_config(solver, "draco3b", 65536 if B >= 4096 else B, 5, ab_gi_alone=True, bounds="tight",
+                                                          jacobians="dense"),
                 # the weakly regularised regime: examples/humanoid_jvrc.py:69-81,112-114 as it is -- nv = 50, four
                 # FrameTasks, NO posture task, damping = 1e-12: cond(H) ~ 1e13-1e14.  dq is only determined to
                 # cond(H) eps there (two correct solvers differ by far more than 1e-8 along the flat directions): the

@@ -310,6 +310,9 @@ typedef struct pinkhip_rollout_step {
   int32_t n_limit_rows;
   const double *limit_rows;  /* [n_limit_rows,6] device */
   const double *limit_h;     /* [n_limit_rows] device */
+  double dq_scale;           /* what is written to dq is the displacement times this (0: 1).  1 / dt hands out the
+                                velocity pink.solve_ik returns (pink/solve_ik.py:274) without another pass over the
+                                array; only with integrate = 0 */
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);

@@ -109,7 +109,7 @@ class RolloutStep(ctypes.Structure):
         ("barrier_bound", ctypes.c_void_p), ("barrier_gain", ctypes.c_void_p),
         ("sT_b", ctypes.c_int64), ("sT_f", ctypes.c_int64),
         ("root_box", ctypes.c_void_p), ("n_limit_rows", ctypes.c_int32), ("limit_rows", ctypes.c_void_p),
-        ("limit_h", ctypes.c_void_p),
+        ("limit_h", ctypes.c_void_p), ("dq_scale", ctypes.c_double),
     ]
 
 

@@ -17,8 +17,20 @@
 #else
 #define PINKHIP_ROLLOUT_DENSE_TABLE(X)
 #endif
-#define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
+#if PINKHIP_DEV_NV + PINKHIP_DEV_MD > PINKHIP_DEV_W  // (more tableau rows than lanes: the dense rows are virtual)
+#define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, 0, PINKHIP_DEV_W)
 #else
+#define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
+#endif
+#if PINKHIP_DEV_MD > 0
+#define PINKHIP_SWEEPX_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
+#else
+#define PINKHIP_SWEEPX_TABLE(X)
+#endif
+#else
+// X(NV, MD, W): the sweep-tableau kernel with VIRTUAL dense rows ik_solve_sweepx_kernel<NV, MD, W> (ik_sweepx.h): NV
+// coordinates on the W lanes, up to MD dense rows riding in a second role of the first MD lanes (NV + MD may exceed W)
+#define PINKHIP_SWEEPX_TABLE(X) X(16, 8, 16) X(30, 6, 32) X(30, 8, 32) X(32, 8, 32)
 // X(NV, MD, W): the sweep-tableau kernel ik_solve_sweep_kernel<NV, MD, W> (ik_sweep.h): NV coordinates + MD dense rows
 // = NT <= W tableau rows, one per lane.  Ordered by NT within box-only / with dense rows; problems that fit none
 // (8-lane groups, more dense rows than lanes are left) run the Goldfarb-Idnani kernel of PINKHIP_PACKED_TABLE.
@@ -29,7 +41,8 @@
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
 #define PINKHIP_ROLLOUT_TABLE(X) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64)
 // ... and, with position-barrier rows formed on chip (X(NV, MD, W): NV + MD tableau rows on W lanes), for these
-#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(12, 4, 16) X(30, 8, 64) X(34, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
+// (NV + MD > W: virtual dense rows, ik_sweepx.h; listed ahead of the wider group that would also hold the robot)
+#define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(12, 4, 16) X(30, 6, 32) X(30, 8, 64) X(34, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 #define PINKHIP_PACKED_TABLE(X)                                                                          \
   X(6, 8) X(8, 8) X(12, 16) X(16, 16) X(24, 32) X(30, 32) X(32, 32) X(34, 64) X(40, 64) X(48, 64) X(50, 64) X(56, 64) X(64, 64)
 #endif
@@ -64,6 +77,26 @@ inline SweepChoice select_sweep(int nv, int md) {
   return SweepChoice{0, 0, 0};
 }
 
+// Smallest instantiation with virtual dense rows that holds nv coordinates and md > 0 dense rows ({0, 0, 0}: none).
+inline SweepChoice select_sweepx(int nv, int md) {
+  if (md <= 0) return SweepChoice{0, 0, 0};
+#define PINKHIP_PICK(NV_, MD_, W_) \
+  if (nv <= NV_ && md <= MD_) return SweepChoice{NV_, MD_, W_};
+  PINKHIP_SWEEPX_TABLE(PINKHIP_PICK)
+#undef PINKHIP_PICK
+  return SweepChoice{0, 0, 0};
+}
+
+// ... and whether it is the kernel to run: when it packs more QPs into a wavefront than the instantiation with one
+// lane per tableau row (nv = 30 with three to eight dense rows: two QPs per wavefront against one) -- or that one
+// does not exist.
+inline bool prefer_sweepx(int nv, int md) {
+  const SweepChoice x = select_sweepx(nv, md);
+  if (!x.NV) return false;
+  const SweepChoice s = select_sweep(nv, md);
+  return !s.NV || x.W < s.W;
+}
+
 // Which of the two stack + solve kernels serves a batch of B problems (measured on MI355X, scripts/ab_solvers.sh):
 // the sweep-tableau kernel wherever it is instantiated, except
 //   * when it needs a wider group than the Goldfarb-Idnani kernel (nv = 30 with six dense rows: 36 tableau rows = one QP
@@ -84,6 +117,9 @@ inline bool prefer_sweep(int nv, int md, long long B) {
 // tu_sweep.hip): H packed, c, the columns of G.
 constexpr int sweep_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + 2 * W + MD * (W + 2); }
 
+// ... of the kernel with virtual dense rows (= SweepXLds<NV, MD, W>::stride, checked in tu_sweepx.hip)
+constexpr int sweepx_lds_doubles(int NV, int MD, int W) { return ((NV * (NV + 1) / 2 + 1) & ~1) + W + MD * (W + 2) + 2 * ((MD + 1) & ~1); }
+
 // Doubles of LDS per QP of the Goldfarb-Idnani kernel (= LdsP<NV>::stride(md), checked at compile time in
 // tu_rollout.hip): the sweep-tableau kernels hand a group over to it when its result fails the certificate.
 constexpr int packed_lds_doubles(int NV, int md) {
@@ -98,7 +134,8 @@ constexpr int rollout_tail_doubles(int nf) { return (3 * nf + 1) & ~1; }
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger (+ the frame positions behind it when dense rows are formed on chip).
 constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0, int nf = 0) {
-  return max3((fk_doubles + 1) & ~1, sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD)) + (MD > 0 ? rollout_tail_doubles(nf) : 0);
+  return max3((fk_doubles + 1) & ~1, NV + MD > W ? sweepx_lds_doubles(NV, MD, W) : sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD)) +
+         (MD > 0 ? rollout_tail_doubles(nf) : 0);
 }
 
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose

@@ -103,6 +103,7 @@ struct KernelArgs {
   int lds_pitch;     // doubles of LDS per QP (0: LdsP<NV>::stride(md)); the whole-step kernel may need more for its kinematics
   int rank_deficient;  // host_tables.h rank_deficient_by_construction(): the Goldfarb-Idnani code by dispatch
   double damping, dt;
+  double out_scale;  // dq is written times this: 1, or 1 / dt when the caller wants the velocity (pink/solve_ik.py:274)
   // per-instance streams
   const double *J, *e, *cost, *lb, *ub, *Gd, *hd, *c_extra;
   // broadcast tables (device memory, built once per descriptor by the host)

@@ -933,7 +933,7 @@ __device__ __forceinline__ void ik_packed_instance(const KernelArgs &a, long lon
     }
   }
   if (valid) {
-    if (in) late->dq[b * (long long)nv + li] = x;
+    if (in) late->dq[b * (long long)nv + li] = x * late->out_scale;
     if (li == 0) {
       late->status[b] = status;
       if (late->iters) late->iters[b] = it | (path << kPathShift);

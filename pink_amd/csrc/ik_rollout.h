@@ -14,6 +14,7 @@
 #include "dispatch.h"
 #include "ik_kinematics.h"
 #include "ik_sweep.h"
+#include "ik_sweepx.h"
 
 namespace pinkhip {
 
@@ -144,7 +145,10 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
     wave_sync();
     keep_frame_positions(a);
-    st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+    // (more tableau rows than lanes: the dense rows are virtual, ik_sweepx.h -- two robots per wavefront at nv = 30
+    // with barrier rows instead of one)
+    if constexpr (NV + MD > W) st_sweep = ik_sweepx_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
+    else st_sweep = ik_sweep_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
   }
   // a result that fails its KKT certificate is not integrated: the Goldfarb-Idnani code solves that robot's QP again
   // (ik_sweep.h, ik_solve_sweep_body).  It forms the rows from the kinematics like the tableau did, and the tableau's

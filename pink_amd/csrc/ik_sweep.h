@@ -707,7 +707,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
 #endif
     const long long bw = block * G + ln / W;
     if (bw < late->B) {
-      if (in) late->dq[bw * (long long)nv + li] = x;
+      if (in) late->dq[bw * (long long)nv + li] = x * late->out_scale;
       if (li == 0) {
         late->status[bw] = status;
         if (late->iters) late->iters[bw] = it;  // (PATH_TABLEAU = 0; a group handed over is written again)

@@ -1,0 +1,646 @@
+// Sweep tableau with *virtual* dense rows: NV coordinates on the W lanes of a group, up to MD dense rows (equalities,
+// barrier rows, limit rows that are not axis-aligned) that own NO lane -- NV + MD may exceed W.
+//
+// ik_sweep.h gives every tableau row a lane: nv = 30 with more than two dense rows needs 64-lane groups (one QP per
+// wavefront, 38 of 64 lanes busy: 1.72 ms per 65 536 against 1.48 ms of the Goldfarb-Idnani kernel, which keeps two
+// QPs per wavefront).  Here the group keeps the width the coordinates need (two QPs per wavefront at nv = 30) and
+// the dense rows ride along in a second role of the first MD lanes:
+//   * coordinate role of lane m < NV: row m of the tableau, T[m][0 .. NV + MD) in registers -- the entries against the
+//     dense rows included (columns NV + d);
+//   * dense role of lane d < MD: what belongs to dense row d alone -- its slack / multiplier, state, right-hand side,
+//     and row d of the dense-dense block D[d][d'] = T[NV + d][NV + d'] (MD registers).
+// The tableau is symmetric: the entries T[NV + d][j] of a dense row against the coordinates ARE the column entries
+// T[j][NV + d] the coordinate lanes hold -- stored once.  What a dense ROW needs from them (its part of an entering
+// column, a product with a vector) is a transposition: lane src hands its MD entries to the lanes 0 .. MD-1 through
+// LDS (column of a coordinate), or the coordinate lanes' partial products fold by transpose_reduce (products).
+// Everything else -- selection, ratio test, pivot -- runs for both roles in the same instructions' shadow: the
+// pivot is  T[m][j] -= t_m c_j  with c_j broadcast from lane j's coordinate role for j < NV and from lane d's dense
+// role for j = NV + d, and  D[d][d'] -= t'_d c_{NV + d'}.
+//
+// The start-up sweeps run on the NV x NV block only; the dense part follows in closed form afterwards
+// (T[.][NV + d] = H^-1 g_d, D = -G H^-1 G^T): 2 MD NV broadcast-FMAs instead of MD columns dragged through NV sweeps.
+//
+// Iteration, certificate, refinement, hand-over: those of ik_sweep.h (same citations: pink/solve_ik.py:206-275).
+#pragma once
+
+#include "ik_sweep.h"
+
+namespace pinkhip {
+
+template <int NV, int MD, int W>
+struct SweepXLds {
+  static __host__ __device__ constexpr int tri(int i) { return i * (i + 1) / 2; }  // H[i][0..i]
+  static constexpr int oC = (NV * (NV + 1) / 2 + 1) & ~1;                            // c, one entry per lane
+  static constexpr int GP = W + 2;                                                   // (pitch: see SweepLds)
+  static constexpr int oG = oC + W;                                                  // G[d][m] at oG + d GP + m
+  static constexpr int oR = oG + MD * GP;                                            // MD entries of one row in transit,
+  static constexpr int RB = (MD + 1) & ~1;                                           // ... two buffers used in turn
+  static constexpr int stride = oR + 2 * RB;
+};
+
+template <int NV, int MD, int W, class Src = HbmTerms>
+__device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
+  constexpr int NT = NV + MD;
+  static_assert((W == 16 || W == 32 || W == 64) && NV <= W && NV % 2 == 0 && MD >= 1 && MD <= 16 && MD <= W, "dense rows ride in the first MD lanes");
+  constexpr int G = kWave / W;
+  constexpr double INF = INFINITY;
+  constexpr double BIG = 1e300;
+  using BcT = Bcast<W>;
+  using SL = SweepXLds<NV, MD, W>;
+
+  const int lane = lane_id();
+  const int g = lane / W, li = lane & (W - 1);
+  const int nv = a.nv, md = a.md, n_eq = a.n_eq;
+#ifdef PINKHIP_SECTION_CLOCK
+  const bool clock_on = (block & 63) == 0;
+  unsigned long long clock_prev = __builtin_readcyclecounter();
+#endif
+  long long b = block * G + g;
+  const bool valid = b < a.B;
+  if (!valid) b = a.B - 1;  // surplus groups of the last wave redo the last instance, write nothing
+
+  const bool in = li < nv;  // coordinate role live
+  const bool dl = li < md;  // dense role live
+
+  // ------------------------------------------------------------------ stack (task.py:145-167, solve_ik.py:54-67)
+  double T[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) T[j] = 0.0;
+  double ci = 0.0, mu_l = 0.0, dadd = 0.0;
+  stack_rows_bcast<NV, W, 8, Src>(a, b, terms, in, li, T, ci, mu_l);
+  if (in) {
+    dadd = stack_diag_tasks<Src>(a, b, terms, li, ci, mu_l);
+    if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
+  }
+  double diag = a.damping + group_sum<W>(mu_l);
+  // K = [H G^T; G 0]: coordinate lane m takes G[d][m] into column NV + d
+  {
+    const double *Gb = Src::kOnTheFly ? nullptr : a.Gd + b * (long long)md * nv;
+    static_for<0, MD>([&](auto Dc) {
+      constexpr int d = decltype(Dc)::value;
+      if constexpr (Src::kOnTheFly) T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
+      else T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+    });
+  }
+  // dense role: right-hand side and Euclidean norm of the row (the selection's threshold is relative to it)
+  double hv = 0.0, ginv = 1.0;
+  {
+    const double n2 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * T[NV + decltype(Dc)::value]; });
+    if (dl) {
+      if constexpr (Src::kOnTheFly) hv = terms->dense_h(li);
+      else hv = a.hd[b * (long long)md + li];
+      ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
+    }
+  }
+  // barrier objective (barrier.py:193-200): rho_b = r_b / ||J_h||_F^2 on the diagonal, J_h = -dt G rows
+  for (int t = 0; t < a.n_barriers; ++t) {
+    const double r = a.barrier_safe_gain[t];
+    if (r > 1e-6) {
+      const int r0 = a.barrier_rows[t], r1 = a.barrier_rows[t + 1];
+      double s = 0.0;
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        if (in && d >= r0 && d < r1) s += T[NV + d] * T[NV + d];
+      });
+      s = group_sum<W>(s);
+      diag += r / (s * a.dt * a.dt);
+    }
+  }
+  diag += dadd;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (j == li) T[j] += in ? diag : 1.0;  // padded coordinates: identity rows, never pivoted
+  // the QP as stated, parked for the closing trips (ik_sweep.h): H (lower triangle, packed), c, the columns of G
+  double *sm = shared_base() + (long long)g * (a.lds_pitch ? a.lds_pitch : SL::stride);
+  wave_sync();
+  if (li < NV) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (j <= li) sm[SL::tri(li) + j] = T[j];
+  }
+  sm[SL::oC + li] = ci;
+  static_for<0, MD>([&](auto Dc) {
+    constexpr int d = decltype(Dc)::value;
+    sm[SL::oG + d * SL::GP + li] = (li < NV) ? T[NV + d] : 0.0;
+  });
+  PINKHIP_TICK(0);  // stacking
+
+  // ------------------------------------------------------------------ sweep in every coordinate: T_cc = -H^-1
+  int status = STATUS_OPTIMAL;
+  static_for<0, NV>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    if (k < nv) {  // wave-uniform
+      const BcT xb = bcast_prepare<W>(T[k]);
+      double p = value_bcast<W, k>(xb);
+      if (!(p > 0.0)) {
+        status = STATUS_NOT_PD;
+        p = 1.0;
+      }
+      const double rp = fast_rcp(p);
+      const double t = T[k] * rp;
+      const double nt = (li == k) ? rp - 1.0 : -t;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
+      });
+      T[k] = (li == k) ? -rp : t;
+    }
+  });
+  PINKHIP_TICK(1);  // initial sweeps
+  double tdiag = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (j == li) tdiag = T[j];
+
+  // x0 = -H^-1 c
+  double x = 0.0;
+  {
+    const BcT cb = bcast_prepare<W>(in ? ci : 0.0);
+    double r0 = 0.0, r1 = 0.0;
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      if constexpr (j % 2 == 0) r0 = fma_bcast<W, j>(r0, cb, T[j]);
+      else r1 = fma_bcast<W, j>(r1, cb, T[j]);
+    });
+    x = in ? r0 + r1 : 0.0;
+  }
+  // The dense part of the tableau swept on every coordinate, in closed form:
+  //   T[m][NV + d] = (H^-1 g_d)_m = -sum_j T[m][j] G[d][j],   D[d][d'] = -g_d^T H^-1 g_d' = -sum_m G[d][m] T[m][NV + d'],
+  // and the slack of row d at x0: h_d - g_d x0.
+  double D[MD], ud = 0.0;
+  {
+    const double gx0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * x; });
+    if (dl) ud = hv - gx0;
+    double Tn[MD];
+    static_for<0, MD>([&](auto Dc) {
+      constexpr int d = decltype(Dc)::value;
+      const BcT gb = bcast_prepare<W>(T[NV + d]);
+      double s0 = 0.0, s1 = 0.0;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) s0 = fma_bcast<W, j>(s0, gb, T[j]);
+        else s1 = fma_bcast<W, j>(s1, gb, T[j]);
+      });
+      Tn[d] = (li < NV) ? -(s0 + s1) : 0.0;
+    });
+    static_for<0, MD>([&](auto Pc) {
+      constexpr int dp = decltype(Pc)::value;
+      D[dp] = -transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * Tn[dp]; });
+    });
+    static_for<0, MD>([&](auto Dc) { T[NV + decltype(Dc)::value] = Tn[decltype(Dc)::value]; });
+  }
+  double ddiag = 0.0;
+#pragma unroll
+  for (int d = 0; d < MD; ++d)
+    if (d == li) ddiag = D[d];
+  // n^T H^-1 n of a constraint normal: the reference of the linear-dependence test
+  const double zd0 = -tdiag, zdd0 = -ddiag;
+  // conditioning estimate (ik_sweep.h): beyond the threshold the group goes to the Goldfarb-Idnani code right away
+  {
+    const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
+    const double kest = -group_min<W>(-(hii0 * zd0));
+    if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;
+  }
+  PINKHIP_TICK(2);  // x0, dense part
+
+  // ------------------------------------------------------------------ dual active set on the tableau
+  const KernelArgs *late = &a;
+  if constexpr (!Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
+  double lbv, ubv;
+  if constexpr (Src::kOnTheFly) {
+    lbv = in ? terms->lb : -INF;
+    ubv = in ? terms->ub : INF;
+  } else {
+    lbv = in ? late->lb[b * (long long)nv + li] : -INF;
+    ubv = in ? late->ub[b * (long long)nv + li] : INF;
+  }
+  const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
+  const double thr_lo = -tol * (1.0 + fabs(lbv)), thr_up = -tol * (1.0 + fabs(ubv));
+  const double thr_d = -tol * (1.0 + fabs(hv) * ginv);
+  const int max_iter = late->max_iter > 0 ? late->max_iter : 20 * (nv + md) + 50;
+  const bool empty_box_somewhere = wave_any(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up));
+  // coordinate role: state 0 = free, 1 = fixed at lb, 2 = fixed at ub; x; u = multiplier of a fixed coordinate
+  int state = 0;
+  double u = 0.0, phi = 0.0, xfree = 1.0;
+  // dense role: dstate 0 = inactive (ud = slack h - g x), 1 = active (ud = multiplier); dphi = 1 for an active inequality
+  int dstate = 0;
+  double dphi = 0.0;
+  // group-uniform.  src / kd / pi are GLOBAL indices: < NV a coordinate, NV + d dense row d
+  int it = 0, eq_next = 0, src = 0, kind = 0;  // kind 0: lower bound, 1: upper bound, 2: dense row, 3: equality row
+  double uplus = 0.0;
+  bool running = (status == STATUS_OPTIMAL);
+  bool need_sel = true;
+  bool refined = (status == STATUS_ROUTED);
+  int nref = 0;
+  double dprev = 0.0;
+
+  // row m of the stated H times a vector held one entry per coordinate lane (packed triangle in LDS)
+  auto hrow_times = [&](double v) -> double {
+    const BcT vb = bcast_prepare<W>(v);
+    const int base = SL::tri(li < NV ? li : 0);
+    double h0 = 0.0, h1 = 0.0;
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      const int ad = (j > li) ? SL::tri(j) + (li < NV ? li : 0) : base + j;
+      const double hv_ = sm[ad];
+      if constexpr (j % 2 == 0) h0 = fma_bcast<W, j>(h0, vb, hv_);
+      else h1 = fma_bcast<W, j>(h1, vb, hv_);
+    });
+    return (li < NV) ? h0 + h1 : 0.0;
+  };
+  // g_d . v for the stated rows of G (lane d of the dense role gets row d's product; v one entry per coordinate lane)
+  auto grow_times = [&](double v) -> double {
+    return transpose_reduce<W, MD, 0>([&](auto Dc) { return sm[SL::oG + decltype(Dc)::value * SL::GP + li] * v; });
+  };
+  // The dense part of row p of the tableau (p a coordinate, group-uniform; -1: none), handed to the dense role: lane p
+  // writes its entries T[p][NV + d], lane d reads entry d -- T[NV + d][p] by symmetry.
+  // (two buffers in turn: the next hand-over writes the other one, so one barrier per hand-over orders everything)
+  int rowsel = 0;
+  auto dense_part_of_row = [&](int p) -> double {
+    double *rowbuf = sm + SL::oR + rowsel;
+    rowsel ^= SL::RB;
+    if (li == p) {
+      Pair *dst = reinterpret_cast<Pair *>(__builtin_assume_aligned(rowbuf, 16));
+#pragma unroll
+      for (int d = 0; d + 1 < MD; d += 2) dst[d >> 1] = Pair{T[NV + d], T[NV + d + 1]};
+      if constexpr (MD % 2) rowbuf[MD - 1] = T[NV + MD - 1];
+    }
+    wave_sync();
+    const double v = rowbuf[li < MD ? li : 0];
+    return (p >= 0 && li < MD) ? v : 0.0;
+  };
+  // Column idx of the tableau (group-uniform global index, -1: none): `colc` = the coordinate role's entry T[m][idx],
+  // `cold` = the dense role's entry T[NV + d][idx].
+  auto column_of = [&](int idx, double &colc, double &cold) {
+    const int pc = (idx >= 0 && idx < NV) ? idx : -1;
+    const int pd = (idx >= NV) ? idx - NV : -1;
+    // (the hand-over through LDS first: its round trip runs under the broadcast-FMAs below)
+    double tr = 0.0;
+    if (wave_any(pc >= 0)) tr = dense_part_of_row(pc);
+    const BcT eb = bcast_indicator<W>(pc);
+    double c0 = 0.0, c1 = 0.0, cx = 0.0, dx = 0.0;
+    static_for<0, NV>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
+      else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+    });
+    static_for<0, MD>([&](auto Dc) {
+      constexpr int d = decltype(Dc)::value;
+      cx = (pd == d) ? T[NV + d] : cx;
+      dx = (pd == d) ? D[d] : dx;
+    });
+    colc = (c0 + c1) + cx;
+    cold = dx + tr;
+  };
+
+  for (;;) {
+    // (a) entering constraint: the violated one that is farthest away in the metric of the objective
+    if (wave_any(running && need_sel)) {
+      const bool sel = running && need_sel;
+      const double slo = x - lbv, sup = ubv - x;
+      const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
+      const float zf = static_cast<float>(-tdiag);
+      const float wz = (zf > 1e-30f) ? approx_rcpf(zf) : 1e30f;
+      const float flo = static_cast<float>(slo), fup = static_cast<float>(sup);
+      const bool clo = vlo && state == 0;
+      bool has = clo;
+      float key = -(flo * flo) * wz;
+      int id = li;
+      if (vup && state == 0) {
+        const float ku = -(fup * fup) * wz;
+        if (!clo || ku < key) key = ku, id = 64 + li;
+        has = true;
+      }
+      float k32 = has ? key32_packf(key, id) : 3.0e38f;
+      // dense role: an inactive inequality row whose slack is negative
+      if (dl && li >= n_eq && dstate == 0 && ud * ginv < thr_d) {
+        const float zdf = static_cast<float>(-ddiag);
+        const float wzd = (zdf > 1e-30f) ? approx_rcpf(zdf) : 1e30f;
+        const float fu = static_cast<float>(ud);
+        const float kd32 = key32_packf(-(fu * fu) * wzd, 128 + li);
+        k32 = (kd32 < k32) ? kd32 : k32;
+      }
+      const float best32 = group_min32<W>(k32);
+      const bool none = !(best32 < 0.0f);
+      bool bad = false;
+      if (empty_box_somewhere) bad = group_first_lane<W>((vlo && vup) || (state != 0 && in && (vlo || vup))) < W;
+      if (sel) {
+        uplus = 0.0;
+        if (bad) {
+          status = STATUS_INFEASIBLE;
+          running = false;
+        } else if (eq_next < n_eq) {
+          src = NV + eq_next;  // equalities (the first n_eq dense rows) are activated first, in order
+          kind = 3;
+          need_sel = false;
+        } else if (none) {
+          running = false;  // optimal
+        } else {
+          const int pl = key32_payload(best32);
+          if (pl & 128) {
+            src = NV + (pl & 63);
+            kind = 2;
+          } else {
+            src = pl & 63;
+            kind = (pl >> 6) & 1;
+          }
+          need_sel = false;
+        }
+      }
+    }
+    if (running) {
+      if (++it > max_iter) {
+        status = STATUS_MAX_ITER;
+        running = false;
+      }
+    }
+    const bool closing = !wave_any(running);
+    const bool ref = closing && !refined;
+    if (closing && !wave_any(ref)) break;
+    const bool act = running;
+    PINKHIP_TICK(3);  // selection
+
+    // (b) column src of the tableau; for a finishing group the certificate and the product T r instead
+    double col = 0.0, cold = 0.0;
+    if (closing) {
+      // residual of the KKT system of the final active set, from the problem AS STATED (ik_sweep.h)
+      const double kx = hrow_times(in ? x : 0.0);
+      const double ci_ = in ? sm[SL::oC + li] : 0.0;
+      double grad = in ? kx + ci_ : 0.0;
+      const bool arow = dl && dstate == 1;
+      {
+        const BcT lamb = bcast_prepare<W>(arow ? ud : 0.0);  // + G_A^T lambda_A
+        double gl = 0.0;
+        static_for<0, MD>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value;
+          gl = fma_bcast<W, d>(gl, lamb, sm[SL::oG + d * SL::GP + li]);
+        });
+        if (in) grad += gl;
+      }
+      const double gx = grow_times(in ? x : 0.0);
+      const double hii = in ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
+      const double gsc = group_min<W>(-hii) * group_min<W>(in ? -fabs(x) : 0.0) - group_min<W>(-fabs(ci_));
+      const double gtol = PINKHIP_SWEEP_CERT_TOL * gsc;
+      bool fails = false;  // (written so that a NaN fails)
+      if (in) {
+        if (state == 0) fails = !(fabs(grad) <= gtol && x - lbv >= 10.0 * thr_lo && ubv - x >= 10.0 * thr_up);
+        else fails = (state == 1) ? !(grad >= -gtol) : !(grad <= gtol);
+      }
+      double r = (in && state == 0) ? grad : 0.0, rd = 0.0;
+      bool failsd = false;
+      if (dl) {
+        const double slack = (hv - gx) * ginv;
+        if (arow) {
+          rd = gx - hv;  // residual of an active row
+          failsd = !(fabs(slack) <= -10.0 * thr_d);
+        } else if (li >= n_eq) {
+          failsd = !(slack >= 10.0 * thr_d);
+        }
+      }
+      const bool cert_fails = group_first_lane<W>(fails || failsd) < W;
+      if (!ref || status != STATUS_OPTIMAL) r = 0.0, rd = 0.0;
+      // (x_F, lambda_A) += T_BB r: the coordinate role's entry, then the dense role's
+      double sdiag = 0.0, sdd = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j == li) sdiag = T[j];
+#pragma unroll
+      for (int d = 0; d < MD; ++d)
+        if (d == li) sdd = D[d];
+      const BcT rb = bcast_prepare<W>(r), rdb = bcast_prepare<W>(rd);
+      double p0 = 0.0, p1 = 0.0;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) p0 = fma_bcast<W, j>(p0, rb, T[j]);
+        else p1 = fma_bcast<W, j>(p1, rb, T[j]);
+      });
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        p0 = fma_bcast<W, d>(p0, rdb, T[NV + d]);
+      });
+      double q0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * r; });
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        q0 = fma_bcast<W, d>(q0, rdb, D[d]);
+      });
+      const double dxc = (ref && in && state == 0) ? (p0 + p1) + (tdiag - sdiag) * r : 0.0;
+      const double dxd = (ref && arow) ? q0 + (ddiag - sdd) * rd : 0.0;
+      const bool more = group_first_lane<W>(fabs(dxc) > 1e-9 * fabs(x) + 1e-13) < W;
+      const double dmax = -group_min<W>(-fabs(dxc));
+      const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
+      const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
+      if (ref) {
+        if (status != STATUS_OPTIMAL) {
+          status = STATUS_BREAKDOWN;  // a verdict reached on the tableau is confirmed by the Goldfarb-Idnani code
+          refined = true;
+        } else if (!cert_fails && !more) {
+          if (sane) x += dxc;
+          refined = true;
+        } else if (sane && nref < 3) {
+          x += dxc;
+          ud += dxd;
+          dprev = dmax;
+          ++nref;
+        } else {
+          status = STATUS_BREAKDOWN;
+          refined = true;
+        }
+      }
+      if (!wave_any(!refined)) break;
+    } else {
+      column_of(act ? src : -1, col, cold);
+    }
+    // the lane that holds the entering constraint -- lane src in its coordinate role or lane src - NV in its dense
+    // role: the group knows which, so every lane offers the value of THAT role and one broadcast fetches it
+    const bool sdense = src >= NV;
+    const int sl = sdense ? src - NV : src;
+    if (li == src && li < NV) col = tdiag;
+    if (li == src - NV) cold = ddiag;
+    // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
+    // entering row; pv = T[src][src] = -n^T Z n
+    const double num = group_bcast<W>(sdense ? -ud : (kind == 0 ? lbv : ubv) - x, sl);
+    double pv = group_bcast<W>(sdense ? ddiag : tdiag, sl);
+    const double z0 = group_bcast<W>(sdense ? zdd0 : zd0, sl);
+    bool lin_dep = false;
+    {
+      // little curvature left along the entering normal: formed again as a sum of squares w^T H w (ik_sweep.h)
+      const bool little = act && !(-pv * 1e6 > z0);
+      if (wave_any(little)) {
+        const double w = (in && state == 0) ? col : 0.0;
+        const double hw = hrow_times(w);
+        const double curv = group_sum<W>((li < NV) ? w * hw : 0.0);
+        if (little) pv = -curv;
+      }
+      lin_dep = !(-pv * 1e12 > z0);
+    }
+    PINKHIP_TICK(4);  // column
+    // (c) step
+    const double rpv = fast_rcp(pv);
+    const double sgn = (num >= 0.0) ? 1.0 : -1.0;
+    const double full = lin_dep ? BIG : -fabs(num) * rpv;
+    const double rate = phi * col * sgn, rated = dphi * cold * sgn;
+    const bool blocking = act && rate > 0.0, blockd = act && rated > 0.0;
+    const double ratio = blocking ? max_raw(u, 0.0) * fast_rcp1(rate) : BIG;
+    const double ratiod = blockd ? max_raw(ud, 0.0) * fast_rcp1(rated) : BIG;
+    const double k1 = group_min<W>((ratiod < ratio) ? ratiod : ratio);
+    const int kdc = group_first_lane<W>(blocking && ratio == k1);
+    const int kdd = group_first_lane<W>(blockd && ratiod == k1);
+    const int kd = (kdc < W) ? kdc : NV + (kdd & (W - 1));
+    const double tstep = (k1 < full) ? k1 : full;
+    const bool stuck = !(tstep < BIG);
+    double hs = 0.0;
+    if (wave_any(act && stuck)) hs = group_bcast<W>(sdense ? hv : (kind == 0 ? lbv : ubv), sl);
+    if (act && stuck) {
+      const bool tiny = fabs(num) <= 1e-9 * (1.0 + fabs(hs));
+      if (kind == 3 && tiny) {
+        ++eq_next;  // equality implied by the active ones and already satisfied: nothing to add
+        need_sel = true;
+      } else if (tiny) {
+        // a dependent inequality that no drop can help, violated by round-off only: the bound moves to the point
+        if (li == src && li < NV) {
+          if (kind == 0) lbv = x;
+          else ubv = x;
+        }
+        if (li == src - NV) hv -= ud, ud = 0.0;
+        need_sel = true;
+      } else {
+        status = STATUS_INFEASIBLE;
+        running = false;
+      }
+    }
+    const bool act2 = act && running && !stuck;
+    const bool do_add = act2 && !(k1 < full);
+    const bool do_drop = act2 && !do_add;
+    {
+      const double nu = act2 ? sgn * tstep : 0.0;
+      const double dc = col * nu;
+      x = fma(-xfree, dc, x);
+      u = fma(-phi, dc, u);
+      ud = fma(-cold, nu, ud);  // slack or multiplier of a row: both move by -col nu
+      uplus += (kind == 3) ? nu : fabs(nu);
+    }
+    PINKHIP_TICK(5);  // step lengths, x / u update
+    // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves)
+    int pi = -1;
+    double pvt = 1.0, rp = 0.0;
+    if (do_add) {
+      pi = src;
+      pvt = pv;
+      rp = rpv;
+      if (li == src && li < NV) {
+        state = kind + 1;
+        x = (kind == 0) ? lbv : ubv;
+        phi = (kind == 0) ? -1.0 : 1.0;
+        xfree = 0.0;
+        u = uplus;
+      }
+      if (li == src - NV) {
+        dstate = 1;
+        dphi = (li >= n_eq) ? 1.0 : 0.0;  // equalities never leave
+        ud = uplus;
+      }
+      if (kind == 3) ++eq_next;
+      need_sel = true;
+    }
+    if (wave_any(do_drop)) {
+      double ck, ckd;
+      column_of(do_drop ? kd : -1, ck, ckd);
+      const double pk = group_bcast<W>(kd >= NV ? ddiag : tdiag, kd >= NV ? kd - NV : kd);
+      if (do_drop) {
+        col = (li == kd && li < NV) ? tdiag : ck;
+        cold = (li == kd - NV) ? ddiag : ckd;
+        pi = kd;
+        pvt = pk;
+        rp = fast_rcp(pk);
+        if (li == kd && li < NV) {
+          state = 0;
+          u = 0.0;
+          phi = 0.0;
+          xfree = 1.0;
+        }
+        if (li == kd - NV) {
+          dstate = 0;
+          ud = 0.0;
+          dphi = 0.0;
+        }
+      }
+    }
+    PINKHIP_TICK(6);  // column of the leaving constraint
+    {
+      // sweep (nonbasic -> basic: sg = +1) or reverse sweep (sg = -1) on pi.  Basic = free coordinate / active row.
+      const double sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
+      double t = col * rp, cp = col, td = cold * rp, cpd = cold;
+      if (li == pi && li < NV) {
+        t = 1.0 - sg * rp;
+        cp = pvt - sg;
+      }
+      if (li == pi - NV) {
+        td = 1.0 - sg * rp;
+        cpd = pvt - sg;
+      }
+      const BcT xb = bcast_prepare<W>(cp), xbd = bcast_prepare<W>(cpd);
+      const double nt = -t, ntd = -td;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        T[j] = fma_bcast<W, j>(T[j], xb, nt);
+      });
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        T[NV + d] = fma_bcast<W, d>(T[NV + d], xbd, nt);
+        D[d] = fma_bcast<W, d>(D[d], xbd, ntd);
+      });
+      tdiag = (li == pi && li < NV) ? -rp : tdiag - t * col;
+      ddiag = (li == pi - NV) ? -rp : ddiag - td * cold;
+    }
+    PINKHIP_TICK(7);  // pivot
+  }
+  PINKHIP_TICK(8);  // exit
+  // ------------------------------------------------------------------ write-out
+  if constexpr (Src::kOnTheFly) {
+    terms->x = in ? x : 0.0;
+    terms->status = status;
+  }
+  {
+    int ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(ln));
+#endif
+    const long long bw = block * G + ln / W;
+    if (bw < late->B) {
+      if (in) late->dq[bw * (long long)nv + li] = x * late->out_scale;
+      if (li == 0) {
+        late->status[bw] = status;
+        if (late->iters) late->iters[bw] = it;
+      }
+    }
+  }
+  return status;
+}
+
+// doubles of LDS per QP: the parking area or, for a group that is handed over, the Goldfarb-Idnani working set
+template <int NV, int MD, int W>
+__host__ __device__ constexpr int sweepx_kernel_lds_doubles(int md) {
+  return SweepXLds<NV, MD, W>::stride > LdsP<NV>::stride(md) ? SweepXLds<NV, MD, W>::stride : LdsP<NV>::stride(md);
+}
+
+template <int NV, int MD, int W>
+__device__ __forceinline__ void ik_solve_sweepx_body(const KernelArgs &a, long long block) {
+  const int st = ik_sweepx_instance<NV, MD, W>(a, block);
+  const bool over = st == STATUS_BREAKDOWN || st == STATUS_ROUTED;
+  if (wave_any(over)) {
+    wave_sync();
+    const KernelArgs *again = kernarg_reload<KernelArgs>(a);
+    long long blk = block;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(blk));
+#endif
+    ik_packed_instance<NV, W, true>(*again, blk, static_cast<HbmTerms *>(nullptr), over, st == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER);
+  }
+}
+
+template <int NV, int MD, int W>
+__global__ void __launch_bounds__(kWave) PINKHIP_OCCUPANCY_SWEEPX(NV, MD) ik_solve_sweepx_kernel(KernelArgs a) {
+  ik_solve_sweepx_body<NV, MD, W>(a, block_id());
+}
+
+}  // namespace pinkhip

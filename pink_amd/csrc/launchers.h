@@ -20,6 +20,12 @@ namespace pinkhip {
 PINKHIP_SWEEP_TABLE(PINKHIP_DECLARE)
 #undef PINKHIP_DECLARE
 
+// tu_sweepx.hip: the same with virtual dense rows, one launcher per entry of PINKHIP_SWEEPX_TABLE
+#define PINKHIP_LAUNCH_SWEEPX_NAME(NV, MD, W) PINKHIP_PASTE6(launch_sweepx_, NV, MD, W)
+#define PINKHIP_DECLARE(NV, MD, W) hipError_t PINKHIP_LAUNCH_SWEEPX_NAME(NV, MD, W)(hipStream_t stream, const KernelArgs &a);
+PINKHIP_SWEEPX_TABLE(PINKHIP_DECLARE)
+#undef PINKHIP_DECLARE
+
 #define PINKHIP_DECLARE(NV, W)                                                                  \
   hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 0)(hipStream_t stream, const KernelArgs &a);     \
   hipError_t PINKHIP_LAUNCH_PACKED_NAME(NV, W, 1)(hipStream_t stream, const KernelArgs &a);

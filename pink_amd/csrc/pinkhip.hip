@@ -128,6 +128,23 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
   const bool sweep = solver_env ? (std::strcmp(solver_env, "packed") != 0 && sc.NV != 0)
                                 : (pinkhip::prefer_sweep(a.nv, a.md, a.B) && !a.rank_deficient);
+  // ... with virtual dense rows where that packs more QPs into a wavefront (ik_sweepx.h, dispatch.h prefer_sweepx)
+  const pinkhip::SweepChoice xc = pinkhip::select_sweepx(a.nv, a.md);
+  const bool sweepx = solver_env ? (std::strcmp(solver_env, "sweepx") == 0 && xc.NV != 0)
+                                 : (pinkhip::prefer_sweepx(a.nv, a.md) && !a.rank_deficient);
+  if (sweepx) {
+    hipError_t ex = hipErrorInvalidValue;
+    switch (xc.NV * 100 + xc.MD) {
+#define PINKHIP_CASE(NV, MD, W)                                            \
+  case NV * 100 + MD:                                                      \
+    ex = pinkhip::PINKHIP_LAUNCH_SWEEPX_NAME(NV, MD, W)(h->stream, a);     \
+    break;
+      PINKHIP_SWEEPX_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+    }
+    PH_HIP(h, ex);
+    return PINKHIP_OK;
+  }
   if (sweep) {
     hipError_t es = hipErrorInvalidValue;
     switch (sc.NV * 100 + sc.MD) {
@@ -166,6 +183,7 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   const std::string why = pinkhip::build_tables(*d, t);
   if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
   a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
+  a.out_scale = 1.0;
   PH_HIP(h, hipSetDevice(h->device));
 
   // pack: [row_gain K][row_lm K][barrier_safe_gain nb] doubles, then int tables
@@ -822,6 +840,9 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, fkd);
   }
   ra.k.cost = st->cost;
+  ra.k.out_scale = (st->dq_scale != 0.0) ? st->dq_scale : 1.0;
+  if (st->dq_scale != 0.0 && st->dq_scale != 1.0 && st->integrate)
+    return fail(h, PINKHIP_E_INVALID, "dq_scale rescales what is written to dq: not together with integrate (the next step reads dq)");
   ra.k.dq = st->dq;
   ra.k.status = st->status;
   ra.k.iters = st->iters;

@@ -24,8 +24,9 @@ hipError_t PINKHIP_LAUNCH_ROLLOUT_NAME(PINKHIP_TU_NV, PINKHIP_TU_W)(hipStream_t 
 hipError_t PINKHIP_LAUNCH_ROLLOUT_DENSE_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKHIP_TU_W)(hipStream_t stream, const RolloutArgs &a) {
 #endif
   constexpr int NV = PINKHIP_TU_NV, MD = PINKHIP_TU_MD, W = PINKHIP_TU_W, G = kWave / W;
-  using SL = SweepLds<NV, MD, W>;
-  static_assert(sweep_lds_doubles(NV, MD, W) == SL::stride, "dispatch.h restates the LDS layout");
+  constexpr bool kVirtual = NV + MD > W;  // (dense rows without lanes of their own: ik_sweepx.h)
+  static_assert(kVirtual ? sweepx_lds_doubles(NV, MD, W) == SweepXLds<NV, MD, W>::stride
+                         : sweep_lds_doubles(NV, MD, W) == SweepLds<NV, MD, W>::stride, "dispatch.h restates the LDS layout");
   static_assert(packed_lds_doubles(NV, MD) == LdsP<NV>::stride(MD), "dispatch.h restates the LDS layout");
   const size_t lds = 8 * static_cast<size_t>(a.k.lds_pitch) * G + 16;
   const dim3 grid(static_cast<unsigned>((a.k.B + G - 1) / G)), block(kWave);

@@ -49,6 +49,13 @@
 #define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 4 : (NT) <= 34 ? 3 : 2)
 #endif
 #define PINKHIP_OCCUPANCY_SWEEP(NT) __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEP_WAVES(NT), PINKHIP_SWEEP_WAVES(NT))))
+// ... with virtual dense rows (ik_sweepx.h): a lane holds NV + 2 MD doubles of tableau (its row + row d of the
+// dense-dense block)
+#ifndef PINKHIP_SWEEPX_WAVES
+#define PINKHIP_SWEEPX_WAVES(NV, MD) ((NV) + 2 * (MD) <= 16 ? 4 : (NV) + 2 * (MD) <= 34 ? 3 : 2)
+#endif
+#define PINKHIP_OCCUPANCY_SWEEPX(NV, MD) \
+  __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEPX_WAVES(NV, MD), PINKHIP_SWEEPX_WAVES(NV, MD))))
 
 // whole-control-step kernel: the kinematics part needs more registers than the solve of the small sizes (12-dof
 // arm, 65 536 robots: 0.136 ms per step at four waves per SIMD with 57 spilled registers, 0.120 ms at three)

@@ -324,7 +324,9 @@ class DeviceRollout:
         iteration counts of ``last_step`` are those of the current configurations, which stay as they are)."""
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         self._pipelined = None
+        self.scaled = False
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
+            self.scaled = False  # (no whole-step kernel for this model: the launches below write dq unscaled)
             if self.md:
                 raise NoWholeStepKernel("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
             self.fused = True  # no instantiation for this model: two launches from now on
@@ -434,6 +436,7 @@ class DeviceRollout:
         st.dq, st.status, st.iters, st.first_failure = self.d_dq, self.d_status, self.d_iters, self.d_fail
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
+        self._scale_out(st, integrate)
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
         if self.d_bar:
@@ -442,6 +445,14 @@ class DeviceRollout:
             st.root_box, st.limit_rows, st.limit_h = self.d_lim
             st.n_limit_rows = len(self.lim_h)
         return self.api.rollout_step(self.desc, self.dmodel, st)
+
+    def _scale_out(self, st, integrate: bool) -> None:
+        """``velocity_out``: a solve without integration writes ``dq / dt`` -- the velocity ``solve_ik`` returns
+        (``pink/solve_ik.py:274``) -- instead of ``dq`` (``pinkhip_rollout_step.dq_scale``): no pass over the array on
+        the host afterwards.  ``self.scaled`` says whether the last launch did."""
+        self.scaled = bool(getattr(self, "velocity_out", False)) and not integrate
+        if self.scaled:
+            st.dq_scale = 1.0 / self.dt
 
     def _one_kernel_step_range(self, integrate: bool, lo: int, hi: int) -> bool:
         """The whole-step kernel on the robots ``lo .. hi`` of the resident batch (per-frame target arrays)."""
@@ -456,6 +467,7 @@ class DeviceRollout:
         st.first_failure = self.d_fail + 4 * lo
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
+        self._scale_out(st, integrate)
         st.sT_b, st.sT_f = 12, 12 * self.B
         if self.d_lim:
             st.root_box = self.d_lim[0]

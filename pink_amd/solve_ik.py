@@ -589,6 +589,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
+        ro.velocity_out = True  # (the whole-step kernel hands out dq / dt: no division over the array afterwards)
         fresh = True
     try:
         # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
@@ -600,7 +601,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
             ro.set_targets(T)
             ro.step(integrate=False)
         api.sync()
-        out = ro.last_step() + (ro.last_path,)
+        out = ro.last_step() + (ro.last_path, bool(getattr(ro, "scaled", False)))
     except BaseException:
         ro.free()
         raise
@@ -673,8 +674,11 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
                                           if bounds[r][1] > bounds[r][0] else None)
                 parts = [p for p in parts if p is not None]
                 dq, status, iters, path = (np.concatenate([p[k] for p in parts]) for k in range(4))
+                scaled = all(p[4] for p in parts)
+                if not scaled and any(p[4] for p in parts):  # (never: the shards share the model and the kernel)
+                    raise PinkError("shards disagree about the scale of dq")
             else:
-                dq, status, iters, path = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter,
+                dq, status, iters, path, scaled = _solve_on_device(plan, dt, damping, safety_break, solver_handle or default_solver(), max_iter,
                                                            out=out if out is not None and out.shape == (len(configurations), plan[0].nv) else None)
         except NoWholeStepKernel:
             # no instantiation of the whole-step kernel holds this model's rows (more barrier rows / joints than the
@@ -687,9 +691,14 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             _record_stats(result, "device")
             if status.any():
                 raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
+            if scaled:  # the kernel wrote v = dq / dt (pink/solve_ik.py:274)
+                if out is not None and dq is not out:
+                    np.copyto(out, dq)
+                    return out
+                return dq
             if out is not None and dq is not out:
                 return np.divide(dq, dt, out=out)
-            return np.divide(dq, dt, out=dq)  # v = dq / dt (pink/solve_ik.py:274), in place: dq is this call's own array
+            return np.divide(dq, dt, out=dq)  # v = dq / dt, in place: dq is this call's own array
     B = len(configurations)
     if B and hasattr(configurations, "check_limits"):
         configurations.check_limits(safety_break=safety_break)

@@ -38,6 +38,11 @@ CONFIGS: Dict[str, dict] = {
     "jvrc": dict(config_id=4, nv=50, root_nv=6, dt=5e-3,
                  frame_costs=[(1.0, 3.0), (1.0, 0.0), (1.0, 3.0), (1.0, 3.0)], frame_lm=0.0,
                  posture_cost=1e-1, n_barriers=2),
+    # the Draco3-shaped stack with two position barriers (examples/barriers/arm_ur5.py:50-57 on the humanoid): nv = 30
+    # plus six dense rows -- 36 tableau rows on a 32-lane group (ik_sweepx.h: the dense rows ride without lanes)
+    "draco3b": dict(config_id=13, nv=30, root_nv=6, dt=5e-3,
+                    frame_costs=[(1.0, 1.0), (1.0, 0.0), (1.0, 1.0), (4.0, 4.0)], frame_lm=0.0,
+                    posture_cost=1e-1, n_barriers=2),
     # examples/humanoid_jvrc.py:69-81,112-114 AS IT IS: four FrameTasks (lm_damping 0, the pelvis without orientation
     # cost), NO posture task, damping = 1e-12 -- 21 weighted rows on 50 coordinates: H is positive definite through
     # `damping` alone (pink/solve_ik.py:55), cond(H) ~ 1e13.  The weakly regularised regime.

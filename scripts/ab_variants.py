@@ -20,8 +20,6 @@ def main():
     if cfg == "custom":  # AB_NV / AB_NB: fixed-base robot of AB_NV joints, two FrameTasks + posture, AB_NB barrier rows
         synthetic.CONFIGS["custom"] = dict(config_id=20, nv=int(os.environ.get("AB_NV", "12")), root_nv=0, dt=5e-3, frame_costs=[(1.0, 1.0), (1.0, 1.0)],
                                            frame_lm=0.0, posture_cost=1e-1, n_barriers=int(os.environ.get("AB_NB", "0")))
-    if cfg == "draco3b":  # the headline robot with two barrier rows: the DENSE instantiation of the same size
-        synthetic.CONFIGS["draco3b"] = dict(synthetic.CONFIGS["draco3"], n_barriers=2, config_id=13)
     B = int(os.environ.get("AB_BATCH", "65536"))
     terms = synthetic.make_terms(cfg, B, bounds=os.environ.get("AB_BOUNDS", "tight"), jacobians="dense")
     batch = synthetic.pack(terms)

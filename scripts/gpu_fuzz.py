@@ -15,13 +15,15 @@ from pink_amd.batch_solver import BatchSolver  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 s = BatchSolver(0)
-for solver in ("sweep", "packed"):
+for solver in ("sweep", "sweepx", "packed"):  # (sweepx: the kernel with virtual dense rows where it is instantiated)
     os.environ["PINKHIP_SOLVER"] = solver
     t0 = time.time()
     n, bad = 0, []
     for sd in range(first, first + count):
         try:
             n += ps.fuzz(s, [sd])
+            if sd % 2 == 0:  # the shapes with virtual dense rows: 25 .. 32 coordinates, up to eight dense rows
+                n += ps.fuzz(s, [sd], nv_lo=25, nv_hi=33, md_hi=6)
             if sd % 4 == 0:  # the wide instantiations: up to 60 coordinates, up to 12 dense rows
                 n += ps.fuzz(s, [sd], nv_lo=34, nv_hi=61, md_hi=13)
             if sd % 2 == 1:  # weakly regularised objectives

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Profiling visit (round 3): the bench line, rocprofv3 kernel stats of EVERY kernel the bench runs (headline, stack-only,
+# Profiling visit (round 4; round 3's plus the A/B of the solve kernels, the stages of the pipelined array call and the fuzz runs): the bench line, rocprofv3 kernel stats of EVERY kernel the bench runs (headline, stack-only,
 # UR5, JVRC, whole-step), HBM PMC passes, SQ counters of the headline and of the JVRC-shaped kernel, section clocks,
-# host latency, closed-loop rollout.  Outputs under gpurun_out/; scripts/collect_profiles.py r03 copies the summaries
+# host latency, closed-loop rollout.  Outputs under gpurun_out/; scripts/collect_profiles.py r04 copies the summaries
 # into profiles/.   Usage (GPU box):  bash scripts/gpu_profile.sh
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -22,4 +22,8 @@ CLOCK_W=64 PINKHIP_CLOCK_LIBRARY=$PWD/pink_amd/csrc/libpinkhip_clock_jvrc.so pyt
 python scripts/host_latency.py > gpurun_out/host_latency.txt 2>&1
 python scripts/rollout_bench.py > gpurun_out/rollout_bench.txt 2>&1; tail -2 gpurun_out/rollout_bench.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rollout -o r01 -- python scripts/rollout_bench.py > /dev/null 2> gpurun_out/prof_rollout.err
+bash scripts/ab_solvers.sh > gpurun_out/ab_solvers.txt 2>&1
+python scripts/prof_pipeline.py > gpurun_out/prof_pipeline.txt 2>&1
+(python scripts/gpu_fuzz.py 300000 12000) > gpurun_out/fuzz.txt 2>&1
+(python scripts/gpu_fuzz_rollout.py 14000 1500; python scripts/gpu_fuzz_rollout.py 24000 1500; python scripts/gpu_fuzz_rollout.py 40000 3000) > gpurun_out/fuzz_rollout.txt 2>&1
 ls gpurun_out/prof gpurun_out/pmc_FETCH_SIZE | head

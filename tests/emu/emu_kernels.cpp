@@ -7,6 +7,7 @@
 #include "../../pink_amd/csrc/dispatch.h"
 #include "../../pink_amd/csrc/ik_kernels_packed.h"
 #include "../../pink_amd/csrc/ik_sweep.h"
+#include "../../pink_amd/csrc/ik_sweepx.h"
 #include "../../pink_amd/csrc/ik_stack_mfma.h"
 #include "../../pink_amd/csrc/ik_frame_task.h"
 #include "../../pink_amd/csrc/ik_kinematics.h"
@@ -35,6 +36,13 @@ void lane_main_sweep(void *p) {
   KernelArgs k = *static_cast<const KernelArgs *>(p);
   k.lds_pitch = pinkhip::sweep_kernel_lds_doubles<NV, MD, W>(k.md);  // as tu_sweep.hip's launcher
   pinkhip::ik_solve_sweep_body<NV, MD, W>(k, pinkhip::block_id());
+}
+
+template <int NV, int MD, int W>
+void lane_main_sweepx(void *p) {
+  KernelArgs k = *static_cast<const KernelArgs *>(p);
+  k.lds_pitch = pinkhip::sweepx_kernel_lds_doubles<NV, MD, W>(k.md);  // as tu_sweepx.hip's launcher
+  pinkhip::ik_solve_sweepx_body<NV, MD, W>(k, pinkhip::block_id());
 }
 
 template <int TP>
@@ -74,6 +82,7 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
   a.max_iter = d->max_iter;
   a.damping = d->damping;
   a.dt = d->dt;
+  a.out_scale = 1.0;
   a.J = in->J;
   a.e = in->e;
   a.cost = in->cost;
@@ -115,7 +124,20 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
     const char *force = std::getenv("PINKHIP_SOLVER");  // "packed" / "sweep": one kernel for every problem it serves
     a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
     const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : (pinkhip::prefer_sweep(a.nv, a.md, d->B) && !a.rank_deficient);
-    if (sweep) {
+    const pinkhip::SweepChoice xc = pinkhip::select_sweepx(a.nv, a.md);
+    const bool sweepx = force ? (std::string(force) == "sweepx" && xc.NV != 0) : (pinkhip::prefer_sweepx(a.nv, a.md) && !a.rank_deficient);
+    if (sweepx) {
+      switch (xc.NV * 100 + xc.MD) {
+#define PINKHIP_CASE(NV, MD, W)                \
+  case NV * 100 + MD:                          \
+    fn = lane_main_sweepx<NV, MD, W>;          \
+    blocks = (d->B + 64 / W - 1) / (64 / W);   \
+    break;
+        PINKHIP_SWEEPX_TABLE(PINKHIP_CASE)
+#undef PINKHIP_CASE
+      }
+    }
+    if (!fn && sweep) {
       switch (sc.NV * 100 + sc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \
@@ -280,6 +302,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   a.damping = d->damping;
   a.dt = d->dt;
   a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;  // (as prepare() of pinkhip.hip)
+  a.out_scale = (st->dq_scale != 0.0) ? st->dq_scale : 1.0;
   a.cost = st->cost;
   a.row_gain = t.row_gain.data();
   a.row_lm = t.row_lm.data();

@@ -102,8 +102,15 @@ def test_makefile_builds_every_instantiation_of_the_dispatch_table():
     dense = table("PINKHIP_ROLLOUT_DENSE_TABLE")
     rdense = re.search(r"^RDENSE\s*:=\s*(.*)$", mk, re.M).group(1).split()
     assert rdense == [f"{nv}_{md}_{w}" for nv, md, w in dense] and len(dense) >= 4
+    # ... and with virtual dense rows (ik_sweepx.h): NV coordinates on W lanes, MD rows in a second role of the first MD lanes
+    virtual = table("PINKHIP_SWEEPX_TABLE")
+    sweepx = re.search(r"^SWEEPX\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert sweepx == [f"{nv}_{md}_{w}" for nv, md, w in virtual] and len(virtual) >= 3
+    for nv, md, w in virtual:
+        assert int(nv) <= int(w) and 1 <= int(md) <= 16 and int(nv) % 2 == 0 and int(w) in (16, 32, 64)
     for nv, md, w in triples + dense:
-        assert int(nv) + int(md) <= int(w) and int(nv) % 2 == 0 and int(w) in (16, 32, 64)
+        # one lane per tableau row, or (whole-step kernel only) virtual dense rows in an instantiated shape
+        assert (int(nv) + int(md) <= int(w) or (nv, md, w) in virtual) and int(nv) % 2 == 0 and int(w) in (16, 32, 64)
 
 
 def test_headline_kernel_has_no_register_spills(built):

@@ -1,13 +1,15 @@
 """Both stack + solve kernels on the shapes where the dispatch rule (``prefer_sweep``, pink_amd/csrc/dispatch.h) would
 pick only one of them: ``PINKHIP_SOLVER=packed`` forces the Goldfarb-Idnani kernel (ik_kernels_packed.h),
-``PINKHIP_SOLVER=sweep`` the sweep-tableau kernel (ik_sweep.h) wherever it is instantiated.  Emulator under
+``PINKHIP_SOLVER=sweep`` the sweep-tableau kernel (ik_sweep.h) wherever it is instantiated, ``PINKHIP_SOLVER=sweepx``
+the one with virtual dense rows (ik_sweepx.h) wherever THAT is instantiated (dense rows on up to 32 coordinates; the
+sweep-tableau kernel elsewhere).  Emulator under
 ``-m "not gpu"``, MI355X under ``-m gpu``; same checks against the oracle as the main parity suites."""
 import pytest
 
 from tests import parity_suite as ps
 
 
-@pytest.fixture(params=["packed", "sweep"])
+@pytest.fixture(params=["packed", "sweep", "sweepx"])
 def forced(request, monkeypatch):
     monkeypatch.setenv("PINKHIP_SOLVER", request.param)
     return request.param
@@ -21,9 +23,9 @@ def _suite(solver, golden, seeds, B):
         ps.config(solver, name, bounds, jac, B=B)
     for nv in (3, 6, 8, 12, 16, 30, 33, 50, 64):
         ps.random_dims(solver, nv, B=2, seed=100 + nv, root=min(2, nv - 1) if nv > 3 else 0)
-    for nv, md in ((6, 1), (12, 4), (24, 8), (30, 2), (30, 6), (50, 6), (31, 32)):
+    for nv, md in ((6, 1), (12, 4), (14, 7), (24, 8), (30, 2), (30, 6), (30, 8), (32, 5), (50, 6), (31, 32)):
         ps.random_dims(solver, nv, B=3, seed=500 + nv, md=md)
-    for nv, n_eq, md in ((6, 2, 0), (12, 3, 2), (30, 6, 3), (50, 4, 2)):
+    for nv, n_eq, md in ((6, 2, 0), (12, 3, 2), (30, 6, 3), (30, 3, 4), (50, 4, 2)):
         ps.equality_constraints(solver, nv, n_eq, md, B=3, seed=900 + nv)
     ps.equality_edge_cases(solver)
     ps.infeasible(solver)

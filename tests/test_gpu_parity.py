@@ -121,6 +121,7 @@ def _kkt_batch(H, c, lb, ub, dq, Gd=None, hd=None):
 
 FULL_SIZE = [  # BASELINE.json configs 2-4 at their full batch size, plus the two other regimes the bench line carries
     ("draco3", 65536, dict(bounds="tight", jacobians="dense")),
+    ("draco3b", 65536, dict(bounds="tight", jacobians="dense")),  # + two barriers: 36 tableau rows on 32 lanes (ik_sweepx.h)
     ("jvrc", 65536, dict(bounds="tight", jacobians="dense")),
     ("ur5", 4096, dict(bounds="tight", jacobians="dense")),
     ("draco3", 65536, dict(bounds="kinematic", jacobians="kinematic")),

@@ -23,7 +23,10 @@ def _models():
     humanoid = build_chain(9, free_flyer=True, seed=3)  # free-flyer root + 9 revolute joints: nv = 15
     humanoid.add_frame("mid", 4, SE3(np.eye(3), [0.05, 0.0, 0.1]))
     arm12 = build_chain(12, seed=5)  # nv = 12: a 16-lane group whose kinematics scratch exceeds the solve's LDS share
-    return [(arm, ["tool0"]), (humanoid, ["tool0", "mid"]), (arm12, ["tool0", "joint_6"])]
+    # free flyer + 24 joints: nv = 30, the headline shape -- with barrier rows 30 + md tableau rows on a 32-lane group
+    # (virtual dense rows, ik_sweepx.h)
+    big = build_chain(24, free_flyer=True, seed=2)
+    return [(arm, ["tool0"]), (humanoid, ["tool0", "mid"]), (arm12, ["tool0", "joint_6"]), (big, ["tool0", "joint_12"])]
 
 
 def _random_q(model, B, rng):
@@ -182,7 +185,7 @@ def test_closed_loop_matches_host_loop_and_converges(api, which, fused):
     ro.free()
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 3])
 def test_closed_loop_with_position_barriers_matches_host_loop(api, which):
     """PositionBarrier rows (pink/barriers/position_barrier.py:109-153; G = -J_h / dt, h = gain * barrier,
     pink/barriers/barrier.py:246-254) formed on chip by the whole-step kernel: the closed loop with two barriers --
@@ -193,9 +196,9 @@ def test_closed_loop_with_position_barriers_matches_host_loop(api, which):
 
     model, frames = _models()[which]
     rng = np.random.default_rng(70 + which)
-    B, dt, steps = 3, 5e-3, 25
+    B, dt, steps = 3, 5e-3, (25 if which != 3 else 12)
     q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
-    if which == 1:
+    if model.root_joint is not None:
         q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
     cfgs = [Configuration(model, q0[b]) for b in range(B)]
     specs = [(f, 1.0, 0.5 if i == 0 else 0.0, 1.0, 1e-3) for i, f in enumerate(frames)]
