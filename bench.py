@@ -314,7 +314,11 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
         out["headline_shape_arrays"] = api_level_arrays(Bh)
         if hasattr(solver, "pinned_empty"):
             out["headline_shape_arrays_page_locked"] = api_level_arrays(Bh, pinned=True)
-        out["headline_shape_host_evaluated"] = api_level_arrays(Bh, extra_task="damping")
+        # one task more than the whole-step kernel forms on chip (a DampingTask): the FrameTask rows are still formed on
+        # the device from q (pink_amd/hybrid.py), the rest evaluated on the host for the whole batch; and the same call
+        # with everything evaluated on the host (vectorised NumPy kinematics) beside it
+        out["headline_shape_plus_damping_task"] = api_level_arrays(Bh, extra_task="damping")
+        out["headline_shape_plus_damping_task_all_host"] = api_level_arrays(Bh, extra_task="damping", all_host=True)
         return out
     finally:
         pink_amd.clear_device_cache()
@@ -364,7 +368,7 @@ def api_level_host_evaluated(m, B: int) -> dict:
             "max_abs_velocity_difference_vs_per_configuration_solve_ik_on_sample": float(np.abs(v[:n] - np.array(v_ref)).max()), "sample": n}
 
 
-def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False) -> dict:
+def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, all_host: bool = False) -> dict:
     """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
     with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
     array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
@@ -403,9 +407,10 @@ def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False) -> dict
     cfgs = ConfigurationBatch(m, q)
     dt = 5e-3
     v_out = alloc((B, m.nv)) if pinned else None
-    v = solve_ik_batch(cfgs, tasks, dt, out=v_out)  # builds the device state
+    route_kw = dict(device_kinematics=False) if all_host else {}  # (all_host: every task evaluated on the host, for comparison)
+    v = solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw)  # builds the device state
     stats = pink_amd.last_solve_stats()
-    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, out=v_out), 5 if not extra_task else 2)
+    ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw), 5 if not all_host else 2)
     t_call = statistics.median(ts)
     n = min(B, 16)
     v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False)

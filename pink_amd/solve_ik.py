@@ -712,6 +712,14 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             for cfg in configurations:
                 cfg.check_limits(safety_break=safety_break)
     api = solver_handle or default_solver()
+    if (device_kinematics is None and B >= 64 and pool is None and kwargs.get("gpu_frame_tasks", True)
+            and hasattr(api, "fk_frame_tasks") and hasattr(api, "solve_raw")):
+        result = _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constraints, api, max_iter)
+        if result is not None:
+            _record_stats(result, "hybrid")
+            if not result.all_found:
+                raise NoSolutionFound(None, result, result.failed_indices(), result.status[result.status != 0])
+            return np.divide(result.dq, dt, out=out if out is not None else result.dq)
     batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, pool[0] if pool else solver_handle,
                                 gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)), constraints=constraints)
     result = api.solve(batch, max_iter=max_iter)
@@ -719,6 +727,51 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     if not result.all_found:
         raise NoSolutionFound(batch, result, result.failed_indices(), result.status[result.status != 0])
     return np.divide(result.dq, dt, out=out) if out is not None else result.dq / dt
+
+
+def _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constraints, api, max_iter):
+    """The host-evaluated stack with its FrameTask rows formed on the device (:mod:`pink_amd.hybrid`): a
+    :class:`BatchResult`, or ``None`` when the stack is not of that shape (a dense task other than FrameTasks,
+    equality constraints, configurations of several models)."""
+    from . import hybrid
+    from .batch_solver import BatchResult
+    from .configuration import ConfigurationBatch
+    from .kinematics_batch import BatchKinematics
+
+    B = len(configurations)
+    if isinstance(configurations, ConfigurationBatch):
+        model, q, make = configurations.model, configurations.q, configurations.kinematics
+    else:
+        model = configurations[0].model
+        if not hasattr(model, "joints") or any(c.model is not model for c in configurations):
+            return None
+        q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
+        make = lambda: BatchKinematics(model, q)  # noqa: E731
+    slots = _task_slots(tasks, B)
+    frame_slots = hybrid.plan(model, slots, constraints)
+    if frame_slots is None:
+        return None
+    if limits is None:  # model defaults, pink/solve_ik.py:94-105
+        model.ensure_limits()
+        limits = [model.configuration_limit, model.velocity_limit]
+        if getattr(model, "floating_base_velocity_limit", None) is not None:
+            limits.append(model.floating_base_velocity_limit)
+    frames = tuple(slots[k][0].frame for k in frame_slots)
+    key = ("hybrid", id(model), _model_fingerprint(model, frames), B, frames)
+    cache = _rollout_cache(api)
+    state = cache.pop(key, None)
+    if state is None:
+        state = hybrid.HybridState(api, model, frames, B)
+        state._cache_owner = model
+    try:
+        dq, status, iters, path = hybrid.solve(state, q, make, slots, frame_slots, limits, barriers, dt, damping, max_iter)
+    except BaseException:
+        state.free()
+        raise
+    cache[key] = state
+    while len(cache) > _ROLLOUT_CACHE_MAX:
+        cache.pop(next(iter(cache))).free()
+    return BatchResult(dq, status, iters, path)
 
 
 def pinned_empty(shape, dtype=np.float64, solver_handle=None) -> np.ndarray:
@@ -743,7 +796,8 @@ def _record_stats(result, route: str) -> None:
 
 def last_solve_stats() -> dict:
     """What the last :func:`solve_ik_batch` call of this process did: ``route`` (``"device"``: kinematics, rows and QP
-    formed on the device from ``q``; ``"host-evaluated"``: tasks / limits / barriers evaluated on the host, QP on the
-    device), ``instances``, ``failed``, ``iters_mean`` and ``paths`` -- the share of the batch per solver path
+    formed on the device from ``q``; ``"hybrid"``: FrameTask rows formed on the device from ``q``, the other tasks /
+    limits / barriers evaluated on the host, QP on the device; ``"host-evaluated"``: everything evaluated on the host,
+    QP on the device), ``instances``, ``failed``, ``iters_mean`` and ``paths`` -- the share of the batch per solver path
     (:meth:`pink_amd.batch_solver.BatchResult.path_fractions`; ``handover`` is the share that paid for both solvers)."""
     return dict(_LAST_STATS)

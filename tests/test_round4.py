@@ -115,8 +115,12 @@ def test_explicit_default_limits_take_the_device_route(backend):
     assert np.array_equal(V_none, V_half)
     assert np.abs(V_none - V_dev).max() > 1e-6  # (the gain matters on this batch)
     for lim in ([ConfigurationLimit(m)], [ConfigurationLimit(m), VelocityLimit(m, np.full(m.nv, 0.7))]):
-        solve_ik_batch(batch, [ft, po], dt, limits=lim)
+        v_h = solve_ik_batch(batch, [ft, po], dt, limits=lim)
+        # (not the whole-step kernel: the limits are evaluated on the host, the FrameTask rows formed on the device)
+        assert pink_amd.last_solve_stats()["route"] == "hybrid"
+        v_a = solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=False)
         assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+        assert np.abs(v_h - v_a).max() < 1e-8 * max(1.0, np.abs(v_a).max())
         with pytest.raises(pink_amd.PinkError):
             solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=True)
 
@@ -169,9 +173,10 @@ def test_auto_route_falls_back_when_no_whole_step_kernel_fits(backend):
     bars = [PositionBarrier(f, p_min=np.full(3, -5.0), p_max=np.full(3, 5.0), gain=np.full(6, 10.0)) for f in frames]
     batch = ConfigurationBatch(m, q)
     V_auto = solve_ik_batch(batch, tasks + [po], dt, barriers=bars)
-    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+    assert pink_amd.last_solve_stats()["route"] == "hybrid"  # (barrier rows from the host, FrameTask rows from the device)
     V_host = solve_ik_batch(batch, tasks + [po], dt, barriers=bars, device_kinematics=False)
-    assert np.array_equal(V_auto, V_host)
+    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+    assert np.abs(V_auto - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
     with pytest.raises(pink_amd.PinkError):
         solve_ik_batch(batch, tasks + [po], dt, barriers=bars, device_kinematics=True)
 
@@ -237,3 +242,61 @@ def test_solver_path_is_reported_per_instance(backend, request, monkeypatch):
     rwp = s.solve(weak)
     # the routed instances ran the same Goldfarb-Idnani code on the same stacked problem
     assert np.abs(rwp.dq - rw.dq).max() < 1e-9 * max(1.0, np.abs(rw.dq).max())
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_hybrid_route_forms_frame_task_rows_on_the_device(backend, free_flyer):
+    """FrameTasks next to identity-Jacobian tasks (posture, damping, low acceleration, joint velocity) under an explicit
+    limit list with an AccelerationLimit and a barrier: in automatic mode the FrameTask rows are formed by the device
+    from q (pinkhip_fk_frame_tasks_device writes them into the packed streams), everything else is evaluated on the host
+    for the whole batch -- same velocities as the all-host evaluation and as one solve_ik per configuration; shared
+    tasks with batched targets and per-instance task lists alike; the device state is kept between calls."""
+    m = build_chain(9, free_flyer=free_flyer, seed=5, limit=2.8, velocity=6.0)
+    rng = np.random.default_rng(21)
+    B, dt = 67, 5e-3
+    q = _draw_q(m, B, rng)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    frames = ["tool0", "joint_5"]
+    shared, per_instance = [], [[] for _ in range(B)]
+    for k, f in enumerate(frames):
+        R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+        ft = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+        for b, c in enumerate(cfgs):
+            T = c.get_transform_frame_to_world(f) * exp6(0.05 * rng.normal(size=6))
+            R[b], t[b] = T.rotation, T.translation
+            fb = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+            fb.set_target(T)
+            per_instance[b].append(fb)
+        ft.set_target_poses(R, t)
+        shared.append(ft)
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    la = LowAccelerationTask(cost=0.05)
+    la.set_last_integration(0.2 * rng.normal(size=m.nv), dt)
+    jv = JointVelocityTask(cost=0.05)
+    jv.set_target(0.3 * rng.normal(size=m.nv - (6 if free_flyer else 0)), dt)
+    rest = [po, DampingTask(cost=1e-2), la, jv]
+    for b in range(B):
+        per_instance[b] += rest
+    acc = AccelerationLimit(m, np.r_[np.full(6 if free_flyer else 0, np.inf), np.full(9, 500.0)])
+    limits = [ConfigurationLimit(m, 0.7), VelocityLimit(m), acc]
+    p_tool = np.array([c.get_transform_frame_to_world("tool0").translation for c in cfgs])
+    bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[:, 2].max() + 0.02]), gain=np.array([50.0]), safe_displacement_gain=1.0)]
+    kw = dict(limits=limits, barriers=bars)
+    V = solve_ik_batch(ConfigurationBatch(m, q), shared + rest, dt, **kw)
+    assert pink_amd.last_solve_stats()["route"] == "hybrid"
+    V_host = solve_ik_batch(ConfigurationBatch(m, q), shared + rest, dt, device_kinematics=False, gpu_frame_tasks=False, **kw)
+    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+    scale = max(1.0, np.abs(V_host).max())
+    assert np.abs(V - V_host).max() < 1e-8 * scale and np.abs(V).max() > 1e-3
+    V_list = solve_ik_batch(cfgs, per_instance, dt, **kw)  # per-instance task objects, the cached device state
+    assert pink_amd.last_solve_stats()["route"] == "hybrid"
+    assert np.abs(V_list - V_host).max() < 1e-8 * scale
+    for b in range(6 if backend == "emu" else B):
+        v = solve_ik(cfgs[b], per_instance[b], dt, **kw)
+        assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
+    # a dense task that is not a FrameTask, or an equality constraint: the all-host evaluation serves the call
+    rt = RelativeFrameTask("tool0", "joint_5", 1.0, 0.0)
+    rt.set_target(cfgs[0].get_transform("tool0", "joint_5"))
+    solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [rt], dt, **kw)
+    assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
