@@ -614,7 +614,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="draco3", choices=["ur5", "draco3", "jvrc"])
+    ap.add_argument("--config", default="draco3", choices=["ur5", "draco3", "draco3b", "jvrc", "jvrc_noposture"])
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=524288, help="total instances, split over the ranks (strong scaling)")

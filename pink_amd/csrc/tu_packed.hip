@@ -37,7 +37,7 @@ hipError_t PINKHIP_LAUNCH_PACKED_NAME(PINKHIP_TU_NV, PINKHIP_TU_W, PINKHIP_TU_DE
 #ifndef PINKHIP_CLOCK_DENSE
 #define PINKHIP_CLOCK_DENSE 0  // which of the two instantiations exports the accessor
 #endif
-#if defined(PINKHIP_SECTION_CLOCK) && !defined(PINKHIP_CLOCK_SWEEP) && PINKHIP_TU_DENSE == PINKHIP_CLOCK_DENSE
+#if defined(PINKHIP_SECTION_CLOCK) && !defined(PINKHIP_CLOCK_SWEEP) && !defined(PINKHIP_CLOCK_SWEEPX) && PINKHIP_TU_DENSE == PINKHIP_CLOCK_DENSE
 // profiling builds only (scripts/section_clock.py, make DEV=1 SECTION_CLOCK=1): read and clear the per-section
 // cycle counters of this translation unit's kernel
 extern "C" int pinkhip_debug_section_clock(void *handle_unused, unsigned long long *out16) {

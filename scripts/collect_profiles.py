@@ -27,7 +27,7 @@ if os.path.exists(os.path.join(src, "rollout_bench.json")):
     shutil.copy(os.path.join(src, "rollout_bench.json"), os.path.join(dst, f"rollout_bench_{tag}.json"))
 if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"bench_{tag}.json"))
-for name in ("sq_counters.txt", "sq_counters_jvrc.txt", "section_clock.txt", "host_latency.txt", "ab_solvers.txt", "prof_pipeline.txt",
+for name in ("sq_counters.txt", "sq_counters_jvrc.txt", "sq_counters_draco3b.txt", "section_clock.txt", "host_latency.txt", "ab_solvers.txt", "prof_pipeline.txt",
              "fuzz.txt", "fuzz_rollout.txt"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
         shutil.copy(os.path.join(src, name), os.path.join(dst, name.replace(".txt", f"_{tag}.txt")))

@@ -28,6 +28,8 @@ def build():
     default the headline one; the sweep-tableau kernel exports the counters unless PINKHIP_SOLVER=packed)."""
     nv, md, w = (os.environ.get(k, d) for k, d in (("CLOCK_NV", "30"), ("CLOCK_MD", "0"), ("CLOCK_W", "32")))
     extra = "" if os.environ.get("PINKHIP_SOLVER") == "packed" else "-DPINKHIP_CLOCK_SWEEP"
+    if os.environ.get("PINKHIP_SOLVER") != "packed" and int(nv) + int(md) > int(w):
+        extra = "-DPINKHIP_CLOCK_SWEEPX"  # (more tableau rows than lanes: the kernel with virtual dense rows, ik_sweepx.h)
     if os.environ.get("PINKHIP_SOLVER") == "packed" and md != "0":
         extra = "-DPINKHIP_CLOCK_DENSE=1"
     out = os.environ.get("CLOCK_OUT", "libpinkhip_clock.so")
@@ -46,8 +48,6 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "draco3"
     bounds = sys.argv[2] if len(sys.argv) > 2 else "tight"
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
-    if name == "draco3b":  # the headline robot with two barrier rows (DENSE instantiation; build with EXTRA=-DPINKHIP_CLOCK_DENSE=1)
-        synthetic.CONFIGS["draco3b"] = dict(synthetic.CONFIGS["draco3"], n_barriers=2, config_id=13)
     s = BatchSolver(0)
     lib = _lib.load_library()
     lib.pinkhip_debug_section_clock.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
