@@ -230,6 +230,15 @@ def _vector_joints_only(limit) -> bool:
     return all(j.kind != "free_flyer" for j in getattr(limit, "joints", ()))
 
 
+def _index(idx):
+    """``idx`` as a slice when it is a run of consecutive integers (the actuated coordinates of a robot usually are):
+    basic indexing of ``[B, n]`` arrays instead of a gather and a scatter."""
+    idx = np.asarray(idx)
+    if idx.size and (np.diff(idx) == 1).all():
+        return slice(int(idx[0]), int(idx[-1]) + 1)
+    return idx
+
+
 def limit_rows(kin: BatchKinematics, limit, dt: float, lb_: np.ndarray, ub_: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
     """Fold ``limit`` into the merged box ``lb_, ub_ [B, nv]`` (in place); returns its dense rows ``(G [B, r, nv],
     h [B, r])`` if it has any.  ``pink/solve_ik.py:107-122`` with every ``+-e_i`` row merged per coordinate."""
@@ -244,19 +253,21 @@ def limit_rows(kin: BatchKinematics, limit, dt: float, lb_: np.ndarray, ub_: np.
         # pink/limits/configuration_limit.py:111-120: gain (q_max (-) q), gain (q_min (-) q) on the bounded joints
         if limit.projection_matrix is None:
             return None
-        idx = limit.indices
-        iq = np.array([j.idx_q for j in limit.joints], dtype=int)
+        idx = _index(limit.indices)
+        iq = _index([j.idx_q for j in limit.joints])
         g = limit.config_limit_gain
-        lo = g * (limit.model.lowerPositionLimit[iq] - kin.q[:, iq])
-        up = g * (limit.model.upperPositionLimit[iq] - kin.q[:, iq])
-        lb_[:, idx] = np.maximum(lb_[:, idx], lo)
-        ub_[:, idx] = np.minimum(ub_[:, idx], up)
+        qi = kin.q[:, iq]
+        lo = g * (limit.model.lowerPositionLimit[iq] - qi)
+        up = g * (limit.model.upperPositionLimit[iq] - qi)
+        np.maximum(lb_[:, idx], lo, out=lo)
+        np.minimum(ub_[:, idx], up, out=up)
+        lb_[:, idx], ub_[:, idx] = lo, up
         return None
     if ty is VelocityLimit:
         # pink/limits/velocity_limit.py:118-120
         if limit.projection_matrix is None:
             return None
-        idx = limit.indices
+        idx = _index(limit.indices)
         v = dt * limit.velocity_limit[idx]
         lb_[:, idx] = np.maximum(lb_[:, idx], -v)
         ub_[:, idx] = np.minimum(ub_[:, idx], v)

@@ -174,18 +174,30 @@ class BatchKinematics:
         m = self.model
         q0, q1 = np.asarray(q0, dtype=float), np.asarray(q1, dtype=float)
         out = np.zeros((self.B, m.nv))
+        # vector-space joints: q1 - q0, runs of consecutive coordinates in one slice each
+        vj = [j for j in m.joints if j.kind != "free_flyer"]
+        k = 0
+        while k < len(vj):
+            e = k
+            while e + 1 < len(vj) and vj[e + 1].idx_q == vj[e].idx_q + 1 and vj[e + 1].idx_v == vj[e].idx_v + 1:
+                e += 1
+            n = e - k + 1
+            out[:, vj[k].idx_v:vj[k].idx_v + n] = q1[..., vj[k].idx_q:vj[k].idx_q + n] - q0[..., vj[k].idx_q:vj[k].idx_q + n]
+            k = e + 1
         for j in m.joints:
-            if j.kind == "free_flyer":
-                a = np.broadcast_to(q0[..., j.idx_q:j.idx_q + 7], (self.B, 7))
-                c = np.broadcast_to(q1[..., j.idx_q:j.idx_q + 7], (self.B, 7))
-                fin = np.isfinite(a).all(axis=1) & np.isfinite(c).all(axis=1)
-                out[:, j.idx_v:j.idx_v + 6] = np.inf  # "difference to an infinite limit": no limit
-                if fin.any():
-                    R0, p0 = lb.quat_to_rot(a[fin, 3:]), a[fin, :3]
-                    R1, p1 = lb.quat_to_rot(c[fin, 3:]), c[fin, :3]
-                    out[fin, j.idx_v:j.idx_v + 6] = lb.log6(*lb.act_inv(R0, p0, R1, p1))
-            else:
-                out[:, j.idx_v] = q1[..., j.idx_q] - q0[..., j.idx_q]
+            if j.kind != "free_flyer":
+                continue
+            a = np.broadcast_to(q0[..., j.idx_q:j.idx_q + 7], (self.B, 7))
+            c = np.broadcast_to(q1[..., j.idx_q:j.idx_q + 7], (self.B, 7))
+            fin = np.isfinite(a).all(axis=1) & np.isfinite(c).all(axis=1)
+            if fin.all():
+                out[:, j.idx_v:j.idx_v + 6] = lb.log6(*lb.act_inv(lb.quat_to_rot(a[:, 3:]), a[:, :3], lb.quat_to_rot(c[:, 3:]), c[:, :3]))
+                continue
+            out[:, j.idx_v:j.idx_v + 6] = np.inf  # "difference to an infinite limit": no limit
+            if fin.any():
+                R0, p0 = lb.quat_to_rot(a[fin, 3:]), a[fin, :3]
+                R1, p1 = lb.quat_to_rot(c[fin, 3:]), c[fin, :3]
+                out[fin, j.idx_v:j.idx_v + 6] = lb.log6(*lb.act_inv(R0, p0, R1, p1))
         return out
 
     def d_difference(self, q0: np.ndarray, q1: np.ndarray) -> Optional[np.ndarray]:
