@@ -314,11 +314,14 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
         out["headline_shape_arrays"] = api_level_arrays(Bh)
         if hasattr(solver, "pinned_empty"):
             out["headline_shape_arrays_page_locked"] = api_level_arrays(Bh, pinned=True)
-        # one task more than the whole-step kernel forms on chip (a DampingTask): the FrameTask rows are still formed on
-        # the device from q (pink_amd/hybrid.py), the rest evaluated on the host for the whole batch; and the same call
-        # with everything evaluated on the host (vectorised NumPy kinematics) beside it
+        # the task stack of the reference's own humanoid example (examples/humanoid_draco3.py:34-71: FrameTasks, a
+        # PostureTask, two JointCouplingTasks) and one with a DampingTask: formed on chip by the whole-step kernel from
+        # constant tables; beside them the same calls with only the FrameTask rows formed on the device
+        # (pink_amd/hybrid.py: the route of stacks the kernel does not form) and with everything evaluated on the host
+        out["reference_example_stack"] = api_level_arrays(Bh, extra_task="couplings")
         out["headline_shape_plus_damping_task"] = api_level_arrays(Bh, extra_task="damping")
-        out["headline_shape_plus_damping_task_all_host"] = api_level_arrays(Bh, extra_task="damping", all_host=True)
+        out["headline_shape_plus_damping_task_frame_rows_only"] = api_level_arrays(Bh, extra_task="damping", route="frame_rows")
+        out["headline_shape_plus_damping_task_all_host"] = api_level_arrays(Bh, extra_task="damping", route=False)
         return out
     finally:
         pink_amd.clear_device_cache()
@@ -368,7 +371,7 @@ def api_level_host_evaluated(m, B: int) -> dict:
             "max_abs_velocity_difference_vs_per_configuration_solve_ik_on_sample": float(np.abs(v[:n] - np.array(v_ref)).max()), "sample": n}
 
 
-def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, all_host: bool = False) -> dict:
+def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=None) -> dict:
     """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
     with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
     array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
@@ -400,21 +403,28 @@ def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, all_hos
     post = PostureTask(cost=1e-1)
     post.set_target(m.neutral())
     tasks.append(post)
-    if extra_task == "damping":  # one task the whole-step kernel does not form on chip: the call takes the host-evaluated route
+    if extra_task == "damping":
         from pink_amd import DampingTask
 
         tasks.append(DampingTask(cost=1e-2))
+    elif extra_task == "couplings":  # (humanoid_draco3.py:57-70: two knee couplings, cost 100, lm_damping 5e-7)
+        from pink_amd.tasks import JointCouplingTask
+
+        tasks.append(JointCouplingTask(["joint_3", "joint_4"], [1.0, -1.0], 100.0, ref, lm_damping=5e-7))
+        tasks.append(JointCouplingTask(["joint_9", "joint_10"], [1.0, -1.0], 100.0, ref, lm_damping=5e-7))
     cfgs = ConfigurationBatch(m, q)
     dt = 5e-3
     v_out = alloc((B, m.nv)) if pinned else None
-    route_kw = dict(device_kinematics=False) if all_host else {}  # (all_host: every task evaluated on the host, for comparison)
+    all_host = route is False
+    route_kw = {} if route is None else dict(device_kinematics=route)  # (False: every task evaluated on the host, for comparison)
     v = solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw)  # builds the device state
     stats = pink_amd.last_solve_stats()
     ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw), 5 if not all_host else 2)
     t_call = statistics.median(ts)
     n = min(B, 16)
     v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False)
-    return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask" + (" + DampingTask" if extra_task else "") +
+    return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask" +
+                        {"": "", "damping": " + DampingTask", "couplings": " + 2 JointCouplingTasks"}[extra_task] +
                         f", default limits, B = {B} as ConfigurationBatch, targets as arrays",
             "route": stats.get("route"), "solver_paths": stats.get("paths"),
             "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,

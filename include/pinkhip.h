@@ -273,7 +273,8 @@ int pinkhip_step_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B
  * QP solve and q <- q (+) dq -- the task Jacobians never reach memory (they are formed from the joints' world
  * twists while the objective is stacked).  `desc` describes the task stack of the model: one 6-row dense task per
  * model frame (in frame order: Kd = 6 nf), optionally followed by one diagonal task on the actuated coordinates
- * (the PostureTask: col0 = root_nv, nv - root_nv rows); box limits, plus md rows of position barriers (below).  Returns
+ * (the PostureTask: col0 = root_nv, nv - root_nv rows) -- and, since version 110, constant-row dense tasks and further
+ * diagonal tasks (fields at the end of the struct); box limits, plus md rows of position barriers (below).  Returns
  * PINKHIP_E_UNSUPPORTED when no instantiation fits the model (nv > 56, or a group of lanes cannot hold the
  * joints / the kinematics scratch): use pinkhip_step_device + pinkhip_solve_device then. */
 typedef struct pinkhip_rollout_step {
@@ -313,6 +314,21 @@ typedef struct pinkhip_rollout_step {
   double dq_scale;           /* what is written to dq is the displacement times this (0: 1).  1 / dt hands out the
                                 velocity pink.solve_ik returns (pink/solve_ik.py:274) without another pass over the
                                 array; only with integrate = 0 */
+  /* Tasks beyond "one FrameTask per model frame + a PostureTask" that the kernel also forms on chip.
+   *  - dense tasks with a CONSTANT Jacobian (LinearHolonomicTask / JointCouplingTask on vector-space joints,
+   *    pink/tasks/linear_holonomic_task.py:103-148, joint_coupling_task.py: e = A (q (-) q_0) - b, J = A): the dense
+   *    tasks of desc behind the nf frame tasks, n_const_rows rows in all (desc.Kd = 6 nf + n_const_rows);
+   *  - diagonal tasks with BATCH-CONSTANT errors (DampingTask: 0, LowAccelerationTask: -dt v_prev, JointVelocityTask:
+   *    -dt v*; pink/tasks/damping_task.py, low_acceleration_task.py:46-84, joint_velocity_task.py:59-110): every
+   *    diagonal task of desc except number `posture_task` (counted among the diagonal tasks; -1: no PostureTask), whose
+   *    error is q (-) q_target.  Their errors are read from diag_error at row - desc.Kd.
+   * All zero (a zero-initialised struct): the stack of before -- frame tasks + at most one diagonal task = the posture. */
+  int32_t n_const_rows;
+  const double *const_rows;  /* [n_const_rows, nv] device: A */
+  const double *const_q0;    /* [nq] device: q_0 */
+  const double *const_b;     /* [n_const_rows] device */
+  int32_t posture_task;
+  const double *diag_error;  /* [desc.K - desc.Kd] device */
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);

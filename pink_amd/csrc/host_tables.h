@@ -104,4 +104,31 @@ inline bool rank_deficient_by_construction(const pinkhip_desc &d) {
   return true;
 }
 
+// Task layout of the whole-step kernel (pinkhip_rollout_step_device; shared with the test emulator): nf FrameTasks of six
+// dense rows, then the constant-row dense tasks (n_const_rows rows in all), then diagonal tasks; the diagonal task
+// number `posture_task` (counted among the diagonal ones; negative: none) is the PostureTask, which must cover the
+// actuated coordinates.  Returns an error text ("" = fine) and the rows of the posture task.
+inline std::string rollout_task_layout(const pinkhip_desc &d, int nf, int nv, int root_nv, int n_const_rows, int posture_task,
+                                       bool have_diag_error, int &post_row0, int &post_k) {
+  post_row0 = post_k = 0;
+  if (d.Kd != 6 * nf + n_const_rows) return "descriptor does not describe this model's task stack (Kd = 6 nf + n_const_rows)";
+  int t = 0, crow_seen = 0, n_diag = 0;
+  for (; t < nf && t < d.T; ++t)
+    if (d.task_kind[t] != PINKHIP_TASK_DENSE || d.task_rows[t + 1] - d.task_rows[t] != 6) return "frame tasks must be dense with six rows each";
+  if (t != nf) return "expected one dense task per frame";
+  for (; t < d.T && d.task_kind[t] == PINKHIP_TASK_DENSE; ++t) crow_seen += d.task_rows[t + 1] - d.task_rows[t];
+  if (crow_seen != n_const_rows) return "dense tasks behind the frame tasks must add up to n_const_rows rows";
+  for (; t < d.T; ++t, ++n_diag) {
+    if (d.task_kind[t] != PINKHIP_TASK_DIAGONAL) return "dense tasks must precede diagonal ones";
+    if (n_diag == posture_task) {
+      post_row0 = d.task_rows[t];
+      post_k = d.task_rows[t + 1] - d.task_rows[t];
+      if (d.task_col0[t] != root_nv || post_k != nv - root_nv) return "the posture task must cover the actuated coordinates";
+    }
+  }
+  if (posture_task >= n_diag && n_diag > 0) return "posture_task is not one of the diagonal tasks";
+  if (n_diag > (post_k ? 1 : 0) && !have_diag_error) return "diagonal tasks other than the posture task need diag_error";
+  return "";
+}
+
 }  // namespace pinkhip

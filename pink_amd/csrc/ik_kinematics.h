@@ -229,7 +229,7 @@ __device__ __host__ inline int fk_lds_doubles(int nj, int nf) { return 12 * (nj 
 struct HbmSink {
   static constexpr bool kKeep = false;
   double *es = nullptr;
-  double lin[3], ang[3], lb, ub, post_e;
+  double lin[3], ang[3], lb, ub, post_e, qv;
   unsigned anc;
 };
 
@@ -467,6 +467,7 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
         sink->lb = lo;
         sink->ub = hi;
         sink->post_e = 0.0;
+        sink->qv = qi;  // (the coordinate's own scalar configuration: errors of constant-row tasks, ik_rollout.h)
         if (a.q_target && ty != JOINT_FREE_FLYER && j >= m.root_nv) {
           const int iq = m.idx_q[jt];
           sink->post_e = qi - (a.target_batched ? a.q_target[b * m.nq + iq] : a.q_target[iq]);

@@ -35,10 +35,22 @@ struct RolloutArgs {
   // tables are indexed by d - n_lim.
   int n_lim = 0;
   const double *lim_rows = nullptr, *lim_h = nullptr;
+  // Dense tasks with a constant Jacobian (LinearHolonomicTask / JointCouplingTask on vector-space joints,
+  // pink/tasks/linear_holonomic_task.py:103-148: e = A (q (-) q_0) - b, J = A): n_crow rows BEHIND the 6 nf FrameTask
+  // rows of the dense block (k.Kd = 6 nf + n_crow); A [n_crow, nv], q_0 [nq], b [n_crow] in device memory
+  int n_crow = 0;
+  const double *crow_A = nullptr, *crow_q0 = nullptr, *crow_b = nullptr;
+  // Diagonal tasks: the one whose error is q (-) q_target (the PostureTask) occupies the rows post_row0 .. + post_k of
+  // e; every other diagonal task has batch-constant errors (DampingTask: 0, LowAccelerationTask: -dt v_prev,
+  // JointVelocityTask: -dt v*; pink/tasks/damping_task.py, low_acceleration_task.py:46-84, joint_velocity_task.py:59-110)
+  // read from diag_e [K - Kd] at row - Kd
+  int post_row0 = 0, post_k = 0;
+  const double *diag_e = nullptr;
 };
 
-// doubles of kinematics scratch per robot: joint poses, ancestor pointers, U / V blocks, frame errors, joint scalars
-__device__ __host__ inline int rollout_fk_doubles(int nj, int nf) { return fk_lds_doubles(nj, nf) + 6 * nf; }
+// doubles of kinematics scratch per robot: joint poses, ancestor pointers, U / V blocks, frame errors (+ the errors of
+// n_crow constant rows), joint scalars
+__device__ __host__ inline int rollout_fk_doubles(int nj, int nf, int n_crow = 0) { return fk_lds_doubles(nj, nf) + 6 * nf + ((n_crow + 1) & ~1); }
 
 template <int W>
 struct FkTerms {
@@ -46,12 +58,23 @@ struct FkTerms {
   static constexpr bool kKeep = true;
   double lb = 0.0, ub = 0.0, x = 0.0;
   int status = 0;
-  double lin[3], ang[3], post_e = 0.0;
+  double lin[3], ang[3], post_e = 0.0, qv = 0.0;
   unsigned anc = 0;
-  double *es = nullptr;        // LDS: frame-task errors [6 nf]
+  double *es = nullptr;        // LDS: errors of the dense rows [6 nf + n_crow]
   const double *UV = nullptr;  // LDS: U (9), V (9) per frame, pitch 36
-  // this lane's entries (tangent column li) of the six rows of FrameTask f
+  int nf = 0, n_crow = 0, col = 0, nvc = 0;  // frames, constant rows, this lane's tangent column, row pitch of crow_A
+  const double *crow_A = nullptr;
+  int post_row0 = 0, post_k = 0, Kd = 0;
+  const double *diag_e = nullptr;
+  // this lane's entries (tangent column li) of the six rows of FrameTask f -- or, behind the frames, of the next six
+  // constant rows (their Jacobian is a table)
   __device__ __forceinline__ void frame_rows(int f, double (&six)[6]) const {
+    if (f >= nf) {
+      const int r0 = 6 * (f - nf);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) six[i] = (r0 + i < n_crow) ? crow_A[(long long)(r0 + i) * nvc + col] : 0.0;
+      return;
+    }
     const double *u = UV + 36 * f;
     const bool on = ((anc >> f) & 1u) != 0;
 #pragma unroll
@@ -64,7 +87,10 @@ struct FkTerms {
     }
   }
   __device__ __forceinline__ double error(int k) const { return es[k]; }
-  __device__ __forceinline__ double diag_error(int) const { return post_e; }
+  __device__ __forceinline__ double diag_error(int r) const {
+    if (r >= post_row0 && r < post_row0 + post_k) return post_e;
+    return diag_e ? diag_e[r - Kd] : 0.0;
+  }
   // dense rows = position barriers: this lane's entry (tangent column li) of row d, and the row's right-hand side.
   // World velocity of the frame origin p_f per unit of this column's joint velocity: lin + ang x p_f (zero unless the
   // joint is an ancestor of the frame) = column li of R J_lin (position_barrier.py:136-145).
@@ -113,6 +139,8 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     FkTerms<W> tt;
     tt.es = sm + fk_lds_doubles(mm.nj, mm.nf);
     tt.UV = sm + 12 * (mm.nj + mm.nf) + ((mm.nj + 1) & ~1);  // = Jls of ik_fk_instance
+    tt.nf = mm.nf, tt.n_crow = ra.n_crow, tt.col = li < mm.nv ? li : 0, tt.nvc = mm.nv, tt.crow_A = ra.crow_A;
+    tt.post_row0 = ra.post_row0, tt.post_k = ra.post_k, tt.Kd = ra.k.Kd, tt.diag_e = ra.diag_e;
     if constexpr (MD > 0) {
       tt.bar_frame = ra.bar_frame, tt.bar_axis = ra.bar_axis;
       tt.bar_sign = ra.bar_sign, tt.bar_bound = ra.bar_bound, tt.bar_gain = ra.bar_gain;
@@ -135,6 +163,20 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
       wave_sync();
     }
   };
+  // errors of the constant-row tasks, e_r = A_r (q (-) q_0) - b_r on the vector-space joints, behind the frame errors in LDS
+  auto const_row_errors = [&](const RolloutArgs &ra, const FkTerms<W> &tt) {
+    if (ra.n_crow > 0) {  // wave-uniform (kernel argument)
+      const ModelDev &mm = ra.fk.m;
+      const int jt = mm.dof_joint[li < mm.nv ? li : 0];
+      const bool vec = li < mm.nv && mm.jtype[jt] != JOINT_FREE_FLYER;
+      const double dqv = vec ? tt.qv - ra.crow_q0[mm.idx_q[jt]] : 0.0;
+      for (int r = 0; r < ra.n_crow; ++r) {
+        const double er = group_sum<W>(vec ? ra.crow_A[(long long)r * mm.nv + li] * dqv : 0.0) - ra.crow_b[r];
+        if (li == 0) tt.es[6 * mm.nf + r] = er;
+      }
+      wave_sync();
+    }
+  };
   // A task stack that is rank deficient by construction (host_tables.h: FrameTasks alone on more coordinates than they
   // have rows, examples/humanoid_jvrc.py:69-81) goes to the Goldfarb-Idnani code right away (kernel argument:
   // wave-uniform; its kinematics pass is the one below); everything else through the sweep tableau.
@@ -145,6 +187,7 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     ik_fk_instance<W, true, true, FkTerms<W>>(a.fk, block, &t, sm);
     wave_sync();
     keep_frame_positions(a);
+    const_row_errors(a, t);
     // (more tableau rows than lanes: the dense rows are virtual, ik_sweepx.h -- two robots per wavefront at nv = 30
     // with barrier rows instead of one)
     if constexpr (NV + MD > W) st_sweep = ik_sweepx_instance<NV, MD, W, FkTerms<W>>(a.k, block, &t);
@@ -162,6 +205,7 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     ik_fk_instance<W, true, true, FkTerms<W>>(again->fk, block, &t2, sm);
     wave_sync();
     keep_frame_positions(*again);
+    const_row_errors(*again, t2);
     ik_packed_instance<NV, W, (MD > 0), FkTerms<W>>(again->k, block, &t2, over,
                                                      again->k.rank_deficient ? PATH_GI : (st_sweep == STATUS_ROUTED ? PATH_ROUTED : PATH_HANDOVER));
     if (over) t.x = t2.x, t.status = t2.status;

@@ -799,8 +799,11 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   if (rc) return rc;
   const pinkhip::ModelDev &md = m->dev;
   if (desc->B == 0) return PINKHIP_OK;
-  if (desc->nv != md.nv || desc->Kd != 6 * md.nf || desc->n_eq != 0)
-    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, Kd = 6 nf, n_eq = 0)");
+  const int n_crow = st->n_const_rows;
+  if (n_crow < 0 || (n_crow > 0 && (!st->const_rows || !st->const_q0 || !st->const_b)))
+    return fail(h, PINKHIP_E_INVALID, "n_const_rows must be >= 0 and come with const_rows / const_q0 / const_b");
+  if (desc->nv != md.nv || desc->n_eq != 0)
+    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, n_eq = 0)");
   if (st->n_limit_rows < 0 || st->n_limit_rows > desc->md || (st->n_limit_rows > 0 && (!st->limit_rows || !st->limit_h)))
     return fail(h, PINKHIP_E_INVALID, "n_limit_rows must lie in [0, md] and come with limit_rows / limit_h");
   if (desc->md > st->n_limit_rows &&
@@ -808,18 +811,24 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     return fail(h, PINKHIP_E_INVALID, "rows of position barriers need the barrier_* tables");
   if ((st->root_box || st->n_limit_rows) && md.root_nv != 6)
     return fail(h, PINKHIP_E_INVALID, "a floating-base velocity limit needs a free-flyer root joint");
-  const int n_post = desc->K - desc->Kd;
-  if (desc->T != md.nf + (n_post ? 1 : 0)) return fail(h, PINKHIP_E_INVALID, "expected one dense task per frame (+ one diagonal task)");
-  for (int t = 0; t < md.nf; ++t)
-    if (desc->task_kind[t] != PINKHIP_TASK_DENSE || desc->task_rows[t + 1] - desc->task_rows[t] != 6)
-      return fail(h, PINKHIP_E_INVALID, "frame tasks must be dense with six rows each");
-  if (n_post && (desc->task_kind[md.nf] != PINKHIP_TASK_DIAGONAL || desc->task_col0[md.nf] != md.root_nv || n_post != md.nv - md.root_nv))
-    return fail(h, PINKHIP_E_INVALID, "the diagonal task must cover the actuated coordinates");
+  int post_row0 = 0, post_k = 0;
+  {
+    const std::string why = pinkhip::rollout_task_layout(*desc, md.nf, md.nv, md.root_nv, n_crow, st->posture_task, st->diag_error != nullptr, post_row0, post_k);
+    if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
+  }
+  const int n_post = post_k;
   if (!st->q || !st->cost || !st->dq || !st->status || (md.nf > 0 && !st->T_target) || (n_post && !st->q_target))
     return fail(h, PINKHIP_E_INVALID, "null pointer");
   if (!(st->config_limit_gain > 0.0 && st->config_limit_gain <= 1.0) || st->step < 0 || st->step >= (1 << 23))
     return fail(h, PINKHIP_E_INVALID, "bad limit gain / step");
-  const int fkd = pinkhip::rollout_fk_doubles(md.nj, md.nf);
+  const int fkd = pinkhip::rollout_fk_doubles(md.nj, md.nf, n_crow);
+  ra.n_crow = n_crow;
+  ra.crow_A = st->const_rows;
+  ra.crow_q0 = st->const_q0;
+  ra.crow_b = st->const_b;
+  ra.post_row0 = post_row0;
+  ra.post_k = post_k;
+  ra.diag_e = st->diag_error;
   pinkhip::PackedChoice pc{0, 0};
   pinkhip::SweepChoice dc{0, 0, 0};
   if (desc->md > 0) {

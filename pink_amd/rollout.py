@@ -138,7 +138,12 @@ class DeviceRollout:
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
-                 position_barriers: Sequence = (), floating_base_limit=None):
+                 position_barriers: Sequence = (), floating_base_limit=None, const_tasks: Sequence = (),
+                 diag_tasks: Sequence = ()):
+        """``const_tasks``: dense tasks with a constant Jacobian, ``(A [k, nv], b [k], q_0 [nq], cost, gain, lm_damping)``
+        each (LinearHolonomicTask / JointCouplingTask on vector-space joints); ``diag_tasks``: identity-Jacobian tasks
+        with batch-constant errors, ``(col0, e [k], cost, gain, lm_damping)`` each (DampingTask, LowAccelerationTask,
+        JointVelocityTask).  Both need the whole-step kernel (``fused="kernel"``)."""
         self.api, self.model, self.dt = api, model, float(dt)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
@@ -149,22 +154,56 @@ class DeviceRollout:
         self.dmodel = api.model_create(self.arrays.desc)
         nf, nv, nq = len(self.frames), self.nv, self.nq
         root_nv = get_root_joint_dim(model)[1]
-        self.Kd = 6 * nf
+        if (const_tasks or diag_tasks) and self.fused != "kernel":
+            raise ValueError('constant-row and extra diagonal tasks need the whole-step kernel: fused="kernel"')
+        const_tasks = [(np.atleast_2d(np.asarray(A, dtype=np.float64)), np.atleast_1d(np.asarray(b, dtype=np.float64)),
+                        np.asarray(q_0, dtype=np.float64), c, g, l) for A, b, q_0, c, g, l in const_tasks]
+        diag_tasks = [(int(c0), np.atleast_1d(np.asarray(e, dtype=np.float64)), c, g, l) for c0, e, c, g, l in diag_tasks]
+        self.n_crow = sum(A.shape[0] for A, *_ in const_tasks)
+        if any(A.shape[1] != nv or q_0.shape != (nq,) for A, _, q_0, *_ in const_tasks):
+            raise ValueError("constant-row tasks: A must be [k, nv] and q_0 [nq]")
+        if self.n_crow and any(not np.array_equal(q_0, const_tasks[0][2]) for _, _, q_0, *_ in const_tasks):
+            raise ValueError("constant-row tasks must share one reference configuration q_0")
+        self.Kd = 6 * nf + self.n_crow
         n_post = nv - root_nv if posture_cost is not None else 0
-        self.K = self.Kd + n_post
-        # task tables of the QP (include/pinkhip.h: dense tasks first, then the diagonal one)
-        T = nf + (1 if n_post else 0)
-        self.task_rows = np.ascontiguousarray([6 * i for i in range(nf + 1)] + ([self.K] if n_post else []), dtype=np.int32)
-        self.task_kind = np.ascontiguousarray([0] * nf + ([1] if n_post else []), dtype=np.int32)
-        self.task_col0 = np.ascontiguousarray([0] * nf + ([root_nv] if n_post else []), dtype=np.int32)
-        self.gain = np.ascontiguousarray([ft[3] for ft in frame_tasks] + ([posture_gain] if n_post else []), dtype=np.float64)
-        self.lm = np.ascontiguousarray([ft[4] for ft in frame_tasks] + ([posture_lm_damping] if n_post else []), dtype=np.float64)
-        cost = []
+        self.K = self.Kd + n_post + sum(e.shape[0] for _, e, *_ in diag_tasks)
+        # task tables of the QP (include/pinkhip.h: frame tasks, constant-row tasks, then the diagonal ones: the posture first)
+        rows, kind, col0, gain, lm, cost = [0], [], [], [], [], []
         for ft in frame_tasks:
+            rows.append(rows[-1] + 6), kind.append(0), col0.append(0), gain.append(ft[3]), lm.append(ft[4])
             cost += list(np.broadcast_to(np.asarray(ft[1], float), (3,))) + list(np.broadcast_to(np.asarray(ft[2], float), (3,)))
+        for A, b, _, c, g, l in const_tasks:
+            k = A.shape[0]
+            rows.append(rows[-1] + k), kind.append(0), col0.append(0), gain.append(g), lm.append(l)
+            cost += list(np.broadcast_to(np.ones(k) if c is None else np.asarray(c, float), (k,)))
         if n_post:
+            rows.append(rows[-1] + n_post), kind.append(1), col0.append(root_nv), gain.append(posture_gain), lm.append(posture_lm_damping)
             cost += [float(posture_cost)] * n_post
+        for c0, e, c, g, l in diag_tasks:
+            k = e.shape[0]
+            if c0 < 0 or c0 + k > nv:
+                raise ValueError("diagonal task exceeds the tangent space")
+            rows.append(rows[-1] + k), kind.append(1), col0.append(c0), gain.append(g), lm.append(l)
+            cost += list(np.broadcast_to(np.ones(k) if c is None else np.asarray(c, float), (k,)))
+        T = len(kind)
+        self.task_rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.task_kind = np.ascontiguousarray(kind if kind else [0], dtype=np.int32)
+        self.task_col0 = np.ascontiguousarray(col0 if col0 else [0], dtype=np.int32)
+        self.gain = np.ascontiguousarray(gain if gain else [0.0], dtype=np.float64)
+        self.lm = np.ascontiguousarray(lm if lm else [0.0], dtype=np.float64)
         self.cost = np.ascontiguousarray(cost if cost else [0.0], dtype=np.float64)
+        self.posture_task = 0 if n_post else -1
+        # errors of the diagonal rows behind the dense block (the posture's rows are formed on chip: left at zero)
+        self._diag_e = np.zeros(max(self.K - self.Kd, 1))
+        off = n_post
+        for _, e, *_ in diag_tasks:
+            self._diag_e[off:off + e.shape[0]] = e
+            off += e.shape[0]
+        self._const = None
+        if self.n_crow:
+            self._const = (np.ascontiguousarray(np.vstack([A for A, *_ in const_tasks])),
+                           np.ascontiguousarray(const_tasks[0][2]), np.ascontiguousarray(np.hstack([b for _, b, *_ in const_tasks])))
+        self._extra_tasks = bool(const_tasks or diag_tasks)
         # position barriers (pink/barriers/position_barrier.py): one dense row per (index, side), rows in Pink's order
         # (p_min rows, then p_max rows); formed on chip by the whole-step kernel (fused="kernel" only)
         # FloatingBaseVelocityLimit (pink/limits/floating_base_velocity_limit.py:104-148): the Jacobian of a frame attached
@@ -228,7 +267,12 @@ class DeviceRollout:
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self.d_qt = f8(B, nq)
-        self.d_bar, self.d_lim = [], []
+        self.d_bar, self.d_lim, self.d_extra = [], [], []
+        if self._extra_tasks:  # tables of the constant-row tasks and the batch-constant errors of the extra diagonal tasks
+            for arr in ([self._diag_e] + (list(self._const) if self._const else [])):
+                ptr = a.alloc(max(arr.nbytes, 8))
+                a.put(ptr, arr)
+                self.d_extra.append(ptr)
         for arr in ([] if self.root_box is None else [self.root_box, np.ascontiguousarray(self.lim_rows), self.lim_h]):
             ptr = a.alloc(max(arr.nbytes, 8))
             if arr.nbytes:
@@ -327,6 +371,8 @@ class DeviceRollout:
         self.scaled = False
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             self.scaled = False  # (no whole-step kernel for this model: the launches below write dq unscaled)
+            if self._extra_tasks:
+                raise NoWholeStepKernel("no whole-step kernel instantiation fits this model: constant-row / extra diagonal tasks need it")
             if self.md:
                 raise NoWholeStepKernel("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
             self.fused = True  # no instantiation for this model: two launches from now on
@@ -437,6 +483,7 @@ class DeviceRollout:
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
         self._scale_out(st, integrate)
+        self._extra(st)
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
         if self.d_bar:
@@ -445,6 +492,28 @@ class DeviceRollout:
             st.root_box, st.limit_rows, st.limit_h = self.d_lim
             st.n_limit_rows = len(self.lim_h)
         return self.api.rollout_step(self.desc, self.dmodel, st)
+
+    def set_diag_errors(self, errors: Sequence[np.ndarray]) -> None:
+        """New batch-constant errors of the extra diagonal tasks (``diag_tasks`` of the constructor, in that order): a
+        LowAccelerationTask / JointVelocityTask changes them every control step."""
+        off = self.n_post
+        for e in errors:
+            e = np.atleast_1d(np.asarray(e, dtype=np.float64))
+            self._diag_e[off:off + e.shape[0]] = e
+            off += e.shape[0]
+        if off != max(self.K - self.Kd, 0):
+            raise ValueError("errors do not match the diagonal tasks of this rollout")
+        if self.d_extra:
+            self.api.put(self.d_extra[0], self._diag_e)
+
+    def _extra(self, st) -> None:
+        """The fields of ``pinkhip_rollout_step`` that describe tasks beyond frames + posture."""
+        st.posture_task = self.posture_task
+        if self._extra_tasks:
+            st.diag_error = self.d_extra[0]
+            if self._const:
+                st.n_const_rows = self.n_crow
+                st.const_rows, st.const_q0, st.const_b = self.d_extra[1:4]
 
     def _scale_out(self, st, integrate: bool) -> None:
         """``velocity_out``: a solve without integration writes ``dq / dt`` -- the velocity ``solve_ik`` returns
@@ -468,6 +537,7 @@ class DeviceRollout:
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
         self._scale_out(st, integrate)
+        self._extra(st)
         st.sT_b, st.sT_f = 12, 12 * self.B
         if self.d_lim:
             st.root_box = self.d_lim[0]
@@ -558,7 +628,7 @@ class DeviceRollout:
     def free(self) -> None:
         for name in self._BUFFERS:
             self.api.release(getattr(self, name, None))
-        for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []):
+        for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []) + getattr(self, "d_extra", []):
             self.api.release(ptr)
-        self.d_bar, self.d_lim = [], []
+        self.d_bar, self.d_lim, self.d_extra = [], [], []
         self.api.model_destroy(self.dmodel)

@@ -434,8 +434,51 @@ def _barrier_key(bar):
             float(bar.safe_displacement_gain))
 
 
+def _extra_task(model, t):
+    """What the whole-step kernel forms on chip beyond FrameTasks and the PostureTask, for a task object shared by the
+    whole batch: ``("const", A, b, q_0, cost, gain, lm)`` -- a dense task with a constant Jacobian
+    (LinearHolonomicTask / JointCouplingTask whose ``A`` has no entry on free-flyer coordinates:
+    ``pink/tasks/linear_holonomic_task.py:103-148``) -- or ``("diag", col0, e, cost, gain, lm)`` -- an identity-Jacobian
+    task with a batch-constant error (``damping_task.py``, ``low_acceleration_task.py:46-84``,
+    ``joint_velocity_task.py:59-110``) -- or ``None``."""
+    from .tasks.linear_holonomic_task import JointCouplingTask, JointVelocityTask, LinearHolonomicTask
+    from .tasks.posture_task import DampingTask, LowAccelerationTask
+    from .utils import get_root_joint_dim
+
+    nv, root_nv = model.nv, get_root_joint_dim(model)[1]
+    ty = type(t)
+    if ty in (LinearHolonomicTask, JointCouplingTask):
+        if t.A.shape[1] != nv or any(j.kind == "free_flyer" and np.any(t.A[:, j.idx_v:j.idx_v + 6]) for j in model.joints):
+            return None
+        q_0 = model.neutral() if t.q_0 is None else np.asarray(t.q_0, dtype=np.float64)
+        return ("const", np.ascontiguousarray(t.A, dtype=np.float64), np.asarray(t.b, dtype=np.float64), q_0, t.cost, float(t.gain), float(t.lm_damping))
+    if ty is DampingTask:
+        return ("diag", root_nv, np.zeros(nv - root_nv), t.cost, float(t.gain), float(t.lm_damping))
+    if ty is LowAccelerationTask:
+        return ("diag", 0, np.zeros(nv) if t.Delta_q_prev is None else -np.asarray(t.Delta_q_prev, dtype=np.float64), t.cost, float(t.gain), float(t.lm_damping))
+    if ty is JointVelocityTask:
+        r = 0 if model.root_joint is None else model.root_joint.nv
+        if t.target_v is None or t.target_dt is None or t.target_v.shape[0] != nv - r:
+            return None  # (the host path raises the reference's errors)
+        return ("diag", r, -t.target_dt * t.target_v, t.cost, float(t.gain), float(t.lm_damping))
+    return None
+
+
+def _extras_key(extras):
+    """Hashable identity of the extra tasks of a plan: everything but the errors of the diagonal ones (those change from
+    one control step to the next and are uploaded per call)."""
+    out = []
+    for x in extras:
+        cost = None if x[-3] is None else tuple(np.atleast_1d(np.asarray(x[-3], dtype=float)).tolist())
+        if x[0] == "const":
+            out.append(("const", x[1].shape, x[1].tobytes(), x[2].tobytes(), x[3].tobytes(), cost, x[-2], x[-1]))
+        else:
+            out.append(("diag", x[1], x[2].shape[0], cost, x[-2], x[-1]))
+    return tuple(out)
+
+
 def _device_kinematics_plan_tasks(configurations, tasks):
-    """The task half of :func:`_device_kinematics_plan`: ``(model, q, specs, targets, posture)`` or ``None``."""
+    """The task half of :func:`_device_kinematics_plan`: ``(model, q, specs, targets, posture, extras)`` or ``None``."""
     from .configuration import ConfigurationBatch
     from .tasks.frame_task import FrameTask
     from .tasks.posture_task import PostureTask
@@ -453,11 +496,9 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     if as_arrays:
         # arrays in, arrays out: the tasks are shared objects carrying per-instance targets as arrays
         model, q = configurations.model, configurations.q
-        specs, targets, posture = [], [], None
+        specs, targets, posture, extras = [], [], None, []
         for t in tasks:
             if type(t) is FrameTask:
-                if posture is not None:
-                    return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
                 if t.target_poses is not None:
                     if t.target_poses.shape != (B, 12):
                         raise PinkError(f"FrameTask {t.frame!r}: {t.target_poses.shape[0]} target poses for {B} configurations")
@@ -482,18 +523,28 @@ def _device_kinematics_plan_tasks(configurations, tasks):
                     return None
                 posture = (float(t.cost), float(t.gain), float(t.lm_damping), qp)
             else:
-                return None
+                x = _extra_task(model, t)
+                if x is None:
+                    return None
+                extras.append(x)
         if not specs:
             return None
-        return model, q, specs, targets, posture  # (targets: one [B, 12] array per frame task, uploaded as they are)
+        return model, q, specs, targets, posture, tuple(extras)  # (targets: one [B, 12] array per frame task, uploaded as they are)
     model = configurations[0].model
     if any(c.model is not model for c in configurations):
         return None
     _check_same_length(tasks)
     slots = [[tasks[b][k] for b in range(B)] for k in range(len(tasks[0]))]
-    specs, targets, posture = [], [], None
+    specs, targets, posture, extras = [], [], None, []
     for col in slots:
         t0 = col[0]
+        if type(t0) not in (FrameTask, PostureTask):
+            # a task the kernel forms from tables: one object shared by every instance
+            x = _extra_task(model, t0) if all(t is t0 for t in col) else None
+            if x is None:
+                return None
+            extras.append(x)
+            continue
         if col[-1] is not t0:  # (one task object for the whole batch: nothing to compare)
             ty, g0, l0 = type(t0), t0.gain, t0.lm_damping
             if not all(type(t) is ty and t.gain == g0 and t.lm_damping == l0 for t in col):
@@ -505,8 +556,8 @@ def _device_kinematics_plan_tasks(configurations, tasks):
             if costs.shape[0] != B or (costs != costs[0]).any():
                 return None
         if type(t0) is FrameTask:
-            if any(t.frame != t0.frame or t.transform_target_to_world is None for t in col) or posture is not None:
-                return None  # (frame tasks first: the packed row order is dense tasks, then the diagonal one)
+            if any(t.frame != t0.frame or t.transform_target_to_world is None for t in col):
+                return None
             specs.append(_spec_of(t0))
             tg = np.empty((B, 12))
             for b, t in enumerate(col):
@@ -523,7 +574,7 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     if not specs:
         return None
     q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
-    return model, q, specs, np.stack(targets, axis=1), posture
+    return model, q, specs, np.stack(targets, axis=1), posture, tuple(extras)
 
 
 # Device-resident state of the last few (model, batch size, task stack) combinations solve_ik_batch was called with,
@@ -572,13 +623,13 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, bars, limit_gain = plan
+    model, q, specs, T, posture, extras, bars, limit_gain = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
     fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
     fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
     key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
-           int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey)
+           int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras))
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     fresh = False
@@ -587,11 +638,14 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
         if posture is not None:
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
-                           max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb, **kw)
+                           max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb,
+                           const_tasks=[x[1:] for x in extras if x[0] == "const"], diag_tasks=[x[1:] for x in extras if x[0] == "diag"], **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
         ro.velocity_out = True  # (the whole-step kernel hands out dq / dt: no division over the array afterwards)
         fresh = True
     try:
+        if not fresh and any(x[0] == "diag" for x in extras):  # (a LowAccelerationTask / JointVelocityTask moves on every step)
+            ro.set_diag_errors([x[2] for x in extras if x[0] == "diag"])
         # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
         qp = None if posture is None else posture[3]
         if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and not bars and ro.md == 0
@@ -612,11 +666,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, bars, limit_gain = plan
+    model, q, specs, T, posture, extras, bars, limit_gain = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, bars, limit_gain
+    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,
@@ -632,9 +686,13 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     Raises :class:`NoSolutionFound` listing the failing instances (the batched
     analogue of ``pink/solve_ik.py:271-273``).
 
-    ``device_kinematics``: when the task stack is FrameTasks (+ one PostureTask) under the model's default limits,
-    forward kinematics, task errors / Jacobians and limits can be evaluated by the device kernels from ``q`` alone
-    instead of per configuration on the host (``None``: do so for batches of 64 and more; ``True``: require it).
+    ``device_kinematics``: when the task stack is FrameTasks next to tasks the whole-step kernel forms from tables --
+    one PostureTask, LinearHolonomicTasks / JointCouplingTasks on the joints behind the root, DampingTask,
+    LowAccelerationTask, JointVelocityTask (one object each for the whole batch) -- under the model's default limits,
+    forward kinematics, task errors / Jacobians and limits are evaluated by the device kernel from ``q`` alone
+    instead of on the host (``None``: do so for batches of 64 and more; ``True``: require it; ``"frame_rows"``: only the
+    FrameTask rows on the device, everything else evaluated on the host for the whole batch -- the route any other
+    stack of FrameTasks + identity-Jacobian tasks takes).
     Device buffers of the last few call shapes are kept (:func:`clear_device_cache`).
 
     ``out``: a ``[B, nv]`` float64 array that receives the velocities (like NumPy's ``out=``).  Allocated through
@@ -656,11 +714,17 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
         solver_handle = device_pool(device_ids)
     pool = getattr(solver_handle, "solvers", None)  # a MultiDeviceSolver
     plan = None
-    if device_kinematics or (device_kinematics is None and len(configurations) >= 64):
+    rows_only = isinstance(device_kinematics, str)
+    if rows_only:
+        if device_kinematics != "frame_rows":
+            raise PinkError(f"device_kinematics={device_kinematics!r}: True, False, None or 'frame_rows'")
+        device_kinematics = None
+    if not rows_only and (device_kinematics or (device_kinematics is None and len(configurations) >= 64)):
         plan = _device_kinematics_plan(configurations, tasks, limits, barriers, constraints)
         if plan is None and device_kinematics:
-            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask), default limits, no constraints, "
-                            "and no barriers other than PositionBarriers (default class-K function) on the task frames")
+            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask, constant-row and identity tasks shared by the "
+                            "batch), default limits, no constraints, and no barriers other than PositionBarriers (default class-K "
+                            "function) on the task frames")
     if plan is not None:
         from .batch_solver import BatchResult
         from .rollout import NoWholeStepKernel
@@ -712,7 +776,7 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             for cfg in configurations:
                 cfg.check_limits(safety_break=safety_break)
     api = solver_handle or default_solver()
-    if (device_kinematics is None and B >= 64 and pool is None and kwargs.get("gpu_frame_tasks", True)
+    if (device_kinematics is None and (B >= 64 or rows_only) and pool is None and kwargs.get("gpu_frame_tasks", True)
             and hasattr(api, "fk_frame_tasks") and hasattr(api, "solve_raw")):
         result = _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constraints, api, max_iter)
         if result is not None:

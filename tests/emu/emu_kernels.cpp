@@ -326,12 +326,23 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   f.dt = d->dt;
   f.config_limit_gain = st->config_limit_gain;
   f.root_box = st->root_box;
-  f.q_target = (d->K > d->Kd) ? st->q_target : nullptr;
+  int post_row0 = 0, post_k = 0;
+  g_err = pinkhip::rollout_task_layout(*d, m->dev.nf, m->dev.nv, m->dev.root_nv, st->n_const_rows, st->posture_task, st->diag_error != nullptr,
+                                       post_row0, post_k);
+  if (!g_err.empty()) return PINKHIP_E_INVALID;
+  f.q_target = post_k ? st->q_target : nullptr;
   f.target_batched = st->target_batched;
   ra.integrate = st->integrate;
   ra.first_failure = st->first_failure;
   ra.step = st->step;
-  const int fkd = pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf);
+  ra.n_crow = st->n_const_rows;
+  ra.crow_A = st->const_rows;
+  ra.crow_q0 = st->const_q0;
+  ra.crow_b = st->const_b;
+  ra.post_row0 = post_row0;
+  ra.post_k = post_k;
+  ra.diag_e = st->diag_error;
+  const int fkd = pinkhip::rollout_fk_doubles(m->dev.nj, m->dev.nf, st->n_const_rows);
   pinkhip::LaneFn fn = nullptr;
   long long blocks = 0;
   pinkhip::PackedChoice pc{0, 0};

@@ -300,3 +300,94 @@ def test_hybrid_route_forms_frame_task_rows_on_the_device(backend, free_flyer):
     rt.set_target(cfgs[0].get_transform("tool0", "joint_5"))
     solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [rt], dt, **kw)
     assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_whole_step_kernel_forms_coupling_and_identity_tasks_on_chip(backend, free_flyer):
+    """The task stack of the reference's own humanoid example (examples/humanoid_draco3.py:34-71: FrameTasks, a
+    PostureTask and two JointCouplingTasks) and the identity-Jacobian tasks next to it (DampingTask, LowAccelerationTask,
+    JointVelocityTask) take the device-resident route: the kernel forms the coupling rows from a constant table and
+    e = A (q (-) q_0) - b from the configuration it already holds (pink/tasks/linear_holonomic_task.py:103-148), the
+    identity tasks from a batch-constant error.  Same velocities as the all-host evaluation and as one solve_ik per
+    configuration, in any task order, with barriers, through the Goldfarb-Idnani code for a stack that is rank deficient
+    by construction; a LowAccelerationTask that moves between two calls is served by the cached device state."""
+    m = build_chain(9, free_flyer=free_flyer, seed=5, limit=2.8, velocity=6.0)
+    rng = np.random.default_rng(33)
+    B, dt = 9, 5e-3
+    q = _draw_q(m, B, rng)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    frames = []
+    for k, f in enumerate(["tool0", "joint_5"]):
+        R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+        ft = FrameTask(f, 1.0, 0.5 if k == 0 else 0.0, lm_damping=1e-3, gain=0.9)
+        for b, c in enumerate(cfgs):
+            T = c.get_transform_frame_to_world(f) * exp6(0.05 * rng.normal(size=6))
+            R[b], t[b] = T.rotation, T.translation
+        ft.set_target_poses(R, t)
+        frames.append(ft)
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    jc1 = JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 100.0, cfgs[0], lm_damping=5e-7)
+    jc2 = JointCouplingTask(["joint_6", "joint_7", "joint_8"], [1.0, 0.5, -2.0], 50.0, cfgs[0], gain=0.7)
+    la = LowAccelerationTask(cost=0.05)
+    la.set_last_integration(0.2 * rng.normal(size=m.nv), dt)
+    jv = JointVelocityTask(cost=0.05)
+    jv.set_target(0.3 * rng.normal(size=m.nv - (6 if free_flyer else 0)), dt)
+    p_tool = np.array([c.get_transform_frame_to_world("tool0").translation for c in cfgs])
+    bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[:, 2].max() + 0.02]), gain=np.array([50.0]), safe_displacement_gain=1.0)]
+    cb = ConfigurationBatch(m, q)
+    stacks = {
+        "reference example": (frames + [po, jc1, jc2], {}),
+        "interleaved": ([frames[0], jc1, frames[1], jc2, po, DampingTask(cost=1e-2)], {}),
+        "every identity task": (frames + [jc1, po, DampingTask(cost=1e-2), la, jv], {}),
+        "no posture": (frames + [jc2, DampingTask(cost=1e-2)], {}),
+        "barrier": (frames + [po, jc1, jc2], dict(barriers=bars)),
+    }
+    for name, (ts, kw) in stacks.items():
+        V = solve_ik_batch(cb, ts, dt, device_kinematics=True, **kw)
+        assert pink_amd.last_solve_stats()["route"] == "device", name
+        V_host = solve_ik_batch(cb, ts, dt, device_kinematics=False, gpu_frame_tasks=False, **kw)
+        assert pink_amd.last_solve_stats()["route"] == "host-evaluated", name
+        scale = max(1.0, np.abs(V_host).max())
+        assert np.abs(V - V_host).max() < 1e-8 * scale and np.abs(V).max() > 1e-3, name
+        for b in range(3):  # Pink's calling pattern: one target per task object, one solve_ik per configuration
+            own = {id(ft): FrameTask(ft.frame, ft.cost[0], ft.cost[3], lm_damping=ft.lm_damping, gain=ft.gain) for ft in frames}
+            for ft in frames:
+                own[id(ft)].set_target(SE3(ft.target_poses[b, :9].reshape(3, 3), ft.target_poses[b, 9:]))
+            v = solve_ik(cfgs[b], [own.get(id(t_), t_) for t_ in ts], dt, **kw)
+            assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), (name, b)
+    # FrameTasks and couplings alone on more coordinates than rows, no damping: rank deficient by construction, the
+    # Goldfarb-Idnani code forms the same rows
+    for ft in frames:
+        ft.lm_damping = 0.0
+    ts = frames + [JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 1.0, cfgs[0])]
+    V = solve_ik_batch(cb, ts, dt, damping=1e-12, device_kinematics=True)
+    st = pink_amd.last_solve_stats()
+    assert st["route"] == "device" and (st["paths"]["goldfarb_idnani"] == 1.0) == (m.nv > 13)
+    V_host = solve_ik_batch(cb, ts, dt, damping=1e-12, device_kinematics=False, gpu_frame_tasks=False)
+    # (H = J^T W J + 1e-12 I has a null space but for the damping: its component of the velocity is fixed to ~1e-4 only,
+    # in either route -- tests/test_gpu_parity.py compares such problems through their KKT certificates)
+    assert np.abs(V - V_host).max() < 1e-3 * max(1.0, np.abs(V_host).max())
+    # the low-acceleration error moves from one control step to the next: same device state, new error table
+    ts = frames + [jc1, po, la]
+    for ft in frames:
+        ft.lm_damping = 1e-3
+    for _ in range(2):
+        la.set_last_integration(0.2 * rng.normal(size=m.nv), dt)
+        V = solve_ik_batch(cb, ts, dt, device_kinematics=True)
+        assert pink_amd.last_solve_stats()["route"] == "device"
+        V_host = solve_ik_batch(cb, ts, dt, device_kinematics=False, gpu_frame_tasks=False)
+        assert np.abs(V - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
+    # a coupling that touches the floating base is not a constant row: the call is served by another route
+    if free_flyer:
+        A = np.zeros((1, m.nv))
+        A[0, 2], A[0, 8] = 1.0, -1.0
+        from pink_amd.tasks import LinearHolonomicTask
+
+        lh = LinearHolonomicTask(A, np.zeros(1), m.neutral(), cost=1.0)
+        with pytest.raises(pink_amd.PinkError):
+            solve_ik_batch(cb, frames + [po, lh], dt, device_kinematics=True)
+        V = solve_ik_batch(cb, frames + [po, lh], dt)
+        assert pink_amd.last_solve_stats()["route"] != "device"
+        V_host = solve_ik_batch(cb, frames + [po, lh], dt, device_kinematics=False, gpu_frame_tasks=False)
+        assert np.abs(V - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
