@@ -23,16 +23,24 @@ struct HbmTerms {
   __device__ __forceinline__ double dense_h(int) const { return 0.0; }
 };
 
-// Dense task rows.  Lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row; the next
-// chunk is in flight while this one is accumulated), lane k the weights of row k.  Row k then enters every lane's H
+// Dense task rows.  Lane li requests J[k][li] for the RC rows of a chunk (one coalesced request per row), lane k the
+// weights of row k; DEPTH chunks are in flight ahead of the one being accumulated.  Row k then enters every lane's H
 // row through the broadcast-FMA:  H[li][j] += (w_k^2 J[k][li]) * J[k][j]  with J[k][j] taken from lane j and w_k^2
 // from lane k.  M holds at least NV entries (the first NV are used); ci and mu_l accumulate this lane's entry of c
 // and its share of the Levenberg-Marquardt term.
-// (two chunks of eight rows in registers: twelve spill at NV = 30; an on-the-fly source delivers one FrameTask = six
-// rows per chunk)
-template <int NV, int W, int RCMAX, class Src, int NM>
+// DEPTH: a chunk of eight rows is accumulated in ~1 k cycles of this wave's own issue time, a request takes several
+// thousand under load -- with ONE chunk ahead (DEPTH = 1) a wave of the sweep-tableau kernel waited out the memory
+// latency once per chunk (section clock, round 4: 30 k cycles per wave in this phase, whatever the input regime);
+// DEPTH = 2 has all 24 rows of the headline stack in flight before the first FMA.  (an on-the-fly source delivers
+// one FrameTask = six rows per chunk and nothing is in flight)
+// `mid` runs between the first requests and the first accumulation: what else the caller wants from HBM (bounds,
+// the terms of the diagonal tasks) is requested there and arrives within the same wait.
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int NV, int W, int RCMAX, class Src, int DEPTH = 1, int NM, class Mid = NoMid>
 __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long b, Src *terms, bool in, int li,
-                                                 double (&M)[NM], double &ci, double &mu_l) {
+                                                 double (&M)[NM], double &ci, double &mu_l, Mid mid = Mid()) {
   static_assert(NM >= NV && W >= 16, "row-group kernels only");
   using BcT = Bcast<W>;
   const int nv = a.nv, Kd = a.Kd, K = a.K;
@@ -40,42 +48,54 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
   const double *eb = a.e + b * (long long)K;
   const double *costb = a.cost_batched ? a.cost + b * (long long)K : a.cost;
   constexpr int RC = Src::kOnTheFly ? 6 : (RCMAX < 8 ? RCMAX : 8);
+  constexpr int NB = Src::kOnTheFly ? 2 : DEPTH + 1;  // chunk buffers: the one being accumulated + those in flight
   static_assert(RC <= 16, "weight rows are broadcast from the first row of 16 lanes");
-  double cur[RC], nxt[RC];
-  double pw = 0.0, pe = 0.0, pg = 0.0, pl = 0.0;
-  auto request = [&](double (&dst)[RC], int r0, int rc) {
+  struct Chunk {
+    double r[RC];
+    double pw, pe, pg, pl;
+  };
+  Chunk buf[NB];
+  auto request = [&](Chunk &dst, int r0) {
+    const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;  // (<= 0: past the end, nothing is read)
     if constexpr (Src::kOnTheFly) {
       double six[6];
       terms->frame_rows(r0 / 6, six);
 #pragma unroll
-      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? six[kk] : 0.0;
+      for (int kk = 0; kk < RC; ++kk) dst.r[kk] = (in && kk < rc) ? six[kk] : 0.0;
     } else {
 #pragma unroll
-      for (int kk = 0; kk < RC; ++kk) dst[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
+      for (int kk = 0; kk < RC; ++kk) dst.r[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
     }
+    dst.pw = dst.pe = dst.pg = dst.pl = 0.0;
     if (li < rc) {
       const int k = r0 + li;
-      pw = costb[k];
-      if constexpr (Src::kOnTheFly) pe = terms->error(k);
-      else pe = eb[k];
-      pg = a.row_gain[k];
-      pl = a.row_lm[k];
+      dst.pw = costb[k];
+      if constexpr (Src::kOnTheFly) dst.pe = terms->error(k);
+      else dst.pe = eb[k];
+      dst.pg = a.row_gain[k];
+      dst.pl = a.row_lm[k];
     }
   };
-  if (Kd > 0) request(cur, 0, Kd < RC ? Kd : RC);
+  if (Kd > 0) {
+#pragma unroll
+    for (int d = 0; d < NB - 1; ++d)
+      if (d * RC < Kd) request(buf[d], d * RC);  // wave-uniform
+  }
+  mid();
   for (int r0 = 0; r0 < Kd; r0 += RC) {
     const int rc = (Kd - r0 < RC) ? Kd - r0 : RC;
-    const double wa = (li < rc) ? pw * pw : 0.0;
-    const double gw = (li < rc) ? pg * wa * pe : 0.0;
-    if (li < rc) mu_l += pl * (pg * pg) * wa * pe * pe;
+    if (r0 + (NB - 1) * RC < Kd) request(buf[NB - 1], r0 + (NB - 1) * RC);
+    const Chunk &cur = buf[0];
+    const double wa = (li < rc) ? cur.pw * cur.pw : 0.0;
+    const double gw = (li < rc) ? cur.pg * wa * cur.pe : 0.0;
+    if (li < rc) mu_l += cur.pl * (cur.pg * cur.pg) * wa * cur.pe * cur.pe;
     const BcT wab = bcast_prepare<W>(wa), gwb = bcast_prepare<W>(gw);
-    if (r0 + RC < Kd) request(nxt, r0 + RC, (Kd - r0 - RC < RC) ? Kd - r0 - RC : RC);
     static_for<0, RC>([&](auto Kc) {
       constexpr int kk = decltype(Kc)::value;
       if (kk < rc) {  // wave-uniform
-        const BcT rowb = bcast_prepare<W>(cur[kk]);
-        const double aa = fma_bcast<W, kk>(0.0, wab, cur[kk]);
-        ci = fma_bcast<W, kk>(ci, gwb, cur[kk]);
+        const BcT rowb = bcast_prepare<W>(cur.r[kk]);
+        const double aa = fma_bcast<W, kk>(0.0, wab, cur.r[kk]);
+        ci = fma_bcast<W, kk>(ci, gwb, cur.r[kk]);
         static_for<0, NV>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
           M[j] = fma_bcast<W, j>(M[j], rowb, aa);
@@ -83,7 +103,7 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
       }
     });
 #pragma unroll
-    for (int kk = 0; kk < RC; ++kk) cur[kk] = nxt[kk];
+    for (int d = 0; d + 1 < NB; ++d) buf[d] = buf[d + 1];
   }
 }
 

@@ -63,6 +63,13 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #define PINKHIP_SWEEP_CERT_TOL 1e-12
 #endif
 // conditioning estimate max_i H_ii (H^-1)_ii beyond which an instance skips the tableau iteration
+// chunks of eight task rows requested ahead of the one being accumulated (ik_stack_rows.h)
+#ifndef PINKHIP_STACK_DEPTH
+#define PINKHIP_STACK_DEPTH 1
+#endif
+#ifndef PINKHIP_STACK_DEPTH_WIDE  // (instantiations at two waves per SIMD: 256 registers)
+#define PINKHIP_STACK_DEPTH_WIDE 2
+#endif
 #ifndef PINKHIP_SWEEP_ROUTE_COND
 #define PINKHIP_SWEEP_ROUTE_COND 1e10
 #endif
@@ -113,23 +120,46 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
 #pragma unroll
   for (int j = 0; j < NT; ++j) T[j] = 0.0;
   double ci = 0.0, mu_l = 0.0, dadd = 0.0;
-  stack_rows_bcast<NV, W, 8, Src>(a, b, terms, in, li, T, ci, mu_l);
-  if (in) {
-    dadd = stack_diag_tasks<Src>(a, b, terms, li, ci, mu_l);
-    if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
-  }
+  // Everything this instance reads from HBM is requested before the first row is accumulated (PINKHIP_STACK_DEPTH
+  // chunks of eight rows ahead = the headline's 24 rows; bounds, c_extra and the terms of the diagonal tasks behind
+  // them): one memory latency per wave instead of one per chunk and two more for the diagonal tasks and the bounds.
+  double ci_d = 0.0, mu_d = 0.0, lbv = -INF, ubv = INF, hv = 0.0, ginv = 1.0;
+  auto others = [&]() {
+    if (in) {
+      if constexpr (!Src::kOnTheFly) {
+        lbv = a.lb[b * (long long)nv + li];
+        ubv = a.ub[b * (long long)nv + li];
+      }
+      dadd = stack_diag_tasks<Src>(a, b, terms, li, ci_d, mu_d);
+      if (a.c_extra) ci_d += a.c_extra[b * (long long)nv + li];
+    }
+    if constexpr (DENSE && !Src::kOnTheFly) {
+      // K = [H G^T; G 0]: coordinate lane li takes G[d][li] into column NV + d (the stacking leaves those alone)
+      if (md > 0) {
+        const double *Gb = a.Gd + b * (long long)md * nv;
+        static_for<0, MD>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value;
+          T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+        });
+        if (dlane) hv = a.hd[b * (long long)md + dr];
+      }
+    }
+  };
+  stack_rows_bcast<NV, W, 8, Src, (NT > 34 ? PINKHIP_STACK_DEPTH_WIDE : PINKHIP_STACK_DEPTH)>(a, b, terms, in, li, T, ci, mu_l, others);
+  ci += ci_d;
+  mu_l += mu_d;
   double diag = a.damping + group_sum<W>(mu_l);
 
-  double hv = 0.0, ginv = 1.0;
   if constexpr (DENSE) {
     if (md > 0) {
-      // K = [H G^T; G 0]: coordinate lane li takes G[d][li] into column NV + d, the lane of dense row d its row
+      // (the lane of dense row d takes its row)
       const double *Gb = Src::kOnTheFly ? nullptr : a.Gd + b * (long long)md * nv;
-      static_for<0, MD>([&](auto Dc) {
-        constexpr int d = decltype(Dc)::value;
-        if constexpr (Src::kOnTheFly) T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
-        else T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
-      });
+      if constexpr (Src::kOnTheFly) {
+        static_for<0, MD>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value;
+          T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
+        });
+      }
       if constexpr (Src::kOnTheFly) {
         // the rows of G exist only as column entries in the coordinate lanes: the lane of row d collects G[d][j] from
         // lane j (K is symmetric)
@@ -151,7 +181,6 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
           const double *gr = Gb + (long long)dr * nv;
 #pragma unroll
           for (int j = 0; j < NV; ++j) T[j] = (j < nv) ? gr[j] : 0.0;
-          hv = a.hd[b * (long long)md + dr];
         } else {
           hv = terms->dense_h(dr);
         }
@@ -204,17 +233,16 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // pivot): not positive = H is not positive definite (quadprog's "matrix G is not positive definite").
   // Lane k's own row becomes col / p; written as T[k][j] - (1 - 1/p) col_j it is the same FMA as every other lane's
   // (T[k][j] and col_j = T[j][k] agree to round-off: the difference enters like a perturbation of H of that size).
+  // (the smallest pivot decides afterwards: a group that met a non-positive one sweeps on through whatever that leaves
+  // -- infinities, NaN -- and never iterates on it; one v_min per column instead of a compare and three selects)
   int status = STATUS_OPTIMAL;
+  double pmin = INF;
   static_for<0, NV>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
     if (k < nv) {  // wave-uniform
       const BcT xb = bcast_prepare<W>(T[k]);
-      double p = value_bcast<W, k>(xb);
-      if (!(p > 0.0)) {
-        status = STATUS_NOT_PD;
-        p = 1.0;
-      }
-      if constexpr (NT > 32) pin(status);  // (fold the test column by column: no NV lane masks kept in SGPRs)
+      const double p = value_bcast<W, k>(xb);
+      pmin = min_raw(pmin, p);
       const double rp = fast_rcp(p);
       const double t = T[k] * rp;
       const double nt = (li == k) ? rp - 1.0 : -t;
@@ -225,6 +253,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       T[k] = (li == k) ? -rp : t;
     }
   });
+  if (!(pmin > 0.0)) status = STATUS_NOT_PD;
   PINKHIP_TICK(1);  // initial sweeps
   // The diagonal entry of a lane's own row: kept in a register of its own from here on (a pivot on a run-time index
   // cannot address "register p of lane p"; the copy inside T is not maintained and never read).
@@ -267,13 +296,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // scalar registers across the loop they spill (v_writelane / v_readlane inside every trip).
   const KernelArgs *late = &a;
   if constexpr (!Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
-  double lbv, ubv;
   if constexpr (Src::kOnTheFly) {
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
-  } else {
-    lbv = in ? late->lb[b * (long long)nv + li] : -INF;
-    ubv = in ? late->ub[b * (long long)nv + li] : INF;
   }
   // violation threshold relative to 1 + |bound|: the round-off of the iterate grows with the dimension and so does
   // the threshold; same rule as oracle/gi_oracle.c and ik_kernels_packed.h

@@ -67,28 +67,42 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
 #pragma unroll
   for (int j = 0; j < NT; ++j) T[j] = 0.0;
   double ci = 0.0, mu_l = 0.0, dadd = 0.0;
-  stack_rows_bcast<NV, W, 8, Src>(a, b, terms, in, li, T, ci, mu_l);
-  if (in) {
-    dadd = stack_diag_tasks<Src>(a, b, terms, li, ci, mu_l);
-    if (a.c_extra) ci += a.c_extra[b * (long long)nv + li];
-  }
+  // (everything the instance reads from HBM is requested before the first row is accumulated: ik_sweep.h)
+  double ci_d = 0.0, mu_d = 0.0, lbv = -INF, ubv = INF, hv = 0.0, ginv = 1.0;
+  auto others = [&]() {
+    if (in) {
+      if constexpr (!Src::kOnTheFly) {
+        lbv = a.lb[b * (long long)nv + li];
+        ubv = a.ub[b * (long long)nv + li];
+      }
+      dadd = stack_diag_tasks<Src>(a, b, terms, li, ci_d, mu_d);
+      if (a.c_extra) ci_d += a.c_extra[b * (long long)nv + li];
+    }
+    if constexpr (!Src::kOnTheFly) {
+      // K = [H G^T; G 0]: coordinate lane m takes G[d][m] into column NV + d (the stacking leaves those alone)
+      const double *Gb = a.Gd + b * (long long)md * nv;
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+      });
+      if (dl) hv = a.hd[b * (long long)md + li];
+    }
+  };
+  stack_rows_bcast<NV, W, 8, Src, PINKHIP_STACK_DEPTH>(a, b, terms, in, li, T, ci, mu_l, others);
+  ci += ci_d;
+  mu_l += mu_d;
   double diag = a.damping + group_sum<W>(mu_l);
-  // K = [H G^T; G 0]: coordinate lane m takes G[d][m] into column NV + d
-  {
-    const double *Gb = Src::kOnTheFly ? nullptr : a.Gd + b * (long long)md * nv;
+  if constexpr (Src::kOnTheFly) {
     static_for<0, MD>([&](auto Dc) {
       constexpr int d = decltype(Dc)::value;
-      if constexpr (Src::kOnTheFly) T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
-      else T[NV + d] = (in && d < md) ? Gb[(long long)d * nv + li] : 0.0;
+      T[NV + d] = (in && d < md) ? terms->dense_col(d) : 0.0;
     });
   }
   // dense role: right-hand side and Euclidean norm of the row (the selection's threshold is relative to it)
-  double hv = 0.0, ginv = 1.0;
   {
     const double n2 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * T[NV + decltype(Dc)::value]; });
     if (dl) {
       if constexpr (Src::kOnTheFly) hv = terms->dense_h(li);
-      else hv = a.hd[b * (long long)md + li];
       ginv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 1.0;
     }
   }
@@ -126,16 +140,16 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   PINKHIP_TICK(0);  // stacking
 
   // ------------------------------------------------------------------ sweep in every coordinate: T_cc = -H^-1
+  // (the smallest pivot decides afterwards: a group that met a non-positive one sweeps on through whatever that leaves
+  // -- infinities, NaN -- and never iterates on it; one v_min per column instead of a compare and three selects)
   int status = STATUS_OPTIMAL;
+  double pmin = INF;
   static_for<0, NV>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
     if (k < nv) {  // wave-uniform
       const BcT xb = bcast_prepare<W>(T[k]);
-      double p = value_bcast<W, k>(xb);
-      if (!(p > 0.0)) {
-        status = STATUS_NOT_PD;
-        p = 1.0;
-      }
+      const double p = value_bcast<W, k>(xb);
+      pmin = min_raw(pmin, p);
       const double rp = fast_rcp(p);
       const double t = T[k] * rp;
       const double nt = (li == k) ? rp - 1.0 : -t;
@@ -146,6 +160,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       T[k] = (li == k) ? -rp : t;
     }
   });
+  if (!(pmin > 0.0)) status = STATUS_NOT_PD;
   PINKHIP_TICK(1);  // initial sweeps
   double tdiag = 0.0;
 #pragma unroll
@@ -206,13 +221,9 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // ------------------------------------------------------------------ dual active set on the tableau
   const KernelArgs *late = &a;
   if constexpr (!Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
-  double lbv, ubv;
   if constexpr (Src::kOnTheFly) {
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
-  } else {
-    lbv = in ? late->lb[b * (long long)nv + li] : -INF;
-    ubv = in ? late->ub[b * (long long)nv + li] : INF;
   }
   const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
   const double thr_lo = -tol * (1.0 + fabs(lbv)), thr_up = -tol * (1.0 + fabs(ubv));

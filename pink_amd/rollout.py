@@ -31,6 +31,14 @@ from .configuration import Model
 from .exceptions import NoSolutionFound, NotWithinConfigurationLimits, PinkError
 from .utils import get_root_joint_dim
 
+# Relative sizes of the ranges one pipelined solve is cut into (DeviceRollout.solve_pipelined).  Four equal ranges:
+# ranges that shrink towards the end (less to wait for after the last byte went up) or more of them measured 3-5 %
+# SLOWER at B = 65 536 (profiles/prof_pipeline_r04.txt: every range costs five uploads, a launch and three downloads of
+# fixed overhead, and a short range fills a third of the chip).  PINKHIP_PIPELINE_SPLIT="30,27,22,13,8" overrides.
+import os as _os
+
+PIPELINE_SPLIT = tuple(float(v) for v in _os.environ.get("PINKHIP_PIPELINE_SPLIT", "1,1,1,1").split(","))
+
 _JT = {"revolute": 0, "prismatic": 1, "free_flyer": 2}
 
 
@@ -266,6 +274,7 @@ class DeviceRollout:
         self.d_status, self.d_iters = a.alloc(4 * B), a.alloc(4 * B)
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
+        self._fail_dirty = False
         self.d_qt = f8(B, nq)
         self.d_bar, self.d_lim, self.d_extra = [], [], []
         if self._extra_tasks:  # tables of the constant-row tasks and the batch-constant errors of the extra diagonal tasks
@@ -315,13 +324,23 @@ class DeviceRollout:
         self._check_limits_device(q0, safety_break)
         if self.n_post:
             self._put_posture(q0, q_posture)
-        a.put(self.d_fail, np.zeros(self.B, dtype=np.int32))
+        if self._fail_dirty:
+            a.put(self.d_fail, np.zeros(self.B, dtype=np.int32))
+            self._fail_dirty = False
         self.steps_done = 0
         self._pending = False
 
-    def _put_posture(self, q0: np.ndarray, q_posture: Optional[np.ndarray]) -> None:
+    def _put_posture(self, q0: np.ndarray, q_posture: Optional[np.ndarray], asyn: bool = False) -> None:
         """Posture target(s): ``None`` = each robot's initial configuration, ``[nq]`` = one for all robots (uploaded
-        as it is: the kernels take either form, ``target_batched``), ``[B, nq]`` = one per robot."""
+        as it is: the kernels take either form, ``target_batched``), ``[B, nq]`` = one per robot.  ``asyn``: one target
+        for all robots goes up on the copy stream from a page-locked mirror, without a synchronisation of its own."""
+        if asyn and q_posture is not None and np.ndim(q_posture) == 1 and hasattr(self.api, "pinned_empty"):
+            if getattr(self, "_h_qt", None) is None:
+                self._h_qt = self.api.pinned_empty((self.nq,), np.float64)
+            self._h_qt[:] = q_posture
+            self.api.put_async(self.d_qt, self._h_qt)
+            self.qt_batched = 0
+            return
         if q_posture is None:
             self.api.put(self.d_qt, q0)
             self.qt_batched = 1
@@ -369,6 +388,8 @@ class DeviceRollout:
         a, B, nv, nf = self.api, self.B, self.nv, len(self.frames)
         self._pipelined = None
         self.scaled = False
+        if integrate:
+            self._fail_dirty = True
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             self.scaled = False  # (no whole-step kernel for this model: the launches below write dq unscaled)
             if self._extra_tasks:
@@ -413,29 +434,34 @@ class DeviceRollout:
         self.steps_done += 1
 
     def solve_pipelined(self, q0: np.ndarray, targets: Sequence[np.ndarray], q_posture: Optional[np.ndarray] = None,
-                        safety_break: bool = True, n_chunks: int = 4, out: Optional[np.ndarray] = None) -> bool:
-        """One differential-IK solve of new configurations ``q0`` (no integration), the batch cut into ``n_chunks``
-        ranges: the upload of one range (``q`` and one ``[B, 12]`` target array per frame task, copy stream), the
+                        safety_break: bool = True, n_chunks: Optional[int] = None, out: Optional[np.ndarray] = None) -> bool:
+        """One differential-IK solve of new configurations ``q0`` (no integration), the batch cut into ranges (``n_chunks``
+        equal ones, or in the proportions of :data:`PIPELINE_SPLIT`): the upload of one range (``q`` and one ``[B, 12]`` target array per frame task, copy stream), the
         whole-step kernel of the previous one (compute stream) and the results of the one before going home (result
         stream) are in flight together; nothing blocks the host until the closing synchronisation when the arrays are
         page-locked (``pink_amd.pinned_empty``; pageable arrays are staged by the runtime: correct, less overlap).
         ``out [B, nv]`` receives ``dq``.  Results through :meth:`last_step`.  ``False`` -- nothing enqueued -- when the
         whole-step kernel does not serve this model or the solver has no copy stream."""
         a, B, nq, nv, nf = self.api, self.B, self.nq, self.nv, len(self.frames)
-        if self.fused != "kernel" or not hasattr(a, "put_overlapped") or len(targets) != nf or B < n_chunks:
+        if n_chunks is None:
+            cuts = np.rint(np.cumsum((0.0,) + PIPELINE_SPLIT) / sum(PIPELINE_SPLIT) * B).astype(int)
+        else:
+            cuts = np.array([(B * c) // n_chunks for c in range(n_chunks + 1)])
+        cuts = np.unique(cuts)
+        if self.fused != "kernel" or not hasattr(a, "put_overlapped") or len(targets) != nf or B < 64:
             return False
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
         if q0.shape != (B, nq):
             raise ValueError(f"q0 must have shape {(B, nq)}, got {q0.shape}")
         tg = [np.ascontiguousarray(np.broadcast_to(t, (B, 12)), dtype=np.float64) for t in targets]
-        if self.n_post:
-            self._put_posture(q0, q_posture)
-        a.put(self.d_fail, np.zeros(B, dtype=np.int32))
-        self.steps_done, self._pending, self.targets_per_frame = 0, False, True
-        from .sharding import shard_bounds
-
         if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
             raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
+        if self.n_post:  # (the first kernel waits for the copy stream: wait_copies below)
+            self._put_posture(q0, q_posture, asyn=hasattr(a, "put_async") and hasattr(a, "is_pinned") and a.is_pinned(q0))
+        if self._fail_dirty:  # (a solve without integration records no failures: only a rollout leaves some behind)
+            a.put(self.d_fail, np.zeros(B, dtype=np.int32))
+            self._fail_dirty = False
+        self.steps_done, self._pending, self.targets_per_frame = 0, False, True
         # Fully asynchronous ranges need page-locked memory on both ends: a pageable source is staged by the runtime
         # before the call returns (no harm), a pageable destination makes the download wait for its kernel on the host
         # thread -- the uploads of the next range would queue behind it.  Without a page-locked `out` the results come
@@ -448,8 +474,8 @@ class DeviceRollout:
             if getattr(self, "_h_status", None) is None:  # page-locked landing buffers of the small result arrays
                 self._h_status, self._h_iters = a.pinned_empty((B,), np.int32), a.pinned_empty((B,), np.int32)
             res = (out, self._h_status, self._h_iters)
-        for c in range(n_chunks):
-            lo, hi = shard_bounds(B, c, n_chunks)
+        for c in range(len(cuts) - 1):
+            lo, hi = int(cuts[c]), int(cuts[c + 1])
             put(self.d_q + 8 * nq * lo, q0[lo:hi])
             for f, t in enumerate(tg):
                 put(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])

@@ -21,7 +21,10 @@ def main():
         synthetic.CONFIGS["custom"] = dict(config_id=20, nv=int(os.environ.get("AB_NV", "12")), root_nv=0, dt=5e-3, frame_costs=[(1.0, 1.0), (1.0, 1.0)],
                                            frame_lm=0.0, posture_cost=1e-1, n_barriers=int(os.environ.get("AB_NB", "0")))
     B = int(os.environ.get("AB_BATCH", "65536"))
-    terms = synthetic.make_terms(cfg, B, bounds=os.environ.get("AB_BOUNDS", "tight"), jacobians="dense")
+    if os.environ.get("AB_BOUNDS") == "tracking":  # bench.py's tracking_small_errors regime
+        terms = synthetic.make_terms(cfg, B, bounds="kinematic", jacobians="kinematic", error_scale=0.02)
+    else:
+        terms = synthetic.make_terms(cfg, B, bounds=os.environ.get("AB_BOUNDS", "tight"), jacobians="dense")
     batch = synthetic.pack(terms)
     n = 2048
     ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms.slice(0, n)), nthreads=16)

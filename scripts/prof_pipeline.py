@@ -79,8 +79,15 @@ for k, f in enumerate(frames):
 tasks_p.append(post)
 cb = ConfigurationBatch(m, qp)
 print(f"whole call (pageable arrays) {med(lambda: solve_ik_batch(cb, tasks_p, 5e-3)):.3f} ms")
-pr = cProfile.Profile(); pr.enable()
+pr = cProfile.Profile(); pr.enable()  # (the whole call, Python included)
 for _ in range(5):
     solve_ik_batch(cfgs, tasks, 5e-3, out=out)
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+# the split of the batch into ranges (pink_amd.rollout.PIPELINE_SPLIT): equal ranges against shrinking ones
+import pink_amd.rollout as _R
+
+for split in [(1, 1, 1, 1), (1, 1, 1, 1, 1, 1), (30, 27, 22, 13, 8), (35, 30, 20, 10, 5), (28, 24, 20, 14, 9, 5), (40, 30, 20, 10), (32, 28, 22, 12, 6)]:
+    _R.PIPELINE_SPLIT = tuple(float(v) for v in split)
+    print(f"ranges {split}: whole call (page-locked) {med(lambda: solve_ik_batch(cfgs, tasks, 5e-3, out=out), 9):.3f} ms   "
+          f"pageable {med(lambda: solve_ik_batch(cb, tasks_p, 5e-3), 5):.3f} ms")

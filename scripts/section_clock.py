@@ -51,7 +51,10 @@ def main():
     s = BatchSolver(0)
     lib = _lib.load_library()
     lib.pinkhip_debug_section_clock.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
-    t = synthetic.make_terms(name, B, bounds=bounds, jacobians="dense" if bounds == "tight" else "kinematic")
+    if bounds == "tracking":  # (bench.py's tracking_small_errors regime: a controller following a slowly moving target)
+        t = synthetic.make_terms(name, B, bounds="kinematic", jacobians="kinematic", error_scale=0.02)
+    else:
+        t = synthetic.make_terms(name, B, bounds=bounds, jacobians="dense" if bounds == "tight" else "kinematic")
     dev = s.upload(synthetic.pack(t))
     out = (ctypes.c_uint64 * 16)()
     s.solve_device(dev)

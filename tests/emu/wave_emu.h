@@ -191,6 +191,7 @@ inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline double fast_rcp1(double x) { return 1.0 / x; }
 inline double max_raw(double a, double b) { return a > b ? a : b; }
+inline double min_raw(double a, double b) { return a < b ? a : b; }
 inline int wave_uniform(int v) { return v; }
 inline double approx_rcp(double x) { return 1.0 / x; }
 inline float approx_rcpf(float x) { return 1.0f / x; }
