@@ -87,7 +87,7 @@ pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 # the split of the batch into ranges (pink_amd.rollout.PIPELINE_SPLIT): equal ranges against shrinking ones
 import pink_amd.rollout as _R
 
-for split in [(1, 1, 1, 1), (1, 1, 1, 1, 1, 1), (30, 27, 22, 13, 8), (35, 30, 20, 10, 5), (28, 24, 20, 14, 9, 5), (40, 30, 20, 10), (32, 28, 22, 12, 6)]:
+for split in [(1, 1, 1, 1), (1, 1, 1, 1, 1, 1), (30, 27, 22, 13, 8), (40, 30, 20, 10), (18, 18, 18, 10), (1, 1, 1), (12, 18, 18, 16)]:
     _R.PIPELINE_SPLIT = tuple(float(v) for v in split)
     print(f"ranges {split}: whole call (page-locked) {med(lambda: solve_ik_batch(cfgs, tasks, 5e-3, out=out), 9):.3f} ms   "
           f"pageable {med(lambda: solve_ik_batch(cb, tasks_p, 5e-3), 5):.3f} ms")
