@@ -18,6 +18,8 @@ done
 bash scripts/pmc_probe.sh gpurun_out/pmc > gpurun_out/sq_counters.txt 2>&1
 bash scripts/pmc_probe.sh gpurun_out/pmc_jvrc --config jvrc > gpurun_out/sq_counters_jvrc.txt 2>&1
 python scripts/section_clock.py > gpurun_out/section_clock.txt 2>&1
+python scripts/section_clock.py draco3 kinematic >> gpurun_out/section_clock.txt 2>&1
+python scripts/section_clock.py draco3 tracking >> gpurun_out/section_clock.txt 2>&1
 CLOCK_W=64 PINKHIP_CLOCK_LIBRARY=$PWD/pink_amd/csrc/libpinkhip_clock_jvrc.so python scripts/section_clock.py jvrc >> gpurun_out/section_clock.txt 2>&1
 PINKHIP_CLOCK_LIBRARY=$PWD/pink_amd/csrc/libpinkhip_clock_draco3b.so python scripts/section_clock.py draco3b >> gpurun_out/section_clock.txt 2>&1
 bash scripts/pmc_probe.sh gpurun_out/pmc_draco3b --config draco3b > gpurun_out/sq_counters_draco3b.txt 2>&1
