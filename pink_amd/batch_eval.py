@@ -128,7 +128,7 @@ def _posture_task(kin: BatchKinematics, col, solver=None):
         if any(t.target_q is None for t in col):
             raise TargetNotSet("no posture target")
         qt = np.stack([t.target_q for t in col])
-    e = kin.difference(qt, kin.q)[:, root_nv:]
+    e = kin.difference(qt, kin.q, from_v=root_nv)[:, root_nv:]
     return DiagonalTaskTerm(col0=root_nv, e=e, cost=_costs(col, e.shape[1]), gain=t0.gain, lm_damping=t0.lm_damping)
 
 
@@ -239,6 +239,15 @@ def _index(idx):
     return idx
 
 
+def _fold(op, box: np.ndarray, idx, values) -> None:
+    """``box[:, idx] = op(box[:, idx], values)``: one pass over the view, in place, when ``idx`` is a run of columns."""
+    if isinstance(idx, slice):
+        view = box[:, idx]
+        op(view, values, out=view)
+    else:
+        box[:, idx] = op(box[:, idx], values)
+
+
 def limit_rows(kin: BatchKinematics, limit, dt: float, lb_: np.ndarray, ub_: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
     """Fold ``limit`` into the merged box ``lb_, ub_ [B, nv]`` (in place); returns its dense rows ``(G [B, r, nv],
     h [B, r])`` if it has any.  ``pink/solve_ik.py:107-122`` with every ``+-e_i`` row merged per coordinate."""
@@ -257,11 +266,14 @@ def limit_rows(kin: BatchKinematics, limit, dt: float, lb_: np.ndarray, ub_: np.
         iq = _index([j.idx_q for j in limit.joints])
         g = limit.config_limit_gain
         qi = kin.q[:, iq]
-        lo = g * (limit.model.lowerPositionLimit[iq] - qi)
-        up = g * (limit.model.upperPositionLimit[iq] - qi)
-        np.maximum(lb_[:, idx], lo, out=lo)
-        np.minimum(ub_[:, idx], up, out=up)
-        lb_[:, idx], ub_[:, idx] = lo, up
+        lo = np.subtract(limit.model.lowerPositionLimit[iq], qi)
+        if g != 1.0:
+            lo *= g
+        _fold(np.maximum, lb_, idx, lo)
+        up = np.subtract(limit.model.upperPositionLimit[iq], qi, out=lo)  # (lo is folded in: its storage serves again)
+        if g != 1.0:
+            up *= g
+        _fold(np.minimum, ub_, idx, up)
         return None
     if ty is VelocityLimit:
         # pink/limits/velocity_limit.py:118-120
@@ -269,8 +281,8 @@ def limit_rows(kin: BatchKinematics, limit, dt: float, lb_: np.ndarray, ub_: np.
             return None
         idx = _index(limit.indices)
         v = dt * limit.velocity_limit[idx]
-        lb_[:, idx] = np.maximum(lb_[:, idx], -v)
-        ub_[:, idx] = np.minimum(ub_[:, idx], v)
+        _fold(np.maximum, lb_, idx, -v)
+        _fold(np.minimum, ub_, idx, v)
         return None
     if ty is AccelerationLimit and not any(j.kind == "free_flyer" and j.idx_v in limit.indices for j in m.joints):
         # pink/limits/acceleration_limit.py:158-199

@@ -172,10 +172,10 @@ class _QOnly:
             self._kin = self._make()
         return self._kin
 
-    def difference(self, q0, q1):
+    def difference(self, q0, q1, from_v: int = 0):
         from .kinematics_batch import BatchKinematics
 
-        return BatchKinematics.difference(self, q0, q1)  # (reads the model and q only: no forward kinematics)
+        return BatchKinematics.difference(self, q0, q1, from_v)  # (reads the model and q only: no forward kinematics)
 
     def __getattr__(self, name):
         return getattr(self._full(), name)
