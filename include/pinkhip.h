@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PINKHIP_VERSION 110 /* 110: iters[b] carries the solver path in its high bits (PINKHIP_ITERS_*) */
+#define PINKHIP_VERSION 111 /* 110: iters[b] carries the solver path in its high bits (PINKHIP_ITERS_*) */
 
 /* API-level error codes (negative). */
 #define PINKHIP_OK 0
@@ -227,6 +227,13 @@ typedef struct pinkhip_model_desc {
   const double *q_min;         /* [nq] model.lowerPositionLimit                      */
   const double *q_max;         /* [nq] model.upperPositionLimit                      */
   const double *v_max;         /* [nv] model.velocityLimit                           */
+  /* Relative frame slots (pink/tasks/relative_frame_task.py:142-231), optional (NULL: none): slot f regulates the pose
+   * of its frame in the frame `frame_root_placement[f]` attached to joint `frame_root_joint[f]` (-1 = world;
+   * -2 = an ordinary slot, target in the world).  T_target[b, f] is then the target pose IN THAT ROOT FRAME; the
+   * rows written / stacked for the slot are those of the RelativeFrameTask up to a common sign of J and e, which
+   * H = J^T W J and c = -J^T W e do not see (pink/tasks/task.py:145-167). */
+  const int32_t *frame_root_joint;     /* [nf] */
+  const double *frame_root_placement;  /* [nf,12] */
 } pinkhip_model_desc;
 int pinkhip_model_create(pinkhip_handle *h, const pinkhip_model_desc *desc, pinkhip_model **model);
 int pinkhip_model_destroy(pinkhip_handle *h, pinkhip_model *model);

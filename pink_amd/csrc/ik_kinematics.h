@@ -37,6 +37,11 @@ struct ModelDev {
   const int *dof_joint;     // [nv]  joint owning tangent column j
   const int *dof_sub;       // [nv]  index inside that joint's tangent (0..5 for the free-flyer)
   const unsigned char *anc; // [nf, nj]  joint is the frame's joint or one of its ancestors
+  // relative frame slots (pink/tasks/relative_frame_task.py): the pose of frame f is regulated in the frame
+  // (root joint, root placement) instead of the world; frame_root_joint[f] = -2: an ordinary slot
+  const int *frame_root_joint;          // [nf]  -1 = world, -2 = not relative
+  const double *frame_root_placement;   // [nf, 12]
+  const unsigned char *ancr;            // [nf, nj]  joint is the root frame's joint or one of its ancestors
   const double *q_min, *q_max;  // [nq]
   const double *v_max;          // [nv]
 };
@@ -230,7 +235,7 @@ struct HbmSink {
   static constexpr bool kKeep = false;
   double *es = nullptr;
   double lin[3], ang[3], lb, ub, post_e, qv;
-  unsigned anc;
+  unsigned anc, ancr;
 };
 
 template <int W, bool FUSED = false, bool STEP = false, class Sink = HbmSink>
@@ -254,10 +259,13 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
   // before the poses are composed, and the kernel is bound by exactly such dependent round trips.
   int pf_fj = -1, pf_jt = 0, pf_sub = 0, pf_ty = 0;
   double pf_FP[12], pf_Tt[12], pf_ax[3];
-  unsigned pf_anc = 0;  // bit f: joint of column li is an ancestor of frame f (first 32 frames)
+  unsigned pf_anc = 0;   // bit f: joint of column li is an ancestor of frame f (first 32 frames)
+  unsigned pf_ancr = 0;  // bit f: ... of the root frame of relative slot f
+  int pf_rj = -2;
   if constexpr (FUSED) {
     const int f0 = li < m.nf ? li : 0;
     pf_fj = m.frame_joint[f0];
+    pf_rj = m.frame_root_joint[f0];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       pf_FP[i] = m.frame_placement[12 * f0 + i];
@@ -269,7 +277,10 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
     pf_ty = m.jtype[pf_jt];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pf_ax[i] = m.axis[3 * pf_jt + i];
-    for (int f = 0; f < m.nf && f < 32; ++f) pf_anc |= (m.anc[f * m.nj + pf_jt] != 0 ? 1u : 0u) << f;
+    for (int f = 0; f < m.nf && f < 32; ++f) {
+      pf_anc |= (m.anc[f * m.nj + pf_jt] != 0 ? 1u : 0u) << f;
+      pf_ancr |= (m.ancr[f * m.nj + pf_jt] != 0 ? 1u : 0u) << f;
+    }
   }
 
   // 1. pose of joint li in its parent's frame
@@ -358,6 +369,25 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
 #pragma unroll
         for (int i = 0; i < 12; ++i) F[i] = FP[i];
       }
+      // A relative slot (relative_frame_task.py:142-231): the target is given in the root frame r.  With the target
+      // carried into the world by the root's current pose, T_t' = T_0r T_rt, the task's error log(T_rt^-1 T_rf) is
+      // log(T_t'^-1 T_f) = -log(T_f^-1 T_t') and its Jacobian Jlog6(T_tf) (fJ_0f - Ad(T_fr) rJ_0r) is
+      // Jlog6(T_t'^-1 T_f) X_f^-1 [lin; ang] ([j anc. of f] - [j anc. of r]) -- Ad(T_fr) X_r^-1 = X_f^-1: the rows of an
+      // ordinary FrameTask on T_t', negated, with a signed ancestor indicator.  J and e change sign together: the
+      // same H and c (task.py:145-167).
+      const int rj = first ? pf_rj : m.frame_root_joint[f];
+      if (rj != -2) {
+        double Rr[12], Tw[12];
+        if (rj >= 0) {
+          se3_mul(oM + 12 * rj, m.frame_root_placement + 12 * f, Rr);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) Rr[i] = m.frame_root_placement[12 * f + i];
+        }
+        se3_mul(Rr, Tt, Tw);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tt[i] = Tw[i];
+      }
       if (valid && a.T_frames) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) a.T_frames[(b * m.nf + f) * 12 + i] = F[i];
@@ -442,9 +472,12 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
           sink->ang[i] = ang[i];
         }
         sink->anc = pf_anc;
+        sink->ancr = pf_ancr;
       }
       for (int f = 0; f < (Sink::kKeep ? 0 : m.nf); ++f) {
-        const bool on = (first && f < 32) ? ((pf_anc >> f) & 1u) != 0 : m.anc[f * m.nj + jt] != 0;
+        // (+1: ancestor of the frame only, -1: of the root frame of a relative slot only, 0: of both or neither)
+        const int on = (first && f < 32) ? (int)((pf_anc >> f) & 1u) - (int)((pf_ancr >> f) & 1u)
+                                         : (int)(m.anc[f * m.nj + jt] != 0) - (int)(m.ancr[f * m.nj + jt] != 0);
         const double *UV = Jls + 36 * f;
         double *Jo = a.J_out + b * a.sJo + (long long)(6 * f) * m.nv;
 #pragma unroll
@@ -453,8 +486,8 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
                              UV[9 + 3 * i] * ang[0] + UV[9 + 3 * i + 1] * ang[1] + UV[9 + 3 * i + 2] * ang[2];
           const double bot = UV[3 * i] * ang[0] + UV[3 * i + 1] * ang[1] + UV[3 * i + 2] * ang[2];
           if (valid) {
-            Jo[i * m.nv + j] = on ? -top : 0.0;
-            Jo[(i + 3) * m.nv + j] = on ? -bot : 0.0;
+            Jo[i * m.nv + j] = on ? (on > 0 ? -top : top) : 0.0;
+            Jo[(i + 3) * m.nv + j] = on ? (on > 0 ? -bot : bot) : 0.0;
           }
         }
       }

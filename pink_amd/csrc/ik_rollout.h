@@ -59,7 +59,7 @@ struct FkTerms {
   double lb = 0.0, ub = 0.0, x = 0.0;
   int status = 0;
   double lin[3], ang[3], post_e = 0.0, qv = 0.0;
-  unsigned anc = 0;
+  unsigned anc = 0, ancr = 0;  // bit f: this column's joint is an ancestor of frame f / of the root frame of relative slot f
   double *es = nullptr;        // LDS: errors of the dense rows [6 nf + n_crow]
   const double *UV = nullptr;  // LDS: U (9), V (9) per frame, pitch 36
   int nf = 0, n_crow = 0, col = 0, nvc = 0;  // frames, constant rows, this lane's tangent column, row pitch of crow_A
@@ -76,14 +76,15 @@ struct FkTerms {
       return;
     }
     const double *u = UV + 36 * f;
-    const bool on = ((anc >> f) & 1u) != 0;
+    // (-1: ancestor of the frame only, +1: of the root frame of a relative slot only, 0: of both or neither)
+    const double sgn = (double)((int)((ancr >> f) & 1u) - (int)((anc >> f) & 1u));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double top = u[3 * i] * lin[0] + u[3 * i + 1] * lin[1] + u[3 * i + 2] * lin[2] + u[9 + 3 * i] * ang[0] +
                          u[9 + 3 * i + 1] * ang[1] + u[9 + 3 * i + 2] * ang[2];
       const double bot = u[3 * i] * ang[0] + u[3 * i + 1] * ang[1] + u[3 * i + 2] * ang[2];
-      six[i] = on ? -top : 0.0;
-      six[i + 3] = on ? -bot : 0.0;
+      six[i] = sgn * top;
+      six[i + 3] = sgn * bot;
     }
   }
   __device__ __forceinline__ double error(int k) const { return es[k]; }

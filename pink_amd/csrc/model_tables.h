@@ -15,7 +15,8 @@ namespace pinkhip {
 struct ModelImage {
   std::vector<char> bytes;  // what goes to the device, 8-byte aligned sections
   size_t off_parent, off_jtype, off_idx_q, off_idx_v, off_placement, off_axis, off_frame_joint,
-      off_frame_placement, off_dof_joint, off_dof_sub, off_anc, off_q_min, off_q_max, off_v_max;
+      off_frame_placement, off_dof_joint, off_dof_sub, off_anc, off_q_min, off_q_max, off_v_max, off_root_joint,
+      off_root_placement, off_ancr;
   int nj, nq, nv, nf, root_nv;
 };
 
@@ -53,6 +54,24 @@ inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im
       j = d.parent[j];
     }
   }
+  // relative frame slots: the ancestors of the root frame's joint; an ordinary slot has none
+  std::vector<unsigned char> ancr((size_t)d.nf * d.nj, 0);
+  std::vector<int32_t> root_joint(d.nf, -2);
+  std::vector<double> root_placement((size_t)12 * d.nf, 0.0);
+  if (d.frame_root_joint) {
+    if (!d.frame_root_placement) return "frame_root_placement must not be NULL when frame_root_joint is given";
+    for (int f = 0; f < d.nf; ++f) {
+      int j = d.frame_root_joint[f];
+      if (j < -2 || j >= d.nj) return "frame_root_joint out of range";
+      root_joint[f] = j;
+      if (j == -2) continue;
+      std::memcpy(root_placement.data() + 12 * f, d.frame_root_placement + 12 * f, 12 * sizeof(double));
+      while (j >= 0) {
+        ancr[(size_t)f * d.nj + j] = 1;
+        j = d.parent[j];
+      }
+    }
+  }
   im.nj = d.nj;
   im.nq = d.nq;
   im.nv = d.nv;
@@ -79,6 +98,9 @@ inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im
   im.off_q_min = put(d.q_min, 8 * d.nq);
   im.off_q_max = put(d.q_max, 8 * d.nq);
   im.off_v_max = put(d.v_max, 8 * d.nv);
+  im.off_root_joint = put(root_joint.data(), 4 * d.nf);
+  im.off_root_placement = put(root_placement.data(), 8 * 12 * d.nf);
+  im.off_ancr = put(ancr.data(), ancr.size());
   return std::string();
 }
 
@@ -105,6 +127,9 @@ inline ModelDevT model_view(const ModelImage &im, const char *base) {
   m.q_min = reinterpret_cast<const double *>(base + im.off_q_min);
   m.q_max = reinterpret_cast<const double *>(base + im.off_q_max);
   m.v_max = reinterpret_cast<const double *>(base + im.off_v_max);
+  m.frame_root_joint = reinterpret_cast<const int *>(base + im.off_root_joint);
+  m.frame_root_placement = reinterpret_cast<const double *>(base + im.off_root_placement);
+  m.ancr = reinterpret_cast<const unsigned char *>(base + im.off_ancr);
   return m;
 }
 

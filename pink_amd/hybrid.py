@@ -3,7 +3,7 @@
 A task stack the whole-step kernel does not form on chip (``pink_amd/solve_ik.py``: anything beyond FrameTasks + one
 PostureTask under the default limits) used to be evaluated entirely on the host: forward kinematics, body Jacobians,
 ``log6`` / ``Jlog6`` and the 6 x 6 by 6 x nv products of every FrameTask for the whole batch in NumPy, then ~6 kB per
-instance across PCIe.  When every task with a dense Jacobian is a FrameTask -- the other tasks of the stack being the
+instance across PCIe.  When every task with a dense Jacobian is a FrameTask or a RelativeFrameTask -- the other tasks of the stack being the
 identity-Jacobian ones (PostureTask, DampingTask, LowAccelerationTask, JointVelocityTask: ``pink/tasks/posture_task.py``,
 ``damping_task.py``, ``low_acceleration_task.py``, ``joint_velocity_task.py``) -- that part needs nothing but ``q`` and
 the targets: ``pinkhip_fk_frame_tasks_device`` writes the rows straight into the packed ``J`` / ``e`` streams in HBM
@@ -34,10 +34,15 @@ def plan(kin_model, slots: Sequence, constraints) -> Optional[List[int]]:
     from .tasks.frame_task import FrameTask
     from .tasks.linear_holonomic_task import JointVelocityTask
     from .tasks.posture_task import DampingTask, LowAccelerationTask, PostureTask
+    from .tasks.relative_frame_task import RelativeFrameTask
 
     if constraints or not hasattr(kin_model, "joints"):
         return None
-    frames = [k for k, col in enumerate(slots) if type(col[0]) is FrameTask]
+    frames = [k for k, col in enumerate(slots) if type(col[0]) in (FrameTask, RelativeFrameTask)]
+    for k in frames:  # (one frame -- and root -- per slot: the device model holds them)
+        t0 = slots[k][0]
+        if any(type(t) is not type(t0) or t.frame != t0.frame or getattr(t, "root", None) != getattr(t0, "root", None) for t in slots[k]):
+            return None
     if not frames or len(frames) > MAX_FRAME_TASKS:
         return None
     for k, col in enumerate(slots):
@@ -108,8 +113,11 @@ def solve(state: HybridState, kin_q: np.ndarray, kin, slots: Sequence, frame_slo
     cost = np.ascontiguousarray(cost)
     e_full = np.zeros((B, K))  # (the kernel overwrites the FrameTask rows: one contiguous upload instead of a strided one)
     e_full[:, Kd:] = b0.e
-    targets = np.ascontiguousarray(np.stack([be._frame_targets(col, B, "transform_target_to_world", "no target set for frame '{0.frame}'")
-                                             for col in fcols], axis=1))  # [B, nf, 12]
+    # (a RelativeFrameTask's target lives in its root frame: a relative slot of the device model, include/pinkhip.h)
+    targets = np.ascontiguousarray(np.stack([
+        be._frame_targets(col, B, "transform_target_to_root", "target pose of frame '{0.frame}' in frame '{0.root}' is undefined")
+        if hasattr(col[0], "root") else be._frame_targets(col, B, "transform_target_to_world", "no target set for frame '{0.frame}'")
+        for col in fcols], axis=1))  # [B, nf, 12]
     i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)  # noqa: E731
     f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)  # noqa: E731
     task_rows = i32([6 * i for i in range(nf + 1)] + [Kd + int(r) for r in b0.task_rows[1:]])

@@ -56,6 +56,7 @@ class ModelDesc(ctypes.Structure):
         ("parent", c_int32_p), ("jtype", c_int32_p), ("idx_q", c_int32_p), ("idx_v", c_int32_p),
         ("placement", c_double_p), ("axis", c_double_p), ("frame_joint", c_int32_p),
         ("frame_placement", c_double_p), ("q_min", c_double_p), ("q_max", c_double_p), ("v_max", c_double_p),
+        ("frame_root_joint", c_int32_p), ("frame_root_placement", c_double_p),
     ]
 
 
@@ -66,11 +67,13 @@ def pose12(T) -> np.ndarray:
 
 class ModelArrays:
     """NumPy tables of a :class:`pink_amd.configuration.Model` for ``pinkhip_model_create``;
-    ``frames`` lists the frame names the rollout needs (their order is the frame index)."""
+    ``frames`` lists the frame names the rollout needs (their order is the frame index).  An entry ``(frame, root)``
+    is a relative slot: the pose of ``frame`` in ``root`` (``pink/tasks/relative_frame_task.py``)."""
 
-    def __init__(self, model: Model, frames: Sequence[str]):
+    def __init__(self, model: Model, frames: Sequence):
         self.model = model
-        self.frames = list(frames)
+        self.roots = [f[1] if isinstance(f, tuple) else None for f in frames]
+        self.frames = [f[0] if isinstance(f, tuple) else f for f in frames]
         js = model.joints
         i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)  # noqa: E731
         self.parent = i32([j.parent for j in js])
@@ -100,6 +103,12 @@ class ModelArrays:
         d.q_min = self.q_min.ctypes.data_as(c_double_p)
         d.q_max = self.q_max.ctypes.data_as(c_double_p)
         d.v_max = self.v_max.ctypes.data_as(c_double_p)
+        if any(r is not None for r in self.roots):
+            rf = [None if r is None else model.frames[model.getFrameId(r)] for r in self.roots]
+            self.frame_root_joint = i32([-2 if f is None else f.joint for f in rf])
+            self.frame_root_placement = np.ascontiguousarray([np.zeros(12) if f is None else pose12(f.placement) for f in rf], dtype=np.float64)
+            d.frame_root_joint = self.frame_root_joint.ctypes.data_as(c_int32_p)
+            d.frame_root_placement = self.frame_root_placement.ctypes.data_as(c_double_p)
         self.desc = d
 
 
@@ -157,8 +166,12 @@ class DeviceRollout:
         self.fused = fused if fused == "kernel" else bool(fused)
         self.B = B = int(q0.shape[0])
         self.nv, self.nq = model.nv, model.nq
-        self.frames = [ft[0] for ft in frame_tasks]
-        self.arrays = ModelArrays(model, self.frames)
+        # (a frame task (frame, ...) regulates the frame in the world; ((frame, root), ...) the pose of frame in root --
+        # a RelativeFrameTask, pink/tasks/relative_frame_task.py: a relative slot of the device model)
+        self.arrays = ModelArrays(model, [ft[0] for ft in frame_tasks])
+        self.frames = self.arrays.frames
+        if any(r is not None for r in self.arrays.roots) and self.fused != "kernel":
+            raise ValueError('relative frame tasks need the whole-step kernel: fused="kernel"')
         self.dmodel = api.model_create(self.arrays.desc)
         nf, nv, nq = len(self.frames), self.nv, self.nq
         root_nv = get_root_joint_dim(model)[1]
@@ -225,11 +238,13 @@ class DeviceRollout:
         n_lim = len(self.lim_h)
         bf, ba, bs, bb, bg, brow, bsafe = [], [], [], [], [], [n_lim], []
         for bar in position_barriers:
-            if bar.frame not in self.frames:
+            # (the frame's world pose and Jacobian: an ordinary slot -- a relative slot carries a signed ancestor table)
+            plain = [i for i, (n, r) in enumerate(zip(self.frames, self.arrays.roots)) if n == bar.frame and r is None]
+            if not plain:
                 raise ValueError(f"position barrier on frame {bar.frame!r}: the frame must carry one of the frame tasks")
             if not getattr(bar, "identity_gain_function", False):
                 raise ValueError("position barriers on the device use the identity class-K function (the default)")
-            f = self.frames.index(bar.frame)
+            f = plain[0]
             gains = np.asarray(bar.gain, dtype=float)
             k = 0
             for sign, bound in ((1.0, bar.p_min), (-1.0, bar.p_max)):

@@ -366,9 +366,10 @@ def _pack_configurations_per_instance(configurations, tasks, dt, damping, limits
 
 
 def _spec_of(task):
-    """``(frame, position cost, orientation cost, gain, lm_damping)`` of a FrameTask, hashable."""
-    return (task.frame, tuple(float(v) for v in np.broadcast_to(np.asarray(task.position_cost, float), (3,))),
-            tuple(float(v) for v in np.broadcast_to(np.asarray(task.orientation_cost, float), (3,))), float(task.gain), float(task.lm_damping))
+    """``(frame, position cost, orientation cost, gain, lm_damping)`` of a FrameTask, hashable; a RelativeFrameTask has
+    ``(frame, root)`` in the first place (a relative slot of the device model, ``pink_amd/rollout.py``)."""
+    name = (task.frame, task.root) if hasattr(task, "root") else task.frame
+    return (name, tuple(float(v) for v in task.cost[0:3]), tuple(float(v) for v in task.cost[3:6]), float(task.gain), float(task.lm_damping))
 
 
 def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints):
@@ -394,7 +395,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
             return None
     plan = _device_kinematics_plan_tasks(configurations, tasks)
     if plan is not None and barriers:
-        frames = [sp[0] for sp in plan[2]]
+        frames = [sp[0] for sp in plan[2] if not isinstance(sp[0], tuple)]  # (ordinary slots: a barrier needs the world pose)
         if any(bar.frame not in frames for bar in barriers):
             return None
         plan = plan + (tuple(barriers), gain)
@@ -480,8 +481,10 @@ def _extras_key(extras):
 def _device_kinematics_plan_tasks(configurations, tasks):
     """The task half of :func:`_device_kinematics_plan`: ``(model, q, specs, targets, posture, extras)`` or ``None``."""
     from .configuration import ConfigurationBatch
+    from .exceptions import TargetNotSet
     from .tasks.frame_task import FrameTask
     from .tasks.posture_task import PostureTask
+    from .tasks.relative_frame_task import RelativeFrameTask
 
     B = len(configurations)
     as_arrays = isinstance(configurations, ConfigurationBatch)
@@ -506,9 +509,13 @@ def _device_kinematics_plan_tasks(configurations, tasks):
                 elif t.transform_target_to_world is not None:
                     targets.append(np.broadcast_to(_pose12(t.transform_target_to_world), (B, 12)))
                 else:
-                    from .exceptions import TargetNotSet
-
                     raise TargetNotSet(f"no target set for frame '{t.frame}'")
+                specs.append(_spec_of(t))
+            elif type(t) is RelativeFrameTask:
+                # the pose of one frame in another (relative_frame_task.py:142-231): one target, in the root frame
+                if t.transform_target_to_root is None:
+                    raise TargetNotSet(f"target pose of frame '{t.frame}' in frame '{t.root}' is undefined")
+                targets.append(np.broadcast_to(_pose12(t.transform_target_to_root), (B, 12)))
                 specs.append(_spec_of(t))
             elif type(t) is PostureTask:
                 if posture is not None or np.ndim(t.cost) != 0:
@@ -538,6 +545,15 @@ def _device_kinematics_plan_tasks(configurations, tasks):
     specs, targets, posture, extras = [], [], None, []
     for col in slots:
         t0 = col[0]
+        if type(t0) is RelativeFrameTask:
+            if any(type(t) is not RelativeFrameTask or t.frame != t0.frame or t.root != t0.root or t.gain != t0.gain
+                   or t.lm_damping != t0.lm_damping or not np.array_equal(t.cost, t0.cost) for t in col):
+                return None
+            if any(t.transform_target_to_root is None for t in col):
+                raise TargetNotSet(f"target pose of frame '{t0.frame}' in frame '{t0.root}' is undefined")
+            specs.append(_spec_of(t0))
+            targets.append(np.stack([_pose12(t.transform_target_to_root) for t in col]))
+            continue
         if type(t0) not in (FrameTask, PostureTask):
             # a task the kernel forms from tables: one object shared by every instance
             x = _extra_task(model, t0) if all(t is t0 for t in col) else None
@@ -610,7 +626,8 @@ def _model_fingerprint(model, frames) -> int:
     """Content hash of what a cached device state bakes in from the model: joint limits, velocity limits and the
     placements of the task frames (edits to them must not be served from the cache)."""
     parts = [model.lowerPositionLimit.tobytes(), model.upperPositionLimit.tobytes(), model.velocityLimit.tobytes()]
-    for name in frames:
+    names = [n for entry in frames for n in (entry if isinstance(entry, tuple) else (entry,))]  # (frame, root) of a relative slot
+    for name in names:
         f = model.frames[model.getFrameId(name)]
         parts.append(np.asarray(f.placement.rotation, dtype=float).tobytes() + np.asarray(f.placement.translation, dtype=float).tobytes())
         parts.append(str(f.joint).encode())
@@ -820,7 +837,7 @@ def _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constrai
         limits = [model.configuration_limit, model.velocity_limit]
         if getattr(model, "floating_base_velocity_limit", None) is not None:
             limits.append(model.floating_base_velocity_limit)
-    frames = tuple(slots[k][0].frame for k in frame_slots)
+    frames = tuple((slots[k][0].frame, slots[k][0].root) if hasattr(slots[k][0], "root") else slots[k][0].frame for k in frame_slots)
     key = ("hybrid", id(model), _model_fingerprint(model, frames), B, frames)
     cache = _rollout_cache(api)
     state = cache.pop(key, None)

@@ -295,10 +295,16 @@ def test_hybrid_route_forms_frame_task_rows_on_the_device(backend, free_flyer):
     for b in range(6 if backend == "emu" else B):
         v = solve_ik(cfgs[b], per_instance[b], dt, **kw)
         assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
-    # a dense task that is not a FrameTask, or an equality constraint: the all-host evaluation serves the call
+    # a RelativeFrameTask is a relative slot of the same kernel ...
     rt = RelativeFrameTask("tool0", "joint_5", 1.0, 0.0)
     rt.set_target(cfgs[0].get_transform("tool0", "joint_5"))
-    solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [rt], dt, **kw)
+    V_rel = solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [rt], dt, **kw)
+    assert pink_amd.last_solve_stats()["route"] == "hybrid"
+    V_rel_host = solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [rt], dt, device_kinematics=False, gpu_frame_tasks=False, **kw)
+    assert np.abs(V_rel - V_rel_host).max() < 1e-8 * max(1.0, np.abs(V_rel_host).max())
+    # ... any other dense task next to explicit limits: the all-host evaluation serves the call
+    jc = JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 10.0, cfgs[0])
+    solve_ik_batch(ConfigurationBatch(m, q), shared + rest + [jc], dt, **kw)
     assert pink_amd.last_solve_stats()["route"] == "host-evaluated"
 
 
@@ -391,3 +397,62 @@ def test_whole_step_kernel_forms_coupling_and_identity_tasks_on_chip(backend, fr
         assert pink_amd.last_solve_stats()["route"] != "device"
         V_host = solve_ik_batch(cb, frames + [po, lh], dt, device_kinematics=False, gpu_frame_tasks=False)
         assert np.abs(V - V_host).max() < 1e-8 * max(1.0, np.abs(V_host).max())
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_relative_frame_tasks_are_formed_on_the_device(backend, free_flyer):
+    """RelativeFrameTask (pink/tasks/relative_frame_task.py:142-231) next to FrameTasks and a PostureTask: a relative
+    slot of the device model -- the target carried into the world by the root frame's current pose, a signed ancestor
+    indicator on the columns -- in the whole-step kernel (device route) and in the frame-row kernel (hybrid route).
+    Same velocities as the all-host evaluation and as one solve_ik per configuration; root frame below or above the
+    task frame in the tree; per-instance task objects with their own targets."""
+    m = build_chain(10, free_flyer=free_flyer, seed=9, limit=2.8, velocity=6.0)
+    m.add_frame("mid", m.getJointId("joint_4"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    rng = np.random.default_rng(44)
+    B, dt = 7, 5e-3
+    q = _draw_q(m, B, rng)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3, gain=0.9)
+    R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    for b, c in enumerate(cfgs):
+        T = c.get_transform_frame_to_world("tool0") * exp6(0.05 * rng.normal(size=6))
+        R[b], t[b] = T.rotation, T.translation
+    ft.set_target_poses(R, t)
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    r1 = RelativeFrameTask("joint_8", "mid", 1.0, 0.4, lm_damping=1e-3, gain=0.8)  # root above the frame
+    r1.set_target(cfgs[0].get_transform("joint_8", "mid") * exp6(0.05 * rng.normal(size=6)))
+    r2 = RelativeFrameTask("joint_3", "tool0", [1.0, 0.5, 2.0], 0.3)  # root below the frame
+    r2.set_target(cfgs[1].get_transform("joint_3", "tool0") * exp6(0.05 * rng.normal(size=6)))
+    cb = ConfigurationBatch(m, q)
+    for name, ts in (("one", [ft, r1, po]), ("two, interleaved", [r2, ft, r1, po, DampingTask(cost=1e-2)])):
+        V = solve_ik_batch(cb, ts, dt, device_kinematics=True)
+        assert pink_amd.last_solve_stats()["route"] == "device", name
+        V_rows = solve_ik_batch(cb, ts, dt, device_kinematics="frame_rows")
+        assert pink_amd.last_solve_stats()["route"] == "hybrid", name
+        V_host = solve_ik_batch(cb, ts, dt, device_kinematics=False, gpu_frame_tasks=False)
+        assert pink_amd.last_solve_stats()["route"] == "host-evaluated", name
+        scale = max(1.0, np.abs(V_host).max())
+        assert np.abs(V - V_host).max() < 1e-8 * scale and np.abs(V_rows - V_host).max() < 1e-8 * scale and np.abs(V).max() > 1e-3, name
+        for b in range(3):  # Pink's calling pattern
+            own = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3, gain=0.9)
+            own.set_target(SE3(R[b], t[b]))
+            v = solve_ik(cfgs[b], [own if t_ is ft else t_ for t_ in ts], dt)
+            assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), (name, b)
+    # per-instance task objects, each with its own relative target
+    per = []
+    for b, c in enumerate(cfgs):
+        fb = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3, gain=0.9)
+        fb.set_target(SE3(R[b], t[b]))
+        rb = RelativeFrameTask("joint_8", "mid", 1.0, 0.4, lm_damping=1e-3, gain=0.8)
+        rb.set_target(c.get_transform("joint_8", "mid") * exp6(0.05 * rng.normal(size=6)))
+        per.append([fb, rb, po])
+    V = solve_ik_batch(cfgs, per, dt, device_kinematics=True)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    for b in range(B):
+        v = solve_ik(cfgs[b], per[b], dt)
+        assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
+    # a position barrier needs the world pose of its frame: an ordinary slot has to carry it
+    bar = PositionBarrier("joint_8", indices=[2], p_max=np.array([10.0]), gain=np.array([50.0]), safe_displacement_gain=1.0)
+    with pytest.raises(pink_amd.PinkError):
+        solve_ik_batch(cb, [ft, r1, po], dt, barriers=[bar], device_kinematics=True)
