@@ -46,6 +46,19 @@ struct ModelDev {
   const double *v_max;          // [nv]
 };
 
+// B <- A * B in place, one column of B at a time (three temporaries)
+__device__ inline void se3_lmul(const double *A, double *Bm) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double c0 = Bm[j], c1 = Bm[3 + j], c2 = Bm[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Bm[3 * i + j] = A[3 * i] * c0 + A[3 * i + 1] * c1 + A[3 * i + 2] * c2;
+  }
+  const double p0 = Bm[9], p1 = Bm[10], p2 = Bm[11];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Bm[9 + i] = A[3 * i] * p0 + A[3 * i + 1] * p1 + A[3 * i + 2] * p2 + A[9 + i];
+}
+
 // C = A * B for 12-double poses (rotation row-major, translation)
 __device__ inline void se3_mul(const double *A, const double *Bm, double *C) {
 #pragma unroll
@@ -349,6 +362,20 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
     wave_sync();
   }
   if constexpr (FUSED) {
+    // A relative slot (relative_frame_task.py:142-231): the target is given in the root frame r.  With the target
+    // carried into the world by the root's current pose, T_t' = T_0r T_rt, the task's error log(T_rt^-1 T_rf) is
+    // log(T_t'^-1 T_f) = -log(T_f^-1 T_t') and its Jacobian Jlog6(T_tf) (fJ_0f - Ad(T_fr) rJ_0r) is
+    // Jlog6(T_t'^-1 T_f) X_f^-1 [lin; ang] ([j anc. of f] - [j anc. of r]) -- Ad(T_fr) X_r^-1 = X_f^-1: the rows of an
+    // ordinary FrameTask on T_t', negated, with a signed ancestor indicator.  J and e change sign together: the
+    // same H and c (task.py:145-167).  The target is composed here, in place and column by column, before the frame
+    // loop below holds five poses in registers (inside it the whole-step kernel spilled ninety registers more);
+    // relative slots are among the first W frames (model_tables.h).
+    if (wave_any(pf_rj != -2)) {  // (rare: wave-uniform)
+      if (li < m.nf && pf_rj != -2) {
+        se3_lmul(m.frame_root_placement + 12 * li, pf_Tt);
+        if (pf_rj >= 0) se3_lmul(oM + 12 * pf_rj, pf_Tt);
+      }
+    }
     // 3. lane = frame: pose, FrameTask error, and the two 3 x 3 blocks that turn a WORLD twist [lin; ang] of a
     //    joint into the six rows of the task Jacobian:  J_task = -Jlog6(T_t^-1 T_f) X_f^-1 [lin; ang]  with
     //    X_f^-1 = [[R_f^T, -R_f^T [p_f]x], [0, R_f^T]] and Jlog6 = [[A, C A], [0, A]]  gives
@@ -368,25 +395,6 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
       } else {
 #pragma unroll
         for (int i = 0; i < 12; ++i) F[i] = FP[i];
-      }
-      // A relative slot (relative_frame_task.py:142-231): the target is given in the root frame r.  With the target
-      // carried into the world by the root's current pose, T_t' = T_0r T_rt, the task's error log(T_rt^-1 T_rf) is
-      // log(T_t'^-1 T_f) = -log(T_f^-1 T_t') and its Jacobian Jlog6(T_tf) (fJ_0f - Ad(T_fr) rJ_0r) is
-      // Jlog6(T_t'^-1 T_f) X_f^-1 [lin; ang] ([j anc. of f] - [j anc. of r]) -- Ad(T_fr) X_r^-1 = X_f^-1: the rows of an
-      // ordinary FrameTask on T_t', negated, with a signed ancestor indicator.  J and e change sign together: the
-      // same H and c (task.py:145-167).
-      const int rj = first ? pf_rj : m.frame_root_joint[f];
-      if (rj != -2) {
-        double Rr[12], Tw[12];
-        if (rj >= 0) {
-          se3_mul(oM + 12 * rj, m.frame_root_placement + 12 * f, Rr);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 12; ++i) Rr[i] = m.frame_root_placement[12 * f + i];
-        }
-        se3_mul(Rr, Tt, Tw);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Tt[i] = Tw[i];
       }
       if (valid && a.T_frames) {
 #pragma unroll

@@ -65,6 +65,7 @@ inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im
       if (j < -2 || j >= d.nj) return "frame_root_joint out of range";
       root_joint[f] = j;
       if (j == -2) continue;
+      if (f >= 16) return "relative frame slots must be among the first 16 frames";  // (one lane per such slot in every kernel)
       std::memcpy(root_placement.data() + 12 * f, d.frame_root_placement + 12 * f, 12 * sizeof(double));
       while (j >= 0) {
         ancr[(size_t)f * d.nj + j] = 1;
