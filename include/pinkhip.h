@@ -336,6 +336,11 @@ typedef struct pinkhip_rollout_step {
   const double *const_b;     /* [n_const_rows] device */
   int32_t posture_task;
   const double *diag_error;  /* [desc.K - desc.Kd] device */
+  /* AccelerationLimit on the joints behind the root (pink/limits/acceleration_limit.py:158-199), folded into the box
+   * on chip: [3, nv] device -- a_max (0: no bound on that tangent coordinate), Delta_q_prev, has_configuration_limit
+   * (0 / 1) -- or NULL:  dq <= min(a dt^2 + dq_prev, dt sqrt(2 a (q_max - q))),  -dq <= min(a dt^2 - dq_prev,
+   * dt sqrt(2 a (q - q_min))), the braking-distance terms only where the joint has a configuration limit. */
+  const double *acc_limit;
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);

@@ -111,7 +111,7 @@ class RolloutStep(ctypes.Structure):
         ("root_box", ctypes.c_void_p), ("n_limit_rows", ctypes.c_int32), ("limit_rows", ctypes.c_void_p),
         ("limit_h", ctypes.c_void_p), ("dq_scale", ctypes.c_double),
         ("n_const_rows", ctypes.c_int32), ("const_rows", ctypes.c_void_p), ("const_q0", ctypes.c_void_p), ("const_b", ctypes.c_void_p),
-        ("posture_task", ctypes.c_int32), ("diag_error", ctypes.c_void_p),
+        ("posture_task", ctypes.c_int32), ("diag_error", ctypes.c_void_p), ("acc_limit", ctypes.c_void_p),
     ]
 
 

@@ -153,10 +153,11 @@ inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md, 
   return SweepChoice{0, 0, 0};
 }
 
-inline PackedChoice select_rollout(int nv, int nj, int fk_doubles) {
+inline PackedChoice select_rollout(int nv, int nj, int fk_doubles, bool needed = false) {
   // robots that fit an 8-lane group keep the two-launch step: padding them to 16 lanes halves the robots per
-  // wavefront (measured, 6-dof arm: 0.107 ms in one kernel at NV = 12 against 0.068 ms in two launches at NV = 6)
-  if (nv <= 8) return PackedChoice{0, 0};
+  // wavefront (measured, 6-dof arm: 0.107 ms in one kernel at NV = 12 against 0.068 ms in two launches at NV = 6) --
+  // unless the task stack has rows only this kernel forms (`needed`: constant rows, extra identity tasks, relative slots)
+  if (nv <= 8 && !needed) return PackedChoice{0, 0};
 #define PINKHIP_PICK(NV_, W_)                                                                              \
   if (nv <= NV_ && nj <= W_)                                                                               \
     return 8 * rollout_lds_doubles(NV_, W_, fk_doubles) * (64 / W_) + 16 <= 65536 ? PackedChoice{NV_, W_} : PackedChoice{0, 0};

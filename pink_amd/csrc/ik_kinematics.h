@@ -174,8 +174,12 @@ __device__ inline void integrate_joint(const ModelDev &m, int j, double *q, cons
 // configuration qi (configuration_limit.py:50-56, 111-120; velocity_limit.py:61-64, 118-120).  root_box (or NULL):
 // lo[6], hi[6] for the tangent coordinates of the free-flyer -- the axis-aligned rows of a
 // FloatingBaseVelocityLimit (floating_base_velocity_limit.py:104-148), which do not depend on q.
+// acc: [3, nv] tables of an AccelerationLimit on the joints behind the root (acceleration_limit.py:158-199) -- a_max
+// (0: no bound on that coordinate), Delta_q_prev, has_configuration_limit -- or NULL:
+//   dq <= min(a dt^2 + dq_prev, dt sqrt(2 a (q_max - q))),  -dq <= min(a dt^2 - dq_prev, dt sqrt(2 a (q - q_min)))
+// (the braking-distance term only where the joint has a configuration limit).
 __device__ inline void coordinate_box(const ModelDev &m, int j, int jt, double qi, double dt, double gain, double &lo, double &hi,
-                                      const double *root_box = nullptr) {
+                                      const double *root_box = nullptr, const double *acc = nullptr) {
   lo = -INFINITY;
   hi = INFINITY;
   if (m.jtype[jt] == JOINT_FREE_FLYER) {
@@ -195,6 +199,20 @@ __device__ inline void coordinate_box(const ModelDev &m, int j, int jt, double q
   if (vmax < 1e20 && vmax > 1e-10) {
     lo = fmax(lo, -dt * vmax);
     hi = fmin(hi, dt * vmax);
+  }
+  if (acc) {
+    const double am = acc[j];
+    if (am > 0.0) {
+      const double dqp = acc[m.nv + j];
+      const bool cfg = acc[2 * m.nv + j] != 0.0;
+      double up = am * dt * dt + dqp, lw = am * dt * dt - dqp;
+      if (cfg) {
+        up = fmin(up, dt * sqrt(2.0 * am * (qmax - qi)));
+        lw = fmin(lw, dt * sqrt(2.0 * am * (qi - qmin)));
+      }
+      lo = fmax(lo, -lw);
+      hi = fmin(hi, up);
+    }
   }
 }
 
@@ -222,6 +240,7 @@ struct FkArgs {
   int step = 0;
   double dt = 0.0, config_limit_gain = 0.5;
   const double *root_box = nullptr;  // [12] box of the free-flyer's tangent coordinates (coordinate_box), or NULL
+  const double *acc_limit = nullptr;  // [3, nv] tables of an AccelerationLimit (coordinate_box), or NULL
   const double *q_target = nullptr;  // [B, nq] / [nq] posture target, NULL: no posture rows
   int target_batched = 0;
   double *lb = nullptr, *ub = nullptr;  // [B, nv]
@@ -503,7 +522,7 @@ __device__ __forceinline__ void ik_fk_instance(const FkArgs &a, long long block,
       // 5. merged box limits and the posture error of tangent coordinate j (qs was published before step 2's barriers)
       const double qi = qs[jt];
       double lo, hi;
-      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi, a.root_box);
+      coordinate_box(m, j, jt, qi, a.dt, a.config_limit_gain, lo, hi, a.root_box, a.acc_limit);
       if constexpr (Sink::kKeep) {
         sink->lb = lo;
         sink->ub = hi;

@@ -18,6 +18,7 @@ struct ModelImage {
       off_frame_placement, off_dof_joint, off_dof_sub, off_anc, off_q_min, off_q_max, off_v_max, off_root_joint,
       off_root_placement, off_ancr;
   int nj, nq, nv, nf, root_nv;
+  bool has_relative = false;  // some frame slot is relative (frame_root_joint != -2)
 };
 
 inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im) {
@@ -55,6 +56,7 @@ inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im
     }
   }
   // relative frame slots: the ancestors of the root frame's joint; an ordinary slot has none
+  im.has_relative = false;
   std::vector<unsigned char> ancr((size_t)d.nf * d.nj, 0);
   std::vector<int32_t> root_joint(d.nf, -2);
   std::vector<double> root_placement((size_t)12 * d.nf, 0.0);
@@ -65,6 +67,7 @@ inline std::string build_model_image(const pinkhip_model_desc &d, ModelImage &im
       if (j < -2 || j >= d.nj) return "frame_root_joint out of range";
       root_joint[f] = j;
       if (j == -2) continue;
+      im.has_relative = true;
       if (f >= 16) return "relative frame slots must be among the first 16 frames";  // (one lane per such slot in every kernel)
       std::memcpy(root_placement.data() + 12 * f, d.frame_root_placement + 12 * f, 12 * sizeof(double));
       while (j >= 0) {

@@ -844,7 +844,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     ra.lim_rows = st->limit_rows;
     ra.lim_h = st->limit_h;
   } else {
-    pc = pinkhip::select_rollout(md.nv, md.nj, fkd);
+    pc = pinkhip::select_rollout(md.nv, md.nj, fkd, st->n_const_rows > 0 || st->diag_error != nullptr || st->acc_limit != nullptr || m->image.has_relative);
     if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");
     ra.k.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, fkd);
   }
@@ -867,6 +867,7 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   f.dt = desc->dt;
   f.config_limit_gain = st->config_limit_gain;
   f.root_box = st->root_box;
+  f.acc_limit = st->acc_limit;
   f.q_target = n_post ? st->q_target : nullptr;
   f.target_batched = st->target_batched;
   ra.integrate = st->integrate;

@@ -156,11 +156,14 @@ class DeviceRollout:
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
                  position_barriers: Sequence = (), floating_base_limit=None, const_tasks: Sequence = (),
-                 diag_tasks: Sequence = ()):
+                 diag_tasks: Sequence = (), acceleration_limit: Optional[np.ndarray] = None):
         """``const_tasks``: dense tasks with a constant Jacobian, ``(A [k, nv], b [k], q_0 [nq], cost, gain, lm_damping)``
         each (LinearHolonomicTask / JointCouplingTask on vector-space joints); ``diag_tasks``: identity-Jacobian tasks
         with batch-constant errors, ``(col0, e [k], cost, gain, lm_damping)`` each (DampingTask, LowAccelerationTask,
-        JointVelocityTask).  Both need the whole-step kernel (``fused="kernel"``)."""
+        JointVelocityTask).  ``acceleration_limit``: ``[3, nv]`` -- ``a_max`` (0: no bound on that coordinate),
+        ``Delta_q_prev``, ``has_configuration_limit`` per tangent coordinate of an AccelerationLimit on the joints behind
+        the root (``pink/limits/acceleration_limit.py:158-199``), folded into the box on chip.  All three need the
+        whole-step kernel (``fused="kernel"``)."""
         self.api, self.model, self.dt = api, model, float(dt)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
@@ -175,8 +178,15 @@ class DeviceRollout:
         self.dmodel = api.model_create(self.arrays.desc)
         nf, nv, nq = len(self.frames), self.nv, self.nq
         root_nv = get_root_joint_dim(model)[1]
-        if (const_tasks or diag_tasks) and self.fused != "kernel":
-            raise ValueError('constant-row and extra diagonal tasks need the whole-step kernel: fused="kernel"')
+        if (const_tasks or diag_tasks or acceleration_limit is not None) and self.fused != "kernel":
+            raise ValueError('constant-row tasks, extra diagonal tasks and an acceleration limit need the whole-step kernel: fused="kernel"')
+        self.d_acc = None
+        if acceleration_limit is not None:
+            self._acc = np.ascontiguousarray(acceleration_limit, dtype=np.float64)
+            if self._acc.shape != (3, nv):
+                raise ValueError(f"acceleration_limit must be [3, {nv}]")
+            self.d_acc = api.alloc(self._acc.nbytes)
+            api.put(self.d_acc, self._acc)
         const_tasks = [(np.atleast_2d(np.asarray(A, dtype=np.float64)), np.atleast_1d(np.asarray(b, dtype=np.float64)),
                         np.asarray(q_0, dtype=np.float64), c, g, l) for A, b, q_0, c, g, l in const_tasks]
         diag_tasks = [(int(c0), np.atleast_1d(np.asarray(e, dtype=np.float64)), c, g, l) for c0, e, c, g, l in diag_tasks]
@@ -407,8 +417,8 @@ class DeviceRollout:
             self._fail_dirty = True
         if self.fused == "kernel" and not self._one_kernel_step(integrate):
             self.scaled = False  # (no whole-step kernel for this model: the launches below write dq unscaled)
-            if self._extra_tasks:
-                raise NoWholeStepKernel("no whole-step kernel instantiation fits this model: constant-row / extra diagonal tasks need it")
+            if self._extra_tasks or self.d_acc is not None:
+                raise NoWholeStepKernel("no whole-step kernel instantiation fits this model: constant-row / extra diagonal tasks / the acceleration limit need it")
             if self.md:
                 raise NoWholeStepKernel("no whole-step kernel instantiation with barrier rows fits this model (nv, rows, joints)")
             self.fused = True  # no instantiation for this model: two launches from now on
@@ -547,9 +557,19 @@ class DeviceRollout:
         if self.d_extra:
             self.api.put(self.d_extra[0], self._diag_e)
 
+    def set_acceleration_limit(self, tables: np.ndarray) -> None:
+        """New ``[3, nv]`` tables of the acceleration limit (``Delta_q_prev`` moves with every control step:
+        ``AccelerationLimit.set_last_integration``)."""
+        if self.d_acc is None:
+            raise ValueError("this rollout was built without an acceleration limit")
+        self._acc[...] = tables
+        self.api.put(self.d_acc, self._acc)
+
     def _extra(self, st) -> None:
         """The fields of ``pinkhip_rollout_step`` that describe tasks beyond frames + posture."""
         st.posture_task = self.posture_task
+        if self.d_acc is not None:
+            st.acc_limit = self.d_acc
         if self._extra_tasks:
             st.diag_error = self.d_extra[0]
             if self._const:
@@ -672,4 +692,7 @@ class DeviceRollout:
         for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []) + getattr(self, "d_extra", []):
             self.api.release(ptr)
         self.d_bar, self.d_lim, self.d_extra = [], [], []
+        if getattr(self, "d_acc", None) is not None:
+            self.api.release(self.d_acc)
+            self.d_acc = None
         self.api.model_destroy(self.dmodel)

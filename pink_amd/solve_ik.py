@@ -385,9 +385,10 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     if B == 0 or constraints:
         return None
     model = configurations.model if hasattr(configurations, "model") else configurations[0].model
-    gain = _default_limits_gain(model, limits)
-    if gain is None:
+    lim = _default_limits_gain(model, limits)
+    if lim is None:
         return None
+    gain, acc = lim
     for bar in barriers or ():
         # position barriers with the default class-K function and no safe displacement of their own are formed on chip
         if (type(bar) is not PositionBarrier or not bar.identity_gain_function
@@ -398,35 +399,46 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         frames = [sp[0] for sp in plan[2] if not isinstance(sp[0], tuple)]  # (ordinary slots: a barrier needs the world pose)
         if any(bar.frame not in frames for bar in barriers):
             return None
-        plan = plan + (tuple(barriers), gain)
+        plan = plan + (tuple(barriers), gain, acc)
     elif plan is not None:
-        plan = plan + ((), gain)
+        plan = plan + ((), gain, acc)
     return plan
 
 
-def _default_limits_gain(model, limits) -> Optional[float]:
-    """``config_limit_gain`` when ``limits`` amounts to the model's default limits (``pink/solve_ik.py:94-105``) --
-    ``None`` itself, or an explicit list holding exactly one ConfigurationLimit and one VelocityLimit of this model
-    with the model's velocity vector (plus the model's floating-base limit if it has one): what the device kernels
-    form from the model tables -- else ``None``."""
-    from .limits import ConfigurationLimit, VelocityLimit
+def _default_limits_gain(model, limits):
+    """``(config_limit_gain, acceleration tables or None)`` when ``limits`` amounts to what the device kernels form from
+    tables: the model's default limits (``pink/solve_ik.py:94-105``) -- ``None`` itself, or an explicit list holding
+    exactly one ConfigurationLimit and one VelocityLimit of this model with the model's velocity vector (plus the
+    model's floating-base limit if it has one) -- optionally with ONE AccelerationLimit of this model on joints behind
+    the root (``pink/limits/acceleration_limit.py:158-199``: a box from ``q``, the previous displacement and three
+    per-coordinate tables ``a_max / Delta_q_prev / has_configuration_limit``) -- else ``None``."""
+    from .limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
 
     if not hasattr(model, "ensure_limits"):
         return None
     model.ensure_limits()
     if limits is None:
-        return float(model.configuration_limit.config_limit_gain)
+        return float(model.configuration_limit.config_limit_gain), None
     fb = getattr(model, "floating_base_velocity_limit", None)
     cl = [l for l in limits if type(l) is ConfigurationLimit]
     vl = [l for l in limits if type(l) is VelocityLimit]
-    rest = [l for l in limits if type(l) not in (ConfigurationLimit, VelocityLimit)]
-    if len(cl) != 1 or len(vl) != 1 or cl[0].model is not model or vl[0].model is not model:
+    al = [l for l in limits if type(l) is AccelerationLimit]
+    rest = [l for l in limits if type(l) not in (ConfigurationLimit, VelocityLimit, AccelerationLimit)]
+    if len(cl) != 1 or len(vl) != 1 or cl[0].model is not model or vl[0].model is not model or len(al) > 1:
         return None
     if rest != ([] if fb is None else [fb]):
         return None
     if not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
         return None
-    return float(cl[0].config_limit_gain)
+    acc = None
+    if al:
+        a = al[0]
+        if a.model is not model or any(j.kind == "free_flyer" and j.idx_v in a.indices for j in model.joints):
+            return None
+        if a.projection_matrix is not None:
+            acc = np.zeros((3, model.nv))  # rows: a_max (0 = no bound on the coordinate), Delta_q_prev, has_configuration_limit
+            acc[0, a.indices], acc[1, a.indices], acc[2, a.indices] = a.a_max, a.Delta_q_prev, a.has_configuration_limit
+    return float(cl[0].config_limit_gain), acc
 
 
 def _barrier_key(bar):
@@ -640,13 +652,14 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, extras, bars, limit_gain = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
     fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
     fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
     key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
-           int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras))
+           int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras),
+           None if acc is None else (acc[0].tobytes(), acc[2].tobytes()))  # (the previous displacement moves per call)
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     fresh = False
@@ -656,13 +669,16 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb,
-                           const_tasks=[x[1:] for x in extras if x[0] == "const"], diag_tasks=[x[1:] for x in extras if x[0] == "diag"], **kw)
+                           const_tasks=[x[1:] for x in extras if x[0] == "const"], diag_tasks=[x[1:] for x in extras if x[0] == "diag"],
+                           acceleration_limit=acc, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
         ro.velocity_out = True  # (the whole-step kernel hands out dq / dt: no division over the array afterwards)
         fresh = True
     try:
         if not fresh and any(x[0] == "diag" for x in extras):  # (a LowAccelerationTask / JointVelocityTask moves on every step)
             ro.set_diag_errors([x[2] for x in extras if x[0] == "diag"])
+        if not fresh and acc is not None:  # (AccelerationLimit.set_last_integration between two control steps)
+            ro.set_acceleration_limit(acc)
         # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
         qp = None if posture is None else posture[3]
         if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and not bars and ro.md == 0
@@ -683,11 +699,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, extras, bars, limit_gain = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain
+    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """One-off fuzz of the device-resident path on the GPU box: random kinematic chains (fixed and floating base), random
-configurations and FrameTask targets, optionally a PositionBarrier and a FloatingBaseVelocityLimit -- the whole-step kernel
+configurations and FrameTask targets, optionally a PositionBarrier and a FloatingBaseVelocityLimit, and (FUZZ_EXTRAS=1)
+the tasks the kernel forms from tables since round 4: RelativeFrameTasks, JointCouplingTasks, DampingTask,
+LowAccelerationTask, JointVelocityTask -- the whole-step kernel
 (solve_ik_batch(device_kinematics=True): kinematics, rows, limits, QP on chip) against the host-evaluated path (tasks,
 limits and barriers evaluated per configuration in NumPy as Pink does, only the QP on the device).
-   python scripts/gpu_fuzz_rollout.py [first] [count]"""
+   python scripts/gpu_fuzz_rollout.py [first] [count]        (FUZZ_EMU=1: on the CPU wave emulator of tests/emu)"""
 import os
 import sys
 import time
@@ -59,6 +61,40 @@ def one(sd):
             p = PostureTask(cost=cost)
             p.set_target(q[b] if rng.random() < 0.5 else m.neutral())
             tasks[b].append(p)
+    if os.environ.get("FUZZ_EXTRAS"):  # (a second stream: the draws above are those of the earlier runs)
+        from pink_amd import DampingTask
+        from pink_amd.tasks import JointCouplingTask, JointVelocityTask, LowAccelerationTask, RelativeFrameTask
+
+        r2 = np.random.default_rng(sd + 10 ** 9)
+        names = [f"joint_{k}" for k in range(1, n + 1)] + ["tool0"]
+        for _ in range(int(r2.integers(0, 3))):  # relative frame tasks: per-instance objects, own targets
+            f, r = (str(v) for v in r2.choice(names, size=2, replace=False))
+            pc, oc = float(r2.uniform(0.3, 2.0)), float(r2.choice([0.0, 0.5, 1.0]))
+            lm, gain = float(r2.choice([0.0, 1e-3])), float(r2.uniform(0.3, 1.0))
+            at = int(r2.integers(0, len(tasks[0]) + 1))
+            for b, cfg in enumerate(cfgs):
+                t = RelativeFrameTask(f, r, pc, oc, lm_damping=lm, gain=gain)
+                t.set_target(cfg.get_transform(f, r) * exp6(scale * r2.normal(size=6)))
+                tasks[b].insert(at, t)
+        shared = []
+        if n >= 3 and r2.random() < 0.5:
+            js = [f"joint_{int(k)}" for k in r2.choice(np.arange(1, n + 1), size=int(r2.integers(2, 4)), replace=False)]
+            shared.append(JointCouplingTask(js, [float(v) for v in r2.uniform(-2.0, 2.0, size=len(js))], float(10 ** r2.uniform(-1, 2)), cfgs[0],
+                                            lm_damping=float(r2.choice([0.0, 5e-7])), gain=float(r2.uniform(0.3, 1.0))))
+        if r2.random() < 0.4:
+            shared.append(DampingTask(cost=float(10 ** r2.uniform(-3, -1))))
+        if r2.random() < 0.3:
+            la = LowAccelerationTask(cost=float(10 ** r2.uniform(-3, -1)))
+            la.set_last_integration(r2.normal(size=m.nv) * 0.3, dt)
+            shared.append(la)
+        if r2.random() < 0.3:
+            jv = JointVelocityTask(cost=float(10 ** r2.uniform(-3, -1)))
+            jv.set_target(r2.normal(size=m.nv - (6 if ff else 0)) * 0.3, dt)
+            shared.append(jv)
+        for t in shared:
+            at = int(r2.integers(0, len(tasks[0]) + 1))
+            for b in range(B):
+                tasks[b].insert(at, t)
     bars = []
     if rng.random() < 0.4:
         p0 = np.array([c.get_transform_frame_to_world(frames[0]).translation for c in cfgs])
@@ -66,6 +102,15 @@ def one(sd):
                                     gain=np.array([float(rng.uniform(5.0, 100.0))]),
                                     safe_displacement_gain=float(rng.choice([0.0, 1.0]))))
     kw = dict(barriers=bars or None)
+    if os.environ.get("FUZZ_EXTRAS") and m.floating_base_velocity_limit is None:
+        r3 = np.random.default_rng(sd + 2 * 10 ** 9)
+        if r3.random() < 0.3:  # an explicit limit list with an AccelerationLimit on the joints behind the root
+            from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+
+            a_max = np.r_[np.full(6 if ff else 0, np.inf), 10 ** r3.uniform(1.0, 3.0, size=n)]
+            acc = AccelerationLimit(m, a_max)
+            acc.set_last_integration(np.r_[np.zeros(6 if ff else 0), r3.normal(size=n)] * 0.3, dt)
+            kw["limits"] = [ConfigurationLimit(m, float(r3.uniform(0.3, 1.0))), VelocityLimit(m), acc]
     try:
         V_host = solve_ik_batch(cfgs, tasks, dt, device_kinematics=False, gpu_frame_tasks=False, **kw)
         host_err = None
@@ -79,7 +124,7 @@ def one(sd):
     if host_err or dev_err:
         return ("same failure" if host_err == dev_err else f"host {host_err} / device {dev_err}"), 0.0
     # two evaluations of the same QP agree to cond(H) eps: the tolerance follows the conditioning of each instance
-    cond = np.array([np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, barriers=bars or None).P) for b in range(B)])
+    cond = np.array([np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **kw).P) for b in range(B)])
     rel = np.abs(V_dev - V_host).max(axis=1) / np.maximum(1.0, np.abs(V_host).max(axis=1))
     err = float((rel / np.maximum(1.0, 1e4 * cond * np.finfo(float).eps / 1e-8)).max())  # (compared with 1e-8)
     if os.environ.get("FUZZ_VERBOSE"):
@@ -89,6 +134,20 @@ def one(sd):
 
 
 def main():
+    if os.environ.get("FUZZ_EMU"):
+        import ctypes
+
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import EmuSolver  # noqa: E402
+        from pink_amd._lib import Desc, Problem, Result
+        from pink_amd.runtime import set_default_solver
+
+        lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libpinkemu.so"))
+        lib.pinkhip_emu_solve_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.POINTER(Result)]
+        lib.pinkhip_emu_stack_host.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Problem), ctypes.c_void_p, ctypes.c_void_p]
+        lib.pinkhip_emu_last_error.restype = ctypes.c_char_p
+        lib.pinkhip_emu_frame_task_host.argtypes = [ctypes.c_longlong, ctypes.c_int] + [ctypes.c_void_p] * 5
+        set_default_solver(EmuSolver(lib))
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     t0, worst, bad, failures = time.time(), 0.0, [], 0

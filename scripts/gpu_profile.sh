@@ -29,5 +29,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rollout 
 bash scripts/ab_solvers.sh > gpurun_out/ab_solvers.txt 2>&1
 python scripts/prof_pipeline.py > gpurun_out/prof_pipeline.txt 2>&1
 (python scripts/gpu_fuzz.py 300000 12000) > gpurun_out/fuzz.txt 2>&1
-(python scripts/gpu_fuzz_rollout.py 14000 1500; python scripts/gpu_fuzz_rollout.py 24000 1500; python scripts/gpu_fuzz_rollout.py 40000 3000) > gpurun_out/fuzz_rollout.txt 2>&1
+(python scripts/gpu_fuzz_rollout.py 14000 1500; python scripts/gpu_fuzz_rollout.py 24000 1500; python scripts/gpu_fuzz_rollout.py 40000 3000; FUZZ_EXTRAS=1 python scripts/gpu_fuzz_rollout.py 50000 6000) > gpurun_out/fuzz_rollout.txt 2>&1
 ls gpurun_out/prof gpurun_out/pmc_FETCH_SIZE | head

@@ -326,6 +326,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   f.dt = d->dt;
   f.config_limit_gain = st->config_limit_gain;
   f.root_box = st->root_box;
+  f.acc_limit = st->acc_limit;
   int post_row0 = 0, post_k = 0;
   g_err = pinkhip::rollout_task_layout(*d, m->dev.nf, m->dev.nv, m->dev.root_nv, st->n_const_rows, st->posture_task, st->diag_error != nullptr,
                                        post_row0, post_k);
@@ -367,7 +368,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
 #undef PINKHIP_CASE
     }
   } else {
-    pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, fkd);
+    pc = pinkhip::select_rollout(m->dev.nv, m->dev.nj, fkd, st->n_const_rows > 0 || st->diag_error != nullptr || st->acc_limit != nullptr || m->image.has_relative);
     a.lds_pitch = pinkhip::rollout_lds_doubles(pc.NV, pc.W, fkd);
   }
   if (d->md == 0) switch (pc.NV) {

@@ -279,7 +279,8 @@ def test_hybrid_route_forms_frame_task_rows_on_the_device(backend, free_flyer):
     for b in range(B):
         per_instance[b] += rest
     acc = AccelerationLimit(m, np.r_[np.full(6 if free_flyer else 0, np.inf), np.full(9, 500.0)])
-    limits = [ConfigurationLimit(m, 0.7), VelocityLimit(m), acc]
+    # (one AccelerationLimit next to the defaults is folded into the box by the whole-step kernel; two are not)
+    limits = [ConfigurationLimit(m, 0.7), VelocityLimit(m), acc, AccelerationLimit(m, np.r_[np.full(6 if free_flyer else 0, np.inf), np.full(9, 800.0)])]
     p_tool = np.array([c.get_transform_frame_to_world("tool0").translation for c in cfgs])
     bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[:, 2].max() + 0.02]), gain=np.array([50.0]), safe_displacement_gain=1.0)]
     kw = dict(limits=limits, barriers=bars)
@@ -456,3 +457,52 @@ def test_relative_frame_tasks_are_formed_on_the_device(backend, free_flyer):
     bar = PositionBarrier("joint_8", indices=[2], p_max=np.array([10.0]), gain=np.array([50.0]), safe_displacement_gain=1.0)
     with pytest.raises(pink_amd.PinkError):
         solve_ik_batch(cb, [ft, r1, po], dt, barriers=[bar], device_kinematics=True)
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_acceleration_limit_is_folded_into_the_box_on_chip(backend, free_flyer):
+    """An explicit limit list with an AccelerationLimit on the joints behind the root
+    (pink/limits/acceleration_limit.py:158-199) stays on the whole-step kernel: the box of a coordinate is formed from q,
+    the previous displacement and three per-coordinate tables.  Same velocities as the all-host evaluation and as one
+    solve_ik per configuration; the limit binds (the velocities differ from those without it); a new
+    set_last_integration between two calls is served by the cached device state; small robots too (the kernel is then
+    needed, whatever their size)."""
+    for n in (9, 5):
+        m = build_chain(n, free_flyer=free_flyer, seed=5, limit=2.8, velocity=60.0)
+        rng = np.random.default_rng(70 + n)
+        B, dt = 8, 5e-3
+        q = _draw_q(m, B, rng, spread=2.5)  # (some joints close to their limits: the braking-distance term binds)
+        cfgs = [Configuration(m, q[b]) for b in range(B)]
+        ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+        R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+        for b, c in enumerate(cfgs):
+            T = c.get_transform_frame_to_world("tool0") * exp6(0.3 * rng.normal(size=6))
+            R[b], t[b] = T.rotation, T.translation
+        ft.set_target_poses(R, t)
+        po = PostureTask(cost=5e-2)
+        po.set_target(m.neutral())
+        a_max = np.r_[np.full(6 if free_flyer else 0, np.inf), rng.uniform(20.0, 400.0, size=n)]
+        a_max[-2] = np.inf  # (one joint without an acceleration bound)
+        acc = AccelerationLimit(m, a_max)
+        acc.set_last_integration(np.r_[np.zeros(6 if free_flyer else 0), rng.normal(size=n)] * 0.5, dt)
+        limits = [ConfigurationLimit(m, 0.7), VelocityLimit(m), acc]
+        cb = ConfigurationBatch(m, q)
+        V_free = solve_ik_batch(cb, [ft, po], dt, device_kinematics=True, limits=limits[:2])
+        for _ in range(2):
+            V = solve_ik_batch(cb, [ft, po], dt, device_kinematics=True, limits=limits)
+            assert pink_amd.last_solve_stats()["route"] == "device"
+            V_host = solve_ik_batch(cb, [ft, po], dt, device_kinematics=False, gpu_frame_tasks=False, limits=limits)
+            scale = max(1.0, np.abs(V_host).max())
+            assert np.abs(V - V_host).max() < 1e-8 * scale
+            assert np.abs(V - V_free).max() > 1e-3 * scale
+            for b in range(3):
+                own = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+                own.set_target(SE3(R[b], t[b]))
+                v = solve_ik(cfgs[b], [own, po], dt, limits=limits)
+                assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
+            acc.set_last_integration(V[0], dt)  # (the next control step: another previous displacement)
+    # a bound on a floating-base coordinate is not a table entry: another route
+    if free_flyer:
+        acc6 = AccelerationLimit(m, np.full(m.nv, 50.0))
+        solve_ik_batch(cb, [ft, po], dt, limits=[ConfigurationLimit(m, 0.7), VelocityLimit(m), acc6])
+        assert pink_amd.last_solve_stats()["route"] != "device"
