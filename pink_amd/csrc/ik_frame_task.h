@@ -81,10 +81,26 @@ __device__ inline void log3(const double *R, double *w, double &theta) {
   }
 }
 
+// beta(th) = 1 / th^2 - sin th / (2 th (1 - cos th)) = (1 - (th / 2) cot(th / 2)) / th^2 and beta_dot = beta'(th) / th as power
+// series in th^2 (|B_2n| / (2n)! and 2 k times them) below kSeriesTh: the closed forms subtract numbers of order 1 / th^2
+// and 1 / th^4 -- at th = 1e-3 they are wrong by 2e-4 and 1e4 relative, and one ulp of difference in sin / cos between
+// two implementations of the same formula became 1e-8 relative on dq (scripts/gpu_fuzz_rollout.py, round 4: a tracking
+// controller's orientation errors ARE that small).  Eight terms hold 1e-16 up to th = 0.6 (checked against 60 digits);
+// same constants as pink_amd/lie.py.
+constexpr double kSeriesTh = 0.5;
+__device__ inline double beta_series(double t2) {
+  return 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 * (1.0 / 1209600.0 + t2 * (1.0 / 47900160.0 +
+         t2 * (691.0 / 1307674368000.0 + t2 * (1.0 / 74724249600.0 + t2 * (3617.0 / 10670622842880000.0)))))));
+}
+__device__ inline double beta_dot_series(double t2) {
+  return 2.0 / 720.0 + t2 * (4.0 / 30240.0 + t2 * (6.0 / 1209600.0 + t2 * (8.0 / 47900160.0 +
+         t2 * (10.0 * 691.0 / 1307674368000.0 + t2 * (12.0 / 74724249600.0 + t2 * (14.0 * 3617.0 / 10670622842880000.0 +
+         t2 * 1.3737699290044551303e-13))))));
+}
 __device__ inline void alpha_beta(double th, double &alpha, double &beta) {
-  if (th < 1e-4) {
-    alpha = 1.0 - th * th / 12.0;
-    beta = 1.0 / 12.0 + th * th / 720.0;
+  if (th < kSeriesTh) {
+    beta = beta_series(th * th);
+    alpha = 1.0 - th * th * beta;
   } else {
     double s, c;
     fast_sincos(th, s, c);
@@ -114,11 +130,11 @@ __device__ inline void log6(const double *R, const double *p, double *xi) {
 // right Jacobian of log6 at (R, p), row-major 6 x 6: [[A, C A], [0, A]], given w = log3(R) and its norm
 __device__ inline void jlog6_from_log3(const double *w, double th, const double *p, double *Jl) {
   double a, d, beta, beta_dot;
-  if (th < 1e-4) {
-    a = 1.0 / 12.0 + th * th / 720.0;
-    d = 1.0 - th * th / 12.0;
+  if (th < kSeriesTh) {
+    a = beta_series(th * th);
+    d = 1.0 - th * th * a;
     beta = a;
-    beta_dot = 1.0 / 360.0;
+    beta_dot = beta_dot_series(th * th);
   } else {
     double s, c;
     fast_sincos(th, s, c);

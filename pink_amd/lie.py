@@ -20,6 +20,9 @@ def exp3(w: np.ndarray) -> np.ndarray:
     K = hat(w)
     if th < 1e-8:
         return np.eye(3) + K + 0.5 * K @ K
+    if th < 0.1:  # ((1 - cos th) / th^2 as a series: the closed form is good to 2e-10 only at th = 1e-3)
+        t2 = th * th
+        return np.eye(3) + (np.sin(th) / th) * K + (0.5 + t2 * (-1.0 / 24.0 + t2 * (1.0 / 720.0 + t2 * (-1.0 / 40320.0 + t2 * (1.0 / 3628800.0))))) * K @ K
     return np.eye(3) + (np.sin(th) / th) * K + ((1.0 - np.cos(th)) / th**2) * K @ K
 
 
@@ -102,11 +105,39 @@ class SE3:
         return f"SE3(R={self.rotation.tolist()}, p={self.translation.tolist()})"
 
 
+# beta(th) = 1 / th^2 - sin th / (2 th (1 - cos th)) = (1 - (th / 2) cot(th / 2)) / th^2 and beta_dot = beta'(th) / th as
+# power series in th^2 (|B_2n| / (2n)! and 2 k times them): the closed forms subtract numbers of order 1 / th^2 and
+# 1 / th^4 -- at th = 1e-3 they are wrong by 2e-4 and 1e4 relative (double precision against 60 digits), which a
+# tracking controller's small orientation errors turned into 1e-8 relative on dq between two implementations of the same
+# formula (scripts/gpu_fuzz_rollout.py, round 4).  Eight terms hold 1e-16 up to th = 0.6; the closed forms take over at
+# 0.5 (beta 2e-14, beta_dot 4e-12 there, improving with th).  Same constants in pink_amd/lie_batch.py and
+# pink_amd/csrc/ik_frame_task.h.
+SERIES_TH = 0.5
+BETA_SERIES = (1.0 / 12.0, 1.0 / 720.0, 1.0 / 30240.0, 1.0 / 1209600.0, 1.0 / 47900160.0, 691.0 / 1307674368000.0,
+               1.0 / 74724249600.0, 3617.0 / 10670622842880000.0)
+BETA_DOT_SERIES = tuple(2.0 * k * c for k, c in enumerate(BETA_SERIES))[1:] + (1.3737699290044551303e-13,)  # (the last: 16 |B_18| / 18!)
+
+
+def _horner(coeffs, t2):
+    acc = 0.0
+    for c in reversed(coeffs):
+        acc = acc * t2 + c
+    return acc
+
+
 def _alpha_beta(th: float):
-    if th < 1e-4:
-        return 1.0 - th**2 / 12.0, 1.0 / 12.0 + th**2 / 720.0
+    if th < SERIES_TH:
+        beta = _horner(BETA_SERIES, th * th)
+        return 1.0 - th * th * beta, beta
     s, c = np.sin(th), np.cos(th)
     return th * s / (2.0 * (1.0 - c)), 1.0 / th**2 - s / (2.0 * th * (1.0 - c))
+
+
+def _beta_dot(th: float) -> float:
+    if th < SERIES_TH:
+        return _horner(BETA_DOT_SERIES, th * th)
+    s, c = np.sin(th), np.cos(th)
+    return -2.0 / th**4 + (1.0 + s / th) / (2.0 * th**2 * (1.0 - c))
 
 
 def log6(M: SE3) -> np.ndarray:
@@ -124,8 +155,11 @@ def exp6(xi: np.ndarray) -> SE3:
     th = float(np.linalg.norm(w))
     R = exp3(w)
     K = hat(w)
-    if th < 1e-8:
-        V = np.eye(3) + 0.5 * K
+    if th < 0.1:  # (series: the closed forms cancel -- 2e-10 / 1e-9 relative at th = 1e-3; same as ik_kinematics.h)
+        t2 = th * th
+        A = 0.5 + t2 * (-1.0 / 24.0 + t2 * (1.0 / 720.0 + t2 * (-1.0 / 40320.0 + t2 * (1.0 / 3628800.0))))
+        Bc = 1.0 / 6.0 + t2 * (-1.0 / 120.0 + t2 * (1.0 / 5040.0 + t2 * (-1.0 / 362880.0 + t2 * (1.0 / 39916800.0))))
+        V = np.eye(3) + A * K + Bc * K @ K
     else:
         V = np.eye(3) + ((1 - np.cos(th)) / th**2) * K + ((th - np.sin(th)) / th**3) * K @ K
     return SE3(R, V @ v)
@@ -133,12 +167,7 @@ def exp6(xi: np.ndarray) -> SE3:
 
 def Jlog3(w: np.ndarray) -> np.ndarray:
     th = float(np.linalg.norm(w))
-    if th < 1e-4:
-        a, d = 1.0 / 12.0 + th**2 / 720.0, 1.0 - th**2 / 12.0
-    else:
-        s, c = np.sin(th), np.cos(th)
-        a = 1.0 / th**2 - s / (2.0 * th * (1.0 - c))
-        d = 0.5 * th * s / (1.0 - c)
+    d, a = _alpha_beta(th)
     return a * np.outer(w, w) + d * np.eye(3) + 0.5 * hat(w)
 
 
@@ -149,11 +178,7 @@ def Jlog6(M: SE3) -> np.ndarray:
     p = M.translation
     A = Jlog3(w)
     _, beta = _alpha_beta(th)
-    if th < 1e-4:
-        beta_dot = 1.0 / 360.0
-    else:
-        s, c = np.sin(th), np.cos(th)
-        beta_dot = -2.0 / th**4 + (1.0 + s / th) / (2.0 * th**2 * (1.0 - c))
+    beta_dot = _beta_dot(th)
     wTp = float(w @ p)
     v3 = beta_dot * wTp * w - (th**2 * beta_dot + 2.0 * beta) * p
     C = np.outer(v3, w) + beta * np.outer(w, p) + beta * wTp * np.eye(3) + 0.5 * hat(p)

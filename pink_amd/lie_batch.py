@@ -13,6 +13,8 @@ from typing import Tuple
 
 import numpy as np
 
+from .lie import BETA_DOT_SERIES, BETA_SERIES, SERIES_TH
+
 
 def hat(w: np.ndarray) -> np.ndarray:
     """``[B, 3] -> [B, 3, 3]`` cross-product matrices."""
@@ -42,12 +44,22 @@ def log3(R: np.ndarray) -> np.ndarray:
     return out
 
 
+def _series(coeffs, t2: np.ndarray) -> np.ndarray:
+    acc = np.zeros_like(t2)
+    for c in reversed(coeffs):
+        acc = acc * t2 + c
+    return acc
+
+
 def _alpha_beta(th: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    small = th < 1e-4
+    """``(th / 2) cot(th / 2)`` and ``beta``: power series below ``lie.SERIES_TH`` (the closed forms cancel: ``lie.py``)."""
+    small = th < SERIES_TH
     ths = np.where(small, 1.0, th)
     s, c = np.sin(ths), np.cos(ths)
-    alpha = np.where(small, 1.0 - th**2 / 12.0, ths * s / (2.0 * (1.0 - c)))
-    beta = np.where(small, 1.0 / 12.0 + th**2 / 720.0, 1.0 / ths**2 - s / (2.0 * ths * (1.0 - c)))
+    t2 = np.where(small, th * th, 0.0)
+    bs = _series(BETA_SERIES, t2)
+    alpha = np.where(small, 1.0 - t2 * bs, ths * s / (2.0 * (1.0 - c)))
+    beta = np.where(small, bs, 1.0 / ths**2 - s / (2.0 * ths * (1.0 - c)))
     return alpha, beta
 
 
@@ -65,15 +77,14 @@ def Jlog6(R: np.ndarray, p: np.ndarray) -> np.ndarray:
     """Right Jacobians of ``log6`` at the transforms ``(R, p)``: ``[B, 6, 6]``."""
     w = log3(R)
     th = np.linalg.norm(w, axis=1)
-    small = th < 1e-4
+    small = th < SERIES_TH
     ths = np.where(small, 1.0, th)
     s, c = np.sin(ths), np.cos(ths)
-    a = np.where(small, 1.0 / 12.0 + th**2 / 720.0, 1.0 / ths**2 - s / (2.0 * ths * (1.0 - c)))
-    d = np.where(small, 1.0 - th**2 / 12.0, 0.5 * ths * s / (1.0 - c))
+    d, a = _alpha_beta(th)
     eye = np.eye(3)
     A = a[:, None, None] * (w[:, :, None] * w[:, None, :]) + d[:, None, None] * eye + 0.5 * hat(w)
     beta = a  # (the same expression, SURVEY.md B.3)
-    beta_dot = np.where(small, 1.0 / 360.0, -2.0 / ths**4 + (1.0 + s / ths) / (2.0 * ths**2 * (1.0 - c)))
+    beta_dot = np.where(small, _series(BETA_DOT_SERIES, np.where(small, th * th, 0.0)), -2.0 / ths**4 + (1.0 + s / ths) / (2.0 * ths**2 * (1.0 - c)))
     wp = np.einsum("bi,bi->b", w, p)
     v3 = (beta_dot * wp)[:, None] * w - (th**2 * beta_dot + 2.0 * beta)[:, None] * p
     C = (v3[:, :, None] * w[:, None, :] + beta[:, None, None] * (w[:, :, None] * p[:, None, :])

@@ -130,6 +130,15 @@ def one(sd):
     if os.environ.get("FUZZ_VERBOSE"):
         print(dict(ff=ff, n=n, frames=frames, B=B, dt=dt, scale=scale, bars=len(bars), fb=m.floating_base_velocity_limit is not None,
                    ntasks=len(tasks[0])), "per-instance rel err", rel, "cond", cond, "max |V_host|", np.abs(V_host).max(axis=1), "max |V_dev|", np.abs(V_dev).max(axis=1))
+        w = int(np.argmax(rel))
+        np.set_printoptions(precision=4, linewidth=200)
+        print("worst instance", w, "tasks", [type(t).__name__ for t in tasks[w]], "limits", [type(l).__name__ for l in (kw.get("limits") or [])])
+        print("V_host", V_host[w]); print("V_dev - V_host", V_dev[w] - V_host[w])
+        pr = pink_amd.build_ik(cfgs[w], tasks[w], dt, **kw)
+        for name, V in (("host", V_host[w]), ("dev", V_dev[w])):
+            dq = V * dt
+            print(name, "objective", 0.5 * dq @ pr.P @ dq + pr.q @ dq, "max G dq - h", None if pr.G is None else float((pr.G @ dq - pr.h).max()),
+                  "active rows", None if pr.G is None else np.nonzero(pr.G @ dq - pr.h > -1e-9)[0])
     return None, err
 
 

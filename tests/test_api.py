@@ -280,6 +280,22 @@ def test_frame_task_kernel_matches_host_lie_and_oracle(backend):
         eo, Jo = se3_oracle.frame_task_terms(Tf[2:], Tt[2:], Jb[2:])  # independent: logm + finite differences
         assert np.abs(e[2:] - eo).max() < 1e-12 and np.abs(J[2:] - Jo).max() < 1e-7
         assert np.array_equal(J[0], -Jb[0]) and not e[0].any()  # tests/test_frame_task.py:112-121
+    # small orientation errors, where a tracking controller lives: the coefficient functions of log6 / Jlog6 are power
+    # series there (tests/test_lie_accuracy.py holds the host's to 60-digit arithmetic); their closed forms gave 1e-10
+    # between the GPU's sin / cos and NumPy's at 1e-3 rad, 1e-8 on dq
+    nv = 30
+    ths = np.r_[10.0 ** np.arange(-6, -0.2, 0.5), 0.45, 0.49, 0.51]
+    frames = [exp6(rng.normal(size=6)) for _ in ths]
+    offs = []
+    for th in ths:
+        w = rng.normal(size=3)
+        offs.append(exp6(np.r_[rng.normal(size=3) * 0.05, w * th / np.linalg.norm(w)]))
+    targets = [f * o for f, o in zip(frames, offs)]
+    Jb = rng.normal(size=(len(ths), 6, nv))
+    e, J = default_solver().frame_task_terms(np.array([_pose12(f) for f in frames]), np.array([_pose12(t) for t in targets]), Jb)
+    for b in range(len(ths)):
+        assert np.abs(e[b] - log6(frames[b].actInv(targets[b]))).max() < 1e-14, ths[b]
+        assert np.abs(J[b] + Jlog6(targets[b].actInv(frames[b])) @ Jb[b]).max() < 2e-13, ths[b]
 
 
 def test_batched_frame_tasks_on_gpu_equal_host_evaluation(backend):
