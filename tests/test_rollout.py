@@ -490,3 +490,68 @@ def test_hand_over_with_barrier_rows_reads_the_frame_positions_it_needs(api):
         assert note is None, (sd, note)
         assert err <= 1e-8, (sd, err)
         pink_amd.clear_device_cache()
+
+
+@pytest.mark.parametrize("which", [0, 1, 3])
+def test_closed_loop_with_table_tasks_and_a_relative_slot_matches_host_loop(api, which):
+    """The tasks the whole-step kernel forms from tables since round 4 -- a JointCouplingTask (constant rows, error
+    A (q - q_0) - b from the configuration of THIS step), a DampingTask, a RelativeFrameTask (relative slot: its target
+    rides on the root frame's current pose) -- and an AccelerationLimit table, inside the closed loop: every step's rows
+    come from the configuration the previous step integrated.  Follows the host loop (solve_ik + integrate_inplace per
+    robot) to 1e-8 over the rollout; the 6-dof arm runs the kernel at NV = 12 because the stack needs it."""
+    from pink_amd import DampingTask
+    from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+    from pink_amd.tasks import JointCouplingTask, RelativeFrameTask
+
+    model, frames = _models()[which]
+    rng = np.random.default_rng(90 + which)
+    B, dt, steps = 3, 5e-3, (20 if which != 3 else 10)
+    q0 = _random_q(model, B, rng) * 0.5 + 0.5 * np.tile(model.neutral(), (B, 1))
+    if model.root_joint is not None:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    cfgs = [Configuration(model, q0[b]) for b in range(B)]
+    nj = len(model.joints) - (1 if model.root_joint is not None else 0)
+    rel = ("tool0", f"joint_{max(nj // 2, 1)}")
+    specs = [(frames[0], 1.0, 0.5, 1.0, 1e-3), (rel, 0.8, 0.3, 0.9, 1e-3)]
+    jc = JointCouplingTask(["joint_2", "joint_3"], [1.0, -0.5], 20.0, cfgs[0], lm_damping=5e-7, gain=0.8)
+    damp = DampingTask(cost=3e-2)
+    root_nv = 6 if model.root_joint is not None else 0
+    a_max = np.r_[np.full(root_nv, np.inf), np.full(model.nv - root_nv, 40.0)]
+    acc = AccelerationLimit(model, a_max)  # (Delta_q_prev = 0 throughout: the table is the same for every step)
+    limits = [ConfigurationLimit(model), VelocityLimit(model), acc]
+    targets = np.zeros((B, 2, 12))
+    host_tasks = []
+    for b, cfg in enumerate(cfgs):
+        ft = FrameTask(frames[0], 1.0, 0.5, lm_damping=1e-3, gain=1.0)
+        tgt = cfg.get_transform_frame_to_world(frames[0]) * exp6(0.08 * rng.normal(size=6))
+        ft.set_target(tgt)
+        rt = RelativeFrameTask(rel[0], rel[1], 0.8, 0.3, lm_damping=1e-3, gain=0.9)
+        rtg = cfg.get_transform(rel[0], rel[1]) * exp6(0.05 * rng.normal(size=6))
+        rt.set_target(rtg)
+        targets[b, 0], targets[b, 1] = pose12(tgt), pose12(rtg)
+        p = PostureTask(cost=1e-2)
+        p.set_target(q0[b])
+        host_tasks.append([ft, rt, jc, p, damp])
+    acc_tables = np.zeros((3, model.nv))
+    acc_tables[0, acc.indices], acc_tables[2, acc.indices] = acc.a_max, acc.has_configuration_limit
+    ro = DeviceRollout(api, model, q0, specs, dt, posture_cost=1e-2, fused="kernel",
+                       const_tasks=[(jc.A, jc.b, jc.q_0, jc.cost, jc.gain, jc.lm_damping)],
+                       diag_tasks=[(root_nv, np.zeros(model.nv - root_nv), damp.cost, damp.gain, damp.lm_damping)],
+                       acceleration_limit=acc_tables)
+    ro.set_targets(targets)
+    ro.run(steps)
+    assert ro.fused == "kernel"
+    qd = ro.configurations()
+    _, st, _ = ro.last_step()
+    assert (st == 0).all()
+    moved = 0.0
+    for b, cfg in enumerate(cfgs):
+        for _ in range(steps):
+            cfg.integrate_inplace(solve_ik(cfg, host_tasks[b], dt, limits=limits), dt)
+        cd = Configuration(model, qd[b])
+        for f in (frames[0], rel[0], rel[1]):
+            Ta, Tb = cd.get_transform_frame_to_world(f), cfg.get_transform_frame_to_world(f)
+            assert np.abs(Ta.translation - Tb.translation).max() < 1e-8 and np.abs(Ta.rotation - Tb.rotation).max() < 1e-8
+        moved = max(moved, np.abs(cfg.q - q0[b]).max())
+    assert moved > 1e-3
+    ro.free()
