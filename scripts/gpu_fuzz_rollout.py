@@ -122,7 +122,18 @@ def one(sd):
     except pink_amd.PinkError as exc:
         V_dev, dev_err = None, type(exc).__name__
     if host_err or dev_err:
-        return ("same failure" if host_err == dev_err else f"host {host_err} / device {dev_err}"), 0.0
+        if host_err == dev_err:
+            return "same failure", 0.0
+        # one route reports "not positive definite" where the other solves: legitimate only where H is singular to working
+        # precision (FrameTasks alone on more coordinates than rows, damping 1e-12: the pivot's sign is round-off; quadprog
+        # raises there as well)
+        try:
+            cmax = max(np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **kw).P) for b in range(B))
+        except Exception:  # noqa: BLE001
+            cmax = 0.0
+        if cmax > 1e15:
+            return "same failure", 0.0
+        return f"host {host_err} / device {dev_err} (cond(H) up to {cmax:.1e})", 0.0
     # two evaluations of the same QP agree to cond(H) eps: the tolerance follows the conditioning of each instance
     cond = np.array([np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **kw).P) for b in range(B)])
     rel = np.abs(V_dev - V_host).max(axis=1) / np.maximum(1.0, np.abs(V_host).max(axis=1))
