@@ -570,6 +570,22 @@ def test_solve_ik_batch_on_arrays_equals_the_list_of_configurations(backend):
         assert np.array_equal(V_pool_host, V_host)
         with pytest.raises(pink_amd.PinkError):
             solve_ik_batch(cfgs, per_instance, 5e-3, solver_handle=pool, device_ids=[0])
+        # the tasks the kernel forms from tables, a relative slot and an acceleration limit travel with every shard
+        from pink_amd import DampingTask
+        from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+        from pink_amd.tasks import JointCouplingTask, RelativeFrameTask
+
+        jc = JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 10.0, cfgs[0], lm_damping=5e-7)
+        rel = RelativeFrameTask("joint_8", "joint_4", 1.0, 0.3, lm_damping=1e-3)
+        rel.set_target(cfgs[0].get_transform("joint_8", "joint_4") * SE3(np.eye(3), [0.01, 0.0, 0.02]))
+        acc = AccelerationLimit(m, np.r_[np.full(6, np.inf), np.full(9, 300.0)])
+        acc.set_last_integration(np.r_[np.zeros(6), 0.2 * rng.normal(size=9)], 5e-3)
+        stack, lim = shared + [jc, rel, post, DampingTask(cost=1e-2)], [ConfigurationLimit(m), VelocityLimit(m), acc]
+        V_one = solve_ik_batch(ConfigurationBatch(m, q), stack, 5e-3, device_kinematics=True, limits=lim)
+        V_two = solve_ik_batch(ConfigurationBatch(m, q), stack, 5e-3, device_kinematics=True, limits=lim, solver_handle=pool)
+        assert np.array_equal(V_two, V_one)
+        V_ref = solve_ik_batch(ConfigurationBatch(m, q), stack, 5e-3, device_kinematics=False, gpu_frame_tasks=False, limits=lim)
+        assert np.abs(V_one - V_ref).max() < 1e-8 * max(1.0, np.abs(V_ref).max())
     finally:
         if backend != "emu":
             pool.close()
