@@ -234,11 +234,14 @@ def pack_terms(
         cost = np.concatenate(costs) if costs else np.zeros(0)
     assert J.shape[1] == Kd
 
-    lb = np.full((B, nv), -np.inf)
-    ub = np.full((B, nv), np.inf)
+    lb = ub = None  # (the first box is taken as it is: no pass over [B, nv] to intersect it with +-inf)
     for blo, bhi in boxes:
-        lb = np.maximum(lb, np.broadcast_to(np.asarray(blo, dtype=np.float64), (B, nv)))
-        ub = np.minimum(ub, np.broadcast_to(np.asarray(bhi, dtype=np.float64), (B, nv)))
+        blo = np.broadcast_to(np.asarray(blo, dtype=np.float64), (B, nv))
+        bhi = np.broadcast_to(np.asarray(bhi, dtype=np.float64), (B, nv))
+        lb = blo if lb is None else np.maximum(lb, blo)
+        ub = bhi if ub is None else np.minimum(ub, bhi)
+    if lb is None:
+        lb, ub = np.full((B, nv), -np.inf), np.full((B, nv), np.inf)
 
     G_list = [np.asarray(A, dtype=np.float64) for A, _ in equality_rows]
     h_list = [np.asarray(bb, dtype=np.float64) for _, bb in equality_rows]

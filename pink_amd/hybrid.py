@@ -41,6 +41,8 @@ def plan(kin_model, slots: Sequence, constraints) -> Optional[List[int]]:
     frames = [k for k, col in enumerate(slots) if type(col[0]) in (FrameTask, RelativeFrameTask)]
     for k in frames:  # (one frame -- and root -- per slot: the device model holds them)
         t0 = slots[k][0]
+        if getattr(slots[k], "shared", False):  # (one task object for the whole batch: nothing to compare)
+            continue
         if any(type(t) is not type(t0) or t.frame != t0.frame or getattr(t, "root", None) != getattr(t0, "root", None) for t in slots[k]):
             return None
     if not frames or len(frames) > MAX_FRAME_TASKS:
