@@ -234,12 +234,12 @@ def pack_terms(
         cost = np.concatenate(costs) if costs else np.zeros(0)
     assert J.shape[1] == Kd
 
-    lb = ub = None  # (the first box is taken as it is: no pass over [B, nv] to intersect it with +-inf)
+    lb = ub = None  # (the first box is copied: no passes over [B, nv] to fill with +-inf and intersect)
     for blo, bhi in boxes:
         blo = np.broadcast_to(np.asarray(blo, dtype=np.float64), (B, nv))
         bhi = np.broadcast_to(np.asarray(bhi, dtype=np.float64), (B, nv))
-        lb = blo if lb is None else np.maximum(lb, blo)
-        ub = bhi if ub is None else np.minimum(ub, bhi)
+        lb = np.array(blo) if lb is None else np.maximum(lb, blo)  # (a copy: the batch owns its arrays)
+        ub = np.array(bhi) if ub is None else np.minimum(ub, bhi)
     if lb is None:
         lb, ub = np.full((B, nv), -np.inf), np.full((B, nv), np.inf)
 

@@ -388,7 +388,11 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         const double slack = (hv - kx) * ginv;  // (rows are g x <= h; normalised like the selection's threshold)
         if (arow) {
           r = kx - hv;  // residual of an active row
-          fails = !(fabs(slack) <= -10.0 * thr_d);
+          // ... and its multiplier has the sign of an active inequality: the corrections of the closing trips move it with
+          // x, and a row that is active with a multiplier of zero (a flat direction of a weakly regularised H) can come
+          // out at -1e-8 -- stationary to 1e-13 with it, 0.09 away from the minimiser (scripts/gpu_fuzz.py seed 537045,
+          // cond(H) = 2e8).  In the gradient's units: lambda |g| >= -gtol.
+          fails = !(fabs(slack) <= -10.0 * thr_d) || (dr >= n_eq && !(u >= -gtol * ginv));
         } else if (state == 0 && dr >= n_eq) {
           fails = !(slack >= 10.0 * thr_d);
         }

@@ -403,7 +403,8 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
         const double slack = (hv - gx) * ginv;
         if (arow) {
           rd = gx - hv;  // residual of an active row
-          failsd = !(fabs(slack) <= -10.0 * thr_d);
+          // (and its multiplier has the sign of an active inequality: ik_sweep.h)
+          failsd = !(fabs(slack) <= -10.0 * thr_d) || (li >= n_eq && !(ud >= -gtol * ginv));
         } else if (li >= n_eq) {
           failsd = !(slack >= 10.0 * thr_d);
         }

@@ -15,7 +15,7 @@ from pink_amd.batch_solver import BatchSolver  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 s = BatchSolver(0)
-for solver in ("sweep", "sweepx", "packed"):  # (sweepx: the kernel with virtual dense rows where it is instantiated)
+for solver in os.environ.get("PINKHIP_FUZZ_KERNELS", "sweep,sweepx,packed").split(","):  # (sweepx: the kernel with virtual dense rows where it is instantiated)
     os.environ["PINKHIP_SOLVER"] = solver
     t0 = time.time()
     n, bad = 0, []

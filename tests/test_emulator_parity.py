@@ -96,7 +96,7 @@ def test_fuzz_weakly_regularised(emu):
     """tests/test_gpu_parity.py::test_fuzz_weakly_regularised on the emulator: draws the tableau cannot certify take
     the hand-over to the Goldfarb-Idnani code (80013: coordinates without bounds at 1e2 before; 80291: NaN behind
     status 0 before; 80135, 102469: false "inconsistent")."""
-    assert ps.fuzz(emu, [80011, 80013, 80015, 80037, 80135, 80261, 80291, 80389, 102469], ill=True) > 20
+    assert ps.fuzz(emu, [80011, 80013, 80015, 80037, 80135, 80261, 80291, 80389, 102469, 520171, 537045], ill=True) > 20
 
 
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):

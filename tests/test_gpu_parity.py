@@ -74,10 +74,12 @@ def test_fuzz_weakly_regularised(gpu_solver, kernel, monkeypatch):
     included.  ZERO uncertified draws: statuses equal the oracle's on every draw, and every instance is either within
     100 eps cond(H) max|x| of the oracle's dq or -- flat directions at cond(H) ~ 1e10 -- passes the KKT + objective
     certificate of parity_suite.certify_point (computed here, on the QP as stated); anything else fails the test.
-    The range holds seed 415035 (off by 1.3e-6 on both kernels in round 3's wide fuzz)."""
+    The range holds seed 415035 (off by 1.3e-6 on both kernels in round 3's wide fuzz) and seeds 520171 / 537045 of
+    round 4's (a dense row active with a multiplier of -1e-8 after the closing corrections: stationary with it, 0.09 from
+    the minimiser at cond(H) = 2e8 -- the certificate now holds the multipliers of active rows to their sign)."""
     monkeypatch.setenv("PINKHIP_SOLVER", kernel)
     del ps.CERTIFIED[:]
-    n = ps.fuzz(gpu_solver, list(range(200001, 204001, 2)) + [415035], ill=True)
+    n = ps.fuzz(gpu_solver, list(range(200001, 204001, 2)) + [415035, 520171, 537045], ill=True)
     assert n > 5000
     print(f"{kernel}: {n} feasible instances, {len(ps.CERTIFIED)} accepted on their KKT / objective certificate: {ps.CERTIFIED[:8]}")
 
