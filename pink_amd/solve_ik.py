@@ -845,7 +845,8 @@ def _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constrai
         q = np.stack([np.asarray(c.q, dtype=np.float64) for c in configurations])
         make = lambda: BatchKinematics(model, q)  # noqa: E731
     slots = _task_slots(tasks, B)
-    frame_slots = hybrid.plan(model, slots, constraints)
+    cslots = _task_slots(constraints, B) if constraints else []
+    frame_slots = hybrid.plan(model, slots, cslots)
     if frame_slots is None:
         return None
     if limits is None:  # model defaults, pink/solve_ik.py:94-105
@@ -861,7 +862,7 @@ def _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constrai
         state = hybrid.HybridState(api, model, frames, B)
         state._cache_owner = model
     try:
-        dq, status, iters, path = hybrid.solve(state, q, make, slots, frame_slots, limits, barriers, dt, damping, max_iter)
+        dq, status, iters, path = hybrid.solve(state, q, make, slots, frame_slots, limits, barriers, dt, damping, max_iter, cslots)
     except BaseException:
         state.free()
         raise

@@ -506,3 +506,57 @@ def test_acceleration_limit_is_folded_into_the_box_on_chip(backend, free_flyer):
         acc6 = AccelerationLimit(m, np.full(m.nv, 50.0))
         solve_ik_batch(cb, [ft, po], dt, limits=[ConfigurationLimit(m, 0.7), VelocityLimit(m), acc6])
         assert pink_amd.last_solve_stats()["route"] != "device"
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_equality_constraints_made_of_frame_tasks_on_the_hybrid_route(backend, free_flyer):
+    """solve_ik(..., constraints=[FrameTask / RelativeFrameTask]) (pink/solve_ik.py:125-149: A = J, b = -gain e): the
+    frame-row kernel writes the constraint's Jacobian into the leading dense rows of the QP and its error into their
+    right-hand sides on the device; only -gain is applied on the host.  Same velocities as the all-host evaluation and as
+    one solve_ik per configuration; the equality holds for the returned velocity."""
+    m = build_chain(10, free_flyer=free_flyer, seed=12, limit=2.8, velocity=8.0)
+    rng = np.random.default_rng(55)
+    B, dt = 70, 5e-3
+    q = _draw_q(m, B, rng, spread=0.6)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    hold_R, hold_t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    for b, c in enumerate(cfgs):
+        T = c.get_transform_frame_to_world("tool0") * exp6(0.05 * rng.normal(size=6))
+        R[b], t[b] = T.rotation, T.translation
+        H = c.get_transform_frame_to_world("joint_9")  # (nine joints upstream: six equations are within reach of the box)
+        hold_R[b], hold_t[b] = H.rotation, H.translation
+    ft.set_target_poses(R, t)
+    hold = FrameTask("joint_9", 1.0, 1.0, gain=0.7)  # enforced strictly: the frame goes where its target is
+    hold.set_target_poses(hold_R, hold_t + 2e-4 * rng.normal(size=(B, 3)))
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    cb = ConfigurationBatch(m, q)
+    stacks = [("one", [hold])]
+    if free_flyer:  # (twelve equations need the floating base's six coordinates); per-instance constraint objects
+        per = []
+        for b, c in enumerate(cfgs):
+            hb = FrameTask("joint_9", 1.0, 1.0, gain=0.7)
+            hb.set_target(SE3(hold.target_poses[b, :9].reshape(3, 3), hold.target_poses[b, 9:]))
+            rb = RelativeFrameTask("tool0", "joint_2", 1.0, 1.0, gain=0.5)
+            rb.set_target(c.get_transform("tool0", "joint_2") * exp6(1e-3 * rng.normal(size=6)))
+            per.append([hb, rb])
+        stacks.append(("frame + relative", per))
+    for name, cons in stacks:
+        V = solve_ik_batch(cb, [ft, po], dt, constraints=cons)
+        assert pink_amd.last_solve_stats()["route"] == "hybrid", name
+        V_host = solve_ik_batch(cb, [ft, po], dt, constraints=cons, device_kinematics=False, gpu_frame_tasks=False)
+        assert pink_amd.last_solve_stats()["route"] == "host-evaluated", name
+        scale = max(1.0, np.abs(V_host).max())
+        assert np.abs(V - V_host).max() < 1e-7 * scale and np.abs(V).max() > 1e-3, name
+        for b in range(3):
+            own = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+            own.set_target(SE3(R[b], t[b]))
+            oh = FrameTask("joint_9", 1.0, 1.0, gain=0.7)
+            oh.set_target(SE3(hold.target_poses[b, :9].reshape(3, 3), hold.target_poses[b, 9:]))
+            mine = [oh] if name == "one" else cons[b]
+            v = solve_ik(cfgs[b], [own, po], dt, constraints=mine)
+            assert np.abs(V[b] - v).max() < 1e-7 * max(1.0, np.abs(v).max()), (name, b)
+            for c_ in mine:  # J dq = -gain e
+                assert np.abs(c_.compute_jacobian(cfgs[b]) @ (V[b] * dt) + c_.gain * c_.compute_error(cfgs[b])).max() < 1e-9, (name, b)
