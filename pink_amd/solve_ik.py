@@ -719,9 +719,10 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     Raises :class:`NoSolutionFound` listing the failing instances (the batched
     analogue of ``pink/solve_ik.py:271-273``).
 
-    ``device_kinematics``: when the task stack is FrameTasks next to tasks the whole-step kernel forms from tables --
-    one PostureTask, LinearHolonomicTasks / JointCouplingTasks on the joints behind the root, DampingTask,
-    LowAccelerationTask, JointVelocityTask (one object each for the whole batch) -- under the model's default limits,
+    ``device_kinematics``: when the task stack is FrameTasks / RelativeFrameTasks next to tasks the whole-step kernel forms
+    from tables -- one PostureTask, LinearHolonomicTasks / JointCouplingTasks on the joints behind the root, DampingTask,
+    LowAccelerationTask, JointVelocityTask (one object each for the whole batch) -- under the model's default limits
+    (``limits=None``, or that list written out, optionally with one AccelerationLimit on the joints behind the root),
     forward kinematics, task errors / Jacobians and limits are evaluated by the device kernel from ``q`` alone
     instead of on the host (``None``: do so for batches of 64 and more; ``True``: require it; ``"frame_rows"``: only the
     FrameTask rows on the device, everything else evaluated on the host for the whole batch -- the route any other
