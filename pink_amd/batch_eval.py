@@ -151,7 +151,7 @@ def _low_acceleration_task(kin: BatchKinematics, col, solver=None):
 
 
 def _joint_velocity_task(kin: BatchKinematics, col, solver=None):
-    """``pink/tasks/joint_velocity_task.py:59-110``: ``e = -dt v*``, ``J = I`` after the root joint."""
+    """``pink/tasks/joint_velocity_task.py:59-110``: ``e = dt v*`` (what the reference's ``compute_error`` returns), ``J = I`` after the root joint."""
     t0 = col[0]
     root = kin.model.root_joint
     r = 0 if root is None else root.nv
@@ -162,7 +162,7 @@ def _joint_velocity_task(kin: BatchKinematics, col, solver=None):
             raise TargetNotSet("no target set for joint velocity task")
         if t.target_v.shape[0] != k:
             raise TaskDefinitionError(f"target velocity has dimension {t.target_v.shape[0]}, expected {k}")
-        rows.append(-t.target_dt * t.target_v)
+        rows.append(t.target_dt * t.target_v)
     e = np.broadcast_to(rows[0], (kin.B, k)) if _same(col) else np.stack(rows)
     return DiagonalTaskTerm(col0=r, e=np.ascontiguousarray(e), cost=_costs(col, k), gain=t0.gain, lm_damping=t0.lm_damping)
 

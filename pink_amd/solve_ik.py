@@ -473,7 +473,7 @@ def _extra_task(model, t):
         r = 0 if model.root_joint is None else model.root_joint.nv
         if t.target_v is None or t.target_dt is None or t.target_v.shape[0] != nv - r:
             return None  # (the host path raises the reference's errors)
-        return ("diag", r, -t.target_dt * t.target_v, t.cost, float(t.gain), float(t.lm_damping))
+        return ("diag", r, t.target_dt * t.target_v, t.cost, float(t.gain), float(t.lm_damping))
     return None
 
 

@@ -67,7 +67,9 @@ class JointCouplingTask(LinearHolonomicTask):
 
 class JointVelocityTask(Task):
     """Track a target tangent velocity of the actuated joints (``joint_velocity_task.py``):
-    ``e = -dt v_target``, ``J = I`` on the columns after the root joint."""
+    ``e = dt v_target`` -- the reference's ``compute_error`` returns the target displacement itself
+    (``joint_velocity_task.py:59-80``; pinned by ``tests/golden/pink_round4.npz``, produced by the reference's class) --
+    ``J = I`` on the columns after the root joint."""
 
     def __init__(self, cost: float) -> None:
         super().__init__(cost=cost, gain=1.0, lm_damping=0.0)
@@ -93,7 +95,7 @@ class JointVelocityTask(Task):
         k = configuration.model.nv - self._root_nv(configuration)
         if self.target_v.shape[0] != k:
             raise TaskDefinitionError(f"target velocity has dimension {self.target_v.shape[0]}, expected {k}")
-        return -self.target_dt * self.target_v
+        return self.target_dt * self.target_v
 
     def compute_jacobian(self, configuration) -> np.ndarray:
         nv, r = configuration.model.nv, self._root_nv(configuration)

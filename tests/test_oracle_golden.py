@@ -91,3 +91,87 @@ def test_c_oracle_stacking_matches_reference(golden, n):
     stat, viol, lam = po.kkt_residuals(golden[f"{n}/P"], golden[f"{n}/qvec"], golden[f"{n}/G"], golden[f"{n}/h"],
                                        out["dq"][0], A=A, b=b)
     assert stat < 1e-10 and viol < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the task / limit classes the whole-step kernel forms from tables, held to the outputs of the REFERENCE's own
+# classes (tests/golden/make_golden_round4.py -> pink_round4.npz: pink.limits.AccelerationLimit, pink.tasks.
+# LinearHolonomicTask / JointCouplingTask / DampingTask / LowAccelerationTask / JointVelocityTask on vector-space models).
+@pytest.fixture(scope="module")
+def golden4():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pink_round4.npz"))
+
+
+def _model_of(g, n):
+    from pink_amd import Configuration, build_chain
+
+    nv = int(g[f"{n}/nv"])
+    m = build_chain(nv)
+    m._lower, m._upper, m._vel = list(g[f"{n}/q_min"]), list(g[f"{n}/q_max"]), list(g[f"{n}/v_max"])
+    return m, Configuration(m, g[f"{n}/q"].copy()), float(g[f"{n}/dt"])
+
+
+@pytest.mark.parametrize("n", ["arm7", "arm12"])
+def test_acceleration_limit_matches_the_reference_class(golden4, n):
+    """pink/limits/acceleration_limit.py:119-199 -- rows +-e_i and their bounds, a joint without configuration limits,
+    a joint without an acceleration limit, a previous displacement -- and the three tables the device reads."""
+    import sys
+
+    from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+
+    g = golden4
+    m, cfg, dt = _model_of(g, n)
+    acc = AccelerationLimit(m, g[f"{n}/a_max"].copy())
+    acc.set_last_integration(g[f"{n}/v_prev"], dt)
+    G, h = acc.compute_qp_inequalities(cfg, dt)
+    assert np.array_equal(G, g[f"{n}/acc_G"]) and np.abs(h - g[f"{n}/acc_h"]).max() < 1e-15
+    # the device's tables (pinkhip_rollout_step.acc_limit) carry the same box: upper bounds then lower bounds of G dq <= h
+    gain, tables = sys.modules["pink_amd.solve_ik"]._default_limits_gain(m, [ConfigurationLimit(m), VelocityLimit(m), acc])
+    idx, k = acc.indices, len(acc.indices)
+    a, dqp, has = tables[0, idx], tables[1, idx], tables[2, idx] != 0
+    with np.errstate(invalid="ignore"):
+        up = np.where(has, np.minimum(a * dt * dt + dqp, dt * np.sqrt(2 * a * (m.upperPositionLimit[idx] - cfg.q[idx]))), a * dt * dt + dqp)
+        lw = np.where(has, np.minimum(a * dt * dt - dqp, dt * np.sqrt(2 * a * (cfg.q[idx] - m.lowerPositionLimit[idx]))), a * dt * dt - dqp)
+    assert np.abs(up - g[f"{n}/acc_h"][:k]).max() < 1e-15 and np.abs(lw - g[f"{n}/acc_h"][k:]).max() < 1e-15
+    assert (tables[0, np.setdiff1d(np.arange(m.nv), idx)] == 0).all()
+
+
+@pytest.mark.parametrize("n", ["arm7", "arm12"])
+def test_table_formed_tasks_match_the_reference_classes(golden4, n, emu):
+    """e, J (and H, c through the stack kernel) of LinearHolonomicTask, JointCouplingTask, DampingTask,
+    LowAccelerationTask, JointVelocityTask (pink/tasks/linear_holonomic_task.py:103-148, joint_coupling_task.py,
+    damping_task.py, low_acceleration_task.py:46-84, joint_velocity_task.py:59-110)."""
+    from pink_amd import DampingTask, PostureTask
+    from pink_amd.runtime import set_default_solver
+    from pink_amd.tasks import JointCouplingTask, JointVelocityTask, LinearHolonomicTask, LowAccelerationTask
+
+    g = golden4
+    m, cfg, dt = _model_of(g, n)
+    set_default_solver(emu)
+    try:
+        lh = LinearHolonomicTask(g[f"{n}/lh_A"], g[f"{n}/lh_b"], g[f"{n}/lh_q0"], cost=[1.0, 2.0, 0.5], lm_damping=1e-3, gain=0.8)
+        jc = JointCouplingTask(["joint_2", "joint_3", "joint_6"], list(g[f"{n}/jc_ratios"]), 100.0, cfg, lm_damping=5e-7)
+        for t, key in ((lh, "lh"), (jc, "jc")):
+            assert np.abs(t.compute_error(cfg) - g[f"{n}/{key}_e"]).max() < 1e-15
+            assert np.abs(t.compute_jacobian(cfg) - g[f"{n}/{key}_J"]).max() < 1e-15
+            H, c = t.compute_qp_objective(cfg)
+            assert np.abs(H - g[f"{n}/{key}_H"]).max() < 1e-12 * max(1.0, np.abs(g[f"{n}/{key}_H"]).max())
+            assert np.abs(c - g[f"{n}/{key}_c"]).max() < 1e-12 * max(1.0, np.abs(g[f"{n}/{key}_c"]).max())
+        dm = DampingTask(cost=0.3)
+        la = LowAccelerationTask(cost=0.2)
+        la.set_last_integration(g[f"{n}/v_prev"], dt)
+        jv = JointVelocityTask(cost=0.1)
+        jv.set_target(g[f"{n}/jv_target"], dt)
+        for t, key in ((dm, "damp"), (la, "la"), (jv, "jv")):
+            assert np.abs(t.compute_error(cfg) - g[f"{n}/{key}_e"]).max() < 1e-16
+            assert np.array_equal(t.compute_jacobian(cfg), g[f"{n}/{key}_J"])
+        po = PostureTask(cost=0.4, lm_damping=1e-2, gain=0.6)
+        po.set_target(g[f"{n}/posture_target"])
+        assert np.abs(po.compute_error(cfg) - g[f"{n}/posture_e"]).max() < 1e-16
+        assert np.array_equal(po.compute_jacobian(cfg), g[f"{n}/posture_J"])
+        H, c = po.compute_qp_objective(cfg)
+        assert np.abs(H - g[f"{n}/posture_H"]).max() < 1e-12 and np.abs(c - g[f"{n}/posture_c"]).max() < 1e-12
+    finally:
+        set_default_solver(None)
