@@ -4,6 +4,7 @@ REFERENCE's own classes (run here, once; needs /root/reference):
   pink.limits.AccelerationLimit.compute_qp_inequalities      (pink/limits/acceleration_limit.py:119-199)
   pink.tasks.LinearHolonomicTask / JointCouplingTask          (pink/tasks/linear_holonomic_task.py, joint_coupling_task.py)
   pink.tasks.DampingTask, LowAccelerationTask, JointVelocityTask, PostureTask (compute_error / compute_jacobian)
+  pink.barriers.PositionBarrier.compute_qp_inequalities / compute_qp_objective  (position_barrier.py:95-153, barrier.py:151-254)
 
 on vector-space models (one single-dof joint per coordinate: the stub `pinocchio` of make_golden.py supplies
 `pin.difference` / `pin.dDifference` for those), seeded inputs.  Nothing of the reference is copied: only its OUTPUTS
@@ -112,6 +113,95 @@ def main():
         out[f"{case}/posture_e"], out[f"{case}/posture_J"] = po.compute_error(cfg), po.compute_jacobian(cfg)
         Hc = po.compute_qp_objective(cfg)
         out[f"{case}/posture_H"], out[f"{case}/posture_c"] = Hc[0], Hc[1]
+    # PositionBarrier (pink/barriers/position_barrier.py:95-153 on top of barrier.py:151-254): the reference's class,
+    # driven by a pink_amd Configuration -- it only asks the configuration for a frame's pose and body Jacobian, which
+    # the NumPy kinematics stand-in of this repo supplies (so the kinematics are ours, the barrier arithmetic -- bounds,
+    # signs, tiled gains, safe-displacement regulariser -- the reference's)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from pink.barriers import PositionBarrier
+
+    from pink_amd import Configuration, build_chain
+
+    for case, n, ff in (("pb_arm", 7, False), ("pb_humanoid", 9, True)):
+        m = build_chain(n, free_flyer=ff, seed=4)
+        q = m.neutral()
+        for j in m.joints:
+            if j.kind != "free_flyer":
+                q[j.idx_q] = rng.uniform(-0.8, 0.8)
+        cfg = Configuration(m, q)
+        p = cfg.get_transform_frame_to_world("tool0").translation
+        dt = 5e-3
+        out[f"{case}/q"], out[f"{case}/dt"], out[f"{case}/n"], out[f"{case}/ff"] = q, dt, n, int(ff)
+        variants = {
+            "max_z": dict(indices=[2], p_max=np.array([p[2] + 0.01]), gain=np.array([50.0]), safe_displacement_gain=0.0),
+            "box_xy": dict(indices=[0, 1], p_min=p[:2] - 0.2, p_max=p[:2] + 0.3, gain=np.array([100.0, 80.0]), safe_displacement_gain=1.0),
+            "min_all": dict(p_min=p - np.array([0.05, 0.1, 0.02]), gain=np.array([10.0, 20.0, 30.0]), safe_displacement_gain=3.0),
+        }
+        for name, kw in variants.items():
+            bar = PositionBarrier("tool0", **kw)
+            G, h = bar.compute_qp_inequalities(cfg, dt)
+            H, c = bar.compute_qp_objective(cfg)
+            out[f"{case}/{name}/G"], out[f"{case}/{name}/h"], out[f"{case}/{name}/H"], out[f"{case}/{name}/c"] = G, h, H, c
+            for k, v in kw.items():
+                out[f"{case}/{name}/{k}"] = np.asarray(v, dtype=float)
+        # BodySphericalBarrier (pink/barriers/body_spherical_barrier.py): two frames kept d_min apart, its own class-K function
+        from pink.barriers import BodySphericalBarrier
+
+        d = float(np.linalg.norm(cfg.get_transform_frame_to_world("tool0").translation - cfg.get_transform_frame_to_world("joint_2").translation))
+        for name, kw in (("far", dict(d_min=0.5 * d, gain=np.array([40.0]), safe_displacement_gain=2.0)),
+                         ("near", dict(d_min=0.98 * d, gain=np.array([5.0]), safe_displacement_gain=0.0))):
+            sb = BodySphericalBarrier(("tool0", "joint_2"), **kw)
+            G, h = sb.compute_qp_inequalities(cfg, dt)
+            H, c = sb.compute_qp_objective(cfg)
+            out[f"{case}/sph_{name}/G"], out[f"{case}/sph_{name}/h"], out[f"{case}/sph_{name}/H"], out[f"{case}/sph_{name}/c"] = G, h, H, c
+            out[f"{case}/sph_{name}/d_min"], out[f"{case}/sph_{name}/gain"] = kw["d_min"], kw["gain"]
+            out[f"{case}/sph_{name}/safe_displacement_gain"] = kw["safe_displacement_gain"]
+    # FloatingBaseVelocityLimit (pink/limits/floating_base_velocity_limit.py:60-148): the reference's class on an adapter
+    # that shows it this repo's model through the pin.Model names it uses; pin.getFrameJacobian hands out the stand-in's
+    # body Jacobian.  Identity, offset and rotated placements of the base frame; one unbounded component.
+    from pink.limits import FloatingBaseVelocityLimit
+
+    from pink_amd.lie import SE3, exp6
+
+    class ModelView:
+        def __init__(self, m):
+            self.m, self.nv, self.nq = m, m.nv, m.nq
+            self.joints = m.joints
+            self.frames = [types.SimpleNamespace(name=f.name, parentJoint=f.joint) for f in m.frames]
+
+        def existJointName(self, name):
+            return any(j.name == name for j in self.m.joints)
+
+        def getJointId(self, name):
+            return self.m.getJointId(name)
+
+        def existFrame(self, name):
+            return any(f.name == name for f in self.m.frames)
+
+        def getFrameId(self, name):
+            return self.m.getFrameId(name)
+
+    m = build_chain(6, free_flyer=True, seed=8)
+    root_id = m.joints.index(m.root_joint)
+    m.add_frame("base_id", root_id, SE3())
+    m.add_frame("base_off", root_id, SE3(np.eye(3), [0.1, -0.05, 0.2]))
+    m.add_frame("base_rot", root_id, exp6(np.array([0.05, 0.1, -0.1, 0.4, -0.3, 0.6])))
+    q = m.neutral()
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[j.idx_q] = rng.uniform(-0.8, 0.8)
+    M0 = exp6(rng.normal(size=6) * 0.5)
+    from pink_amd.configuration import _rot_to_quat
+
+    q[0:3], q[3:7] = M0.translation, _rot_to_quat(M0.rotation)
+    cfg = Configuration(m, q)
+    view = ModelView(m)
+    pin.getFrameJacobian = lambda model, data, fid, rf: np.array(data.get_frame_jacobian(model.frames[fid].name))
+    out["fb/q"], out["fb/dt"] = q, 5e-3
+    for name in ("base_id", "base_off", "base_rot"):
+        lim = FloatingBaseVelocityLimit(view, name, [0.3, 0.2, np.inf], 0.5)
+        G, h = lim.compute_qp_inequalities(types.SimpleNamespace(data=cfg), 5e-3)
+        out[f"fb/{name}/G"], out[f"fb/{name}/h"] = G, h
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

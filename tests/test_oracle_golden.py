@@ -175,3 +175,103 @@ def test_table_formed_tasks_match_the_reference_classes(golden4, n, emu):
         assert np.abs(H - g[f"{n}/posture_H"]).max() < 1e-12 and np.abs(c - g[f"{n}/posture_c"]).max() < 1e-12
     finally:
         set_default_solver(None)
+
+
+@pytest.mark.parametrize("case", ["pb_arm", "pb_humanoid"])
+def test_position_barrier_matches_the_reference_class(golden4, case, emu):
+    """pink.barriers.PositionBarrier of the reference (position_barrier.py:95-153 over barrier.py:151-254), run by
+    make_golden_round4.py on this repo's kinematics stand-in: G = -J_h / dt, h = gain (p - p_min | p_max - p) with the
+    gains tiled when both bounds are given, and the regulariser (H, c) of its objective -- pink_amd's class and the
+    stack kernel against it; then the rows the whole-step kernel forms on chip, through the velocities they produce."""
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.barriers import PositionBarrier
+    from pink_amd.runtime import set_default_solver
+
+    g = golden4
+    n, ff, dt = int(g[f"{case}/n"]), bool(g[f"{case}/ff"]), float(g[f"{case}/dt"])
+    m = build_chain(n, free_flyer=ff, seed=4)
+    cfg = Configuration(m, g[f"{case}/q"].copy())
+    set_default_solver(emu)
+    try:
+        for name in ("max_z", "box_xy", "min_all"):
+            kw = {}
+            for k in ("indices", "p_min", "p_max", "gain", "safe_displacement_gain"):
+                if f"{case}/{name}/{k}" in g:
+                    v = g[f"{case}/{name}/{k}"]
+                    kw[k] = [int(i) for i in v] if k == "indices" else (float(v) if k == "safe_displacement_gain" else v.copy())
+            bar = PositionBarrier("tool0", **kw)
+            G, h = bar.compute_qp_inequalities(cfg, dt)
+            assert np.abs(G - g[f"{case}/{name}/G"]).max() < 1e-12 * max(1.0, np.abs(G).max()), name
+            assert np.abs(h - g[f"{case}/{name}/h"]).max() < 1e-13 * max(1.0, np.abs(h).max()), name
+            H, c = bar.compute_qp_objective(cfg)
+            assert np.abs(H - g[f"{case}/{name}/H"]).max() < 1e-12 * max(1.0, np.abs(H).max()), name
+            assert np.abs(c - g[f"{case}/{name}/c"]).max() < 1e-12, name
+            # the whole-step kernel forms these rows on chip from the frame position and the columns' world twists: the QP
+            # with the REFERENCE's barrier rows and regulariser, solved by the host route from explicit terms, gives the
+            # same velocity as the device route
+            ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+            T = cfg.get_transform_frame_to_world("tool0").copy()
+            T.translation = T.translation + np.array([0.02, -0.01, 0.05])
+            ft.set_target(T)
+            po = PostureTask(cost=1e-2)
+            po.set_target(m.neutral())
+            cb = ConfigurationBatch(m, np.tile(cfg.q, (3, 1)))
+            V_dev = solve_ik_batch(cb, [ft, po], dt, barriers=[bar], device_kinematics=True)
+            assert pink_amd.last_solve_stats()["route"] == "device"
+            pr = pink_amd.build_ik(cfg, [ft, po], dt, barriers=[bar])
+            k = g[f"{case}/{name}/G"].shape[0]
+            assert np.abs(pr.G[-k:] - g[f"{case}/{name}/G"]).max() < 1e-12 * max(1.0, np.abs(G).max())  # (barriers come last: solve_ik.py:107-122)
+            v = pink_amd.solve_ik(cfg, [ft, po], dt, barriers=[bar])
+            assert np.abs(V_dev - v).max() < 1e-8 * max(1.0, np.abs(v).max()), name
+        # BodySphericalBarrier (body_spherical_barrier.py; evaluated on the host for the whole batch: DESIGN.md 3.4)
+        from pink_amd.barriers import BodySphericalBarrier
+
+        for name in ("far", "near"):
+            sb = BodySphericalBarrier(("tool0", "joint_2"), float(g[f"{case}/sph_{name}/d_min"]), gain=g[f"{case}/sph_{name}/gain"].copy(),
+                                      safe_displacement_gain=float(g[f"{case}/sph_{name}/safe_displacement_gain"]))
+            G, h = sb.compute_qp_inequalities(cfg, dt)
+            assert np.abs(G - g[f"{case}/sph_{name}/G"]).max() < 1e-12 * max(1.0, np.abs(G).max()), name
+            assert np.abs(h - g[f"{case}/sph_{name}/h"]).max() < 1e-13 * max(1.0, np.abs(h).max()), name
+            H, c = sb.compute_qp_objective(cfg)
+            assert np.abs(H - g[f"{case}/sph_{name}/H"]).max() < 1e-12 * max(1.0, np.abs(H).max()), name
+            assert np.abs(c - g[f"{case}/sph_{name}/c"]).max() < 1e-12, name
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
+
+
+def test_floating_base_velocity_limit_matches_the_reference_class(golden4, emu):
+    """pink.limits.FloatingBaseVelocityLimit of the reference (floating_base_velocity_limit.py:60-148) on this repo's model
+    (shown to it through an adapter with pin.Model's names): rows +-J_root and bounds dt twist_max, a component without a
+    bound, base frames with identity / offset / rotated placements -- pink_amd's class row for row; then what the device
+    makes of it (a box on the root coordinates + constant dense rows, rollout._floating_base_rows) describes the same set."""
+    from pink_amd import Configuration, build_chain
+    from pink_amd.lie import SE3, exp6
+    from pink_amd.limits import FloatingBaseVelocityLimit
+    from pink_amd.rollout import _floating_base_rows
+
+    g = golden4
+    m = build_chain(6, free_flyer=True, seed=8)
+    root_id = m.joints.index(m.root_joint)
+    m.add_frame("base_id", root_id, SE3())
+    m.add_frame("base_off", root_id, SE3(np.eye(3), [0.1, -0.05, 0.2]))
+    m.add_frame("base_rot", root_id, exp6(np.array([0.05, 0.1, -0.1, 0.4, -0.3, 0.6])))
+    cfg, dt = Configuration(m, g["fb/q"].copy()), float(g["fb/dt"])
+    rng = np.random.default_rng(1)
+    for name in ("base_id", "base_off", "base_rot"):
+        lim = FloatingBaseVelocityLimit(m, name, [0.3, 0.2, np.inf], 0.5)
+        G, h = lim.compute_qp_inequalities(cfg, dt)
+        assert np.abs(G - g[f"fb/{name}/G"]).max() < 1e-13 and np.abs(h - g[f"fb/{name}/h"]).max() < 1e-16, name
+        # the device form: box lo / hi on the six root coordinates + dense rows [n, 6]: same feasible set as G dq <= h
+        box, rows, hh = _floating_base_rows(m, lim, dt)
+        Gr, hr = g[f"fb/{name}/G"], g[f"fb/{name}/h"]
+        for _ in range(200):
+            dq = np.r_[rng.normal(size=6) * 2e-3, rng.normal(size=m.nv - 6)]
+            ref_ok = bool((Gr @ dq <= hr + 1e-15).all())
+            dev_ok = True
+            if box is not None:
+                dev_ok &= bool((dq[:6] >= box[:6] - 1e-15).all() and (dq[:6] <= box[6:] + 1e-15).all())
+            if len(hh):
+                dev_ok &= bool((np.asarray(rows) @ dq[:6] <= np.asarray(hh) + 1e-15).all())
+            assert ref_ok == dev_ok, name
