@@ -202,6 +202,42 @@ def main():
         lim = FloatingBaseVelocityLimit(view, name, [0.3, 0.2, np.inf], 0.5)
         G, h = lim.compute_qp_inequalities(types.SimpleNamespace(data=cfg), 5e-3)
         out[f"fb/{name}/G"], out[f"fb/{name}/h"] = G, h
+    # FrameTask / RelativeFrameTask (pink/tasks/frame_task.py:148-227, relative_frame_task.py:142-231): the reference's
+    # classes decide WHICH transforms are composed and with which sign; pin.log / pin.Jlog6 are stubbed with the
+    # independent SE(3) maps of oracle/se3_oracle.py (matrix logarithm through SciPy, Jacobian by central differences:
+    # 1e-8 on J) -- not with the closed forms the product uses.
+    from oracle import se3_oracle
+
+    from pink.tasks import FrameTask, RelativeFrameTask
+
+    def mat(T):
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = T.rotation, T.translation
+        return M
+
+    pin.log = lambda T: types.SimpleNamespace(vector=se3_oracle.log6(mat(T)))
+    pin.Jlog6 = lambda T: se3_oracle.jlog6_fd(mat(T))
+    m = build_chain(8, free_flyer=True, seed=11)
+    m.add_frame("mid", m.getJointId("joint_4"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    q = m.neutral()
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[j.idx_q] = rng.uniform(-0.8, 0.8)
+    M0 = exp6(rng.normal(size=6) * 0.5)
+    q[0:3], q[3:7] = M0.translation, _rot_to_quat(M0.rotation)
+    cfg = Configuration(m, q)
+    out["ft/q"] = q
+    for name, scale in (("small", 1e-2), ("large", 0.6)):
+        ft = FrameTask("tool0", position_cost=1.0, orientation_cost=0.5)
+        tgt = cfg.get_transform_frame_to_world("tool0") * exp6(scale * rng.normal(size=6))
+        ft.set_target(tgt)
+        out[f"ft/{name}/target"] = np.r_[np.asarray(tgt.rotation).ravel(), tgt.translation]
+        out[f"ft/{name}/e"], out[f"ft/{name}/J"] = ft.compute_error(cfg), ft.compute_jacobian(cfg)
+        rt = RelativeFrameTask("tool0", "mid", position_cost=1.0, orientation_cost=0.5)
+        rtg = cfg.get_transform("tool0", "mid") * exp6(scale * rng.normal(size=6))
+        rt.set_target(rtg)
+        out[f"ft/{name}/rel_target"] = np.r_[np.asarray(rtg.rotation).ravel(), rtg.translation]
+        out[f"ft/{name}/rel_e"], out[f"ft/{name}/rel_J"] = rt.compute_error(cfg), rt.compute_jacobian(cfg)
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

@@ -275,3 +275,29 @@ def test_floating_base_velocity_limit_matches_the_reference_class(golden4, emu):
             if len(hh):
                 dev_ok &= bool((np.asarray(rows) @ dq[:6] <= np.asarray(hh) + 1e-15).all())
             assert ref_ok == dev_ok, name
+
+
+def test_frame_tasks_follow_the_compositions_of_the_reference_classes(golden4):
+    """pink.tasks.FrameTask / RelativeFrameTask of the reference (frame_task.py:148-227, relative_frame_task.py:142-231),
+    run on this repo's kinematics with pin.log / pin.Jlog6 replaced by the independent maps of oracle/se3_oracle.py
+    (matrix logarithm; central differences for the Jacobian, hence 1e-7 on J): which transforms are composed, in which
+    order and with which sign is the reference's; pink_amd's classes (closed forms / series) give the same e and J."""
+    from pink_amd import Configuration, FrameTask, build_chain
+    from pink_amd.lie import SE3
+    from pink_amd.tasks import RelativeFrameTask
+
+    g = golden4
+    m = build_chain(8, free_flyer=True, seed=11)
+    m.add_frame("mid", m.getJointId("joint_4"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    cfg = Configuration(m, g["ft/q"].copy())
+    for name in ("small", "large"):
+        ft = FrameTask("tool0", 1.0, 0.5)
+        T = g[f"ft/{name}/target"]
+        ft.set_target(SE3(T[:9].reshape(3, 3), T[9:]))
+        assert np.abs(ft.compute_error(cfg) - g[f"ft/{name}/e"]).max() < 1e-11, name
+        assert np.abs(ft.compute_jacobian(cfg) - g[f"ft/{name}/J"]).max() < 2e-7, name
+        rt = RelativeFrameTask("tool0", "mid", 1.0, 0.5)
+        T = g[f"ft/{name}/rel_target"]
+        rt.set_target(SE3(T[:9].reshape(3, 3), T[9:]))
+        assert np.abs(rt.compute_error(cfg) - g[f"ft/{name}/rel_e"]).max() < 1e-11, name
+        assert np.abs(rt.compute_jacobian(cfg) - g[f"ft/{name}/rel_J"]).max() < 2e-7, name
