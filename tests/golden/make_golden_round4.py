@@ -106,6 +106,12 @@ def main():
         jv.set_target(v_t, dt)
         out[f"{case}/jv_target"] = v_t
         out[f"{case}/jv_e"], out[f"{case}/jv_J"] = jv.compute_error(cfg), jv.compute_jacobian(cfg)
+        from pink.limits import ConfigurationLimit, VelocityLimit
+
+        cl = ConfigurationLimit(model, config_limit_gain=0.7)  # (an explicit gain: honoured by the device's coordinate_box)
+        Gc, hc = cl.compute_qp_inequalities(cfg, dt)
+        Gv, hv = VelocityLimit(model).compute_qp_inequalities(cfg, dt)
+        out[f"{case}/cl_G"], out[f"{case}/cl_h"], out[f"{case}/vl_G"], out[f"{case}/vl_h"] = Gc, hc, Gv, hv
         po = PostureTask(cost=0.4, lm_damping=1e-2, gain=0.6)
         q_star = rng.uniform(-0.5, 0.5, size=nv)
         po.set_target(q_star)
