@@ -163,7 +163,10 @@ class DeviceRollout:
         JointVelocityTask).  ``acceleration_limit``: ``[3, nv]`` -- ``a_max`` (0: no bound on that coordinate),
         ``Delta_q_prev``, ``has_configuration_limit`` per tangent coordinate of an AccelerationLimit on the joints behind
         the root (``pink/limits/acceleration_limit.py:158-199``), folded into the box on chip.  All three need the
-        whole-step kernel (``fused="kernel"``)."""
+        whole-step kernel (``fused="kernel"``).  The tables are the same for every robot and stay what they are over
+        :meth:`run`: state that follows the previous step of each robot (``LowAccelerationTask.set_last_integration``,
+        ``AccelerationLimit.set_last_integration``) is the caller's to refresh between steps
+        (:meth:`set_diag_errors`, :meth:`set_acceleration_limit`) -- :func:`pink_amd.solve_ik_batch` does so per call."""
         self.api, self.model, self.dt = api, model, float(dt)
         # "kernel": the whole step in one launch; True: step kernel + solve; False: five separate launches
         self.fused = fused if fused == "kernel" else bool(fused)
