@@ -244,6 +244,34 @@ def main():
         rt.set_target(rtg)
         out[f"ft/{name}/rel_target"] = np.r_[np.asarray(rtg.rotation).ravel(), rtg.translation]
         out[f"ft/{name}/rel_e"], out[f"ft/{name}/rel_J"] = rt.compute_error(cfg), rt.compute_jacobian(cfg)
+    # Configuration.check_limits (pink/configuration.py:166-201): the reference's method, called unbound on a stand-in
+    # that has .q and .model -- tolerance, "no limit" joints, the skipped root coordinates, which entry is reported
+    import pink
+    from pink.exceptions import NotWithinConfigurationLimits
+
+    for case, ff in (("cl_arm", False), ("cl_humanoid", True)):
+        mm = build_chain(6, free_flyer=ff, seed=3, limit=1.0)
+        lo, up = mm.lowerPositionLimit, mm.upperPositionLimit
+        view = ModelView(mm)
+        view.lowerPositionLimit, view.upperPositionLimit = lo, up
+        r = 7 if ff else 0
+        base = mm.neutral()
+        qs, verdicts = [], []
+        trials = [(), ((r + 2, up[r + 2] + 5e-7),), ((r + 2, up[r + 2] + 2e-6),), ((r + 4, lo[r + 4] - 3e-6), (r + 1, up[r + 1] + 1.0)),
+                  ((r + 0, lo[r + 0] - 0.5),)]
+        if ff:
+            trials.append(((1, 50.0),))  # a root coordinate far away: not checked
+        for edits in trials:
+            q = base.copy()
+            for i, v in edits:
+                q[i] = v
+            try:
+                pink.Configuration.check_limits(types.SimpleNamespace(q=q, model=view), 1e-6, True)
+                verdicts.append([-1, 0.0, 0.0, 0.0])
+            except NotWithinConfigurationLimits as exc:
+                verdicts.append([exc.joint, exc.value, exc.lower, exc.upper])
+            qs.append(q)
+        out[f"{case}/q"], out[f"{case}/verdict"] = np.array(qs), np.array(verdicts, dtype=float)
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

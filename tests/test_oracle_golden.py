@@ -341,3 +341,33 @@ def test_device_box_equals_the_reference_limits_merged(golden4, n, emu):
     for p_ in (d_q, d_qt, d_lb, d_ub, d_e):
         emu.release(p_)
     emu.model_destroy(dm)
+
+
+@pytest.mark.parametrize("case", ["cl_arm", "cl_humanoid"])
+def test_check_limits_follows_the_reference_method(golden4, case, emu):
+    """pink.Configuration.check_limits of the reference (configuration.py:166-201), called on stand-ins by
+    make_golden_round4.py: inside, outside by less / more than the tolerance, two offending entries (the first one is
+    reported), the root joint's coordinates (never checked) -- pink_amd's Configuration.check_limits, the vectorised check
+    of a ConfigurationBatch and the device kernel (pinkhip_check_limits_device) give the same verdicts."""
+    from pink_amd import Configuration, ConfigurationBatch, build_chain
+    from pink_amd.exceptions import NotWithinConfigurationLimits
+    from pink_amd.rollout import ModelArrays
+
+    g = golden4
+    m = build_chain(6, free_flyer=case == "cl_humanoid", seed=3, limit=1.0)
+    arrays = ModelArrays(m, ["tool0"])
+    dm = emu.model_create(arrays.desc)
+    d_q = emu.alloc(8 * m.nq)
+    for q, verdict in zip(g[f"{case}/q"], g[f"{case}/verdict"]):
+        want = int(verdict[0])
+        for check in (lambda: Configuration(m, q.copy()).check_limits(), lambda: ConfigurationBatch(m, q[None].copy()).check_limits()):
+            if want < 0:
+                check()
+            else:
+                with pytest.raises(NotWithinConfigurationLimits) as ei:
+                    check()
+                assert (ei.value.joint, ei.value.value, ei.value.lower, ei.value.upper) == (want, verdict[1], verdict[2], verdict[3])
+        emu.put(d_q, q[None].copy())
+        assert emu.check_limits(dm, 1, d_q) == want  # (b * nq + i with b = 0, or -1)
+    emu.release(d_q)
+    emu.model_destroy(dm)
