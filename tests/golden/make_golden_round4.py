@@ -272,6 +272,76 @@ def main():
                 verdicts.append([exc.joint, exc.value, exc.lower, exc.upper])
             qs.append(q)
         out[f"{case}/q"], out[f"{case}/verdict"] = np.array(qs), np.array(verdicts, dtype=float)
+    # ------------------------------------------------------------------------------------------------------------------
+    # The whole stacking path at once: the reference's OWN pink.build_ik (pink/solve_ik.py:152-203) over the reference's OWN
+    # FrameTask x 3, RelativeFrameTask, PostureTask, JointCouplingTask x 2, DampingTask, ConfigurationLimit, VelocityLimit,
+    # AccelerationLimit, FloatingBaseVelocityLimit and PositionBarrier objects -- the stack of examples/humanoid_draco3.py and
+    # then some -- on a floating-base robot whose kinematics come from this repo's stand-in.  pin.Jlog6 by a fourth-order
+    # difference of the matrix logarithm (1e-11), so that the QP it builds can be held to 1e-9.
+    def jlog6_4th(T, h=1e-3):
+        Tm = mat(T)
+        J = np.zeros((6, 6))
+        f = lambda d: se3_oracle.log6(Tm @ se3_oracle.exp6(d))  # noqa: E731
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = h
+            J[:, k] = (-f(2 * d) + 8 * f(d) - 8 * f(-d) + f(-2 * d)) / (12 * h)
+        return J
+
+    pin.Jlog6 = jlog6_4th
+    pin.difference = lambda model, q0, q1: model.m.difference(np.asarray(q0, dtype=float), np.asarray(q1, dtype=float))
+    pin.neutral = lambda model: model.m.neutral()
+    pin.dDifference = lambda model, q0, q1, arg: model.m.d_difference(np.asarray(q0, dtype=float), np.asarray(q1, dtype=float))
+    from pink.limits import ConfigurationLimit, VelocityLimit
+
+    m = build_chain(12, free_flyer=True, seed=21, limit=2.5, velocity=6.0)
+    root_id = m.joints.index(m.root_joint)
+    m.add_frame("base", root_id, exp6(np.array([0.02, 0.0, 0.05, 0.1, -0.2, 0.3])))
+    m.add_frame("mid", m.getJointId("joint_5"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    q = m.neutral()
+    for j in m.joints:
+        if j.kind != "free_flyer":
+            q[j.idx_q] = rng.uniform(-0.8, 0.8)
+    M0 = exp6(rng.normal(size=6) * 0.4)
+    q[0:3], q[3:7] = M0.translation, _rot_to_quat(M0.rotation)
+    cfg = Configuration(m, q)
+    view = ModelView(m)
+    view.lowerPositionLimit, view.upperPositionLimit, view.velocityLimit = m.lowerPositionLimit, m.upperPositionLimit, m.velocityLimit
+    view.hasConfigurationLimit = lambda: np.isfinite(m.upperPositionLimit)
+    ref_cfg = types.SimpleNamespace(q=cfg.q, model=view, tangent=cfg.tangent, data=cfg, get_transform_frame_to_world=cfg.get_transform_frame_to_world,
+                                    get_transform=cfg.get_transform, get_frame_jacobian=cfg.get_frame_jacobian)
+    dt, damping = 5e-3, 1e-12
+    tasks, targets = [], {}
+    for k, (frame, pc, oc, lm, gain) in enumerate((("tool0", 1.0, 1.0, 1e-3, 1.0), ("joint_4", [1.0, 2.0, 0.5], 0.0, 0.0, 0.85), ("joint_9", 4.0, 4.0, 1e-2, 0.5))):
+        t = FrameTask(frame, position_cost=pc, orientation_cost=oc, lm_damping=lm, gain=gain)
+        tgt = cfg.get_transform_frame_to_world(frame) * exp6(0.05 * rng.normal(size=6))
+        t.set_target(tgt)
+        targets[f"frame{k}"] = np.r_[np.asarray(tgt.rotation).ravel(), tgt.translation]
+        tasks.append(t)
+    rt = RelativeFrameTask("tool0", "mid", position_cost=0.8, orientation_cost=0.3, lm_damping=1e-3, gain=0.9)
+    rtg = cfg.get_transform("tool0", "mid") * exp6(0.03 * rng.normal(size=6))
+    rt.set_target(rtg)
+    targets["rel"] = np.r_[np.asarray(rtg.rotation).ravel(), rtg.translation]
+    po = PostureTask(cost=1e-1)
+    q_star = m.neutral()
+    po.set_target(q_star)
+    jc1 = JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 100.0, ref_cfg, lm_damping=5e-7)
+    jc2 = JointCouplingTask(["joint_7", "joint_8"], [1.0, -1.0], 100.0, ref_cfg, lm_damping=5e-7)
+    dm = DampingTask(cost=1e-2)
+    tasks += [rt, po, jc1, jc2, dm]
+    a_max = np.r_[np.full(6, np.inf), np.full(12, 300.0)]
+    acc = AccelerationLimit(view, a_max.copy())
+    v_prev = np.r_[np.zeros(6), rng.normal(size=12) * 0.3]
+    acc.set_last_integration(v_prev, dt)
+    fb = FloatingBaseVelocityLimit(view, "base", [0.4, 0.3, 0.5], 0.8)
+    limits = [ConfigurationLimit(view, config_limit_gain=0.6), VelocityLimit(view), acc, fb]
+    p = cfg.get_transform_frame_to_world("tool0").translation
+    bar = PositionBarrier("tool0", indices=[2], p_max=np.array([p[2] + 0.01]), gain=np.array([50.0]), safe_displacement_gain=1.0)
+    problem = pink.build_ik(ref_cfg, tasks, dt, damping=damping, limits=limits, barriers=[bar])
+    out["full/q"], out["full/dt"], out["full/a_max"], out["full/v_prev"], out["full/bar_pmax"] = q, dt, a_max, v_prev, p[2] + 0.01
+    for k, v in targets.items():
+        out[f"full/target_{k}"] = v
+    out["full/P"], out["full/c"], out["full/G"], out["full/h"] = problem.P, problem.q, problem.G, problem.h
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

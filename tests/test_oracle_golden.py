@@ -371,3 +371,66 @@ def test_check_limits_follows_the_reference_method(golden4, case, emu):
         assert emu.check_limits(dm, 1, d_q) == want  # (b * nq + i with b = 0, or -1)
     emu.release(d_q)
     emu.model_destroy(dm)
+
+
+@pytest.mark.parametrize("where", ["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_whole_stack_against_the_references_build_ik(golden4, where, request):
+    """The reference's OWN pink.build_ik (pink/solve_ik.py:152-203) over its OWN FrameTask x 3, RelativeFrameTask,
+    PostureTask, JointCouplingTask x 2, DampingTask, ConfigurationLimit (explicit gain), VelocityLimit, AccelerationLimit,
+    FloatingBaseVelocityLimit and PositionBarrier objects on a floating-base robot (make_golden_round4.py: kinematics from
+    this repo's stand-in, pin.log / pin.Jlog6 from the matrix logarithm): (P, q, G, h) of pink_amd.build_ik row for row,
+    and the velocity of the device route -- every one of these terms formed on chip by the whole-step kernel -- as the
+    minimiser of THAT QP (KKT residuals, and the C oracle's solution of it)."""
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, DampingTask, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.barriers import PositionBarrier
+    from pink_amd.lie import SE3, exp6
+    from pink_amd.limits import AccelerationLimit, ConfigurationLimit, FloatingBaseVelocityLimit, VelocityLimit
+    from pink_amd.runtime import set_default_solver
+    from pink_amd.tasks import JointCouplingTask, RelativeFrameTask
+
+    g = golden4
+    m = build_chain(12, free_flyer=True, seed=21, limit=2.5, velocity=6.0)
+    root_id = m.joints.index(m.root_joint)
+    m.add_frame("base", root_id, exp6(np.array([0.02, 0.0, 0.05, 0.1, -0.2, 0.3])))
+    m.add_frame("mid", m.getJointId("joint_5"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
+    cfg, dt = Configuration(m, g["full/q"].copy()), float(g["full/dt"])
+    se3 = lambda v: SE3(v[:9].reshape(3, 3), v[9:])  # noqa: E731
+    tasks = []
+    for k, (frame, pc, oc, lm, gain) in enumerate((("tool0", 1.0, 1.0, 1e-3, 1.0), ("joint_4", [1.0, 2.0, 0.5], 0.0, 0.0, 0.85), ("joint_9", 4.0, 4.0, 1e-2, 0.5))):
+        t = FrameTask(frame, pc, oc, lm_damping=lm, gain=gain)
+        t.set_target(se3(g[f"full/target_frame{k}"]))
+        tasks.append(t)
+    rt = RelativeFrameTask("tool0", "mid", 0.8, 0.3, lm_damping=1e-3, gain=0.9)
+    rt.set_target(se3(g["full/target_rel"]))
+    posture = PostureTask(cost=1e-1)
+    posture.set_target(m.neutral())
+    tasks += [rt, posture, JointCouplingTask(["joint_2", "joint_3"], [1.0, -1.0], 100.0, cfg, lm_damping=5e-7),
+              JointCouplingTask(["joint_7", "joint_8"], [1.0, -1.0], 100.0, cfg, lm_damping=5e-7), DampingTask(cost=1e-2)]
+    acc = AccelerationLimit(m, g["full/a_max"].copy())
+    acc.set_last_integration(g["full/v_prev"], dt)
+    fb = FloatingBaseVelocityLimit(m, "base", [0.4, 0.3, 0.5], 0.8)
+    m.ensure_limits()
+    m.floating_base_velocity_limit = fb
+    limits = [ConfigurationLimit(m, 0.6), VelocityLimit(m), acc, fb]
+    bar = PositionBarrier("tool0", indices=[2], p_max=np.array([float(g["full/bar_pmax"])]), gain=np.array([50.0]), safe_displacement_gain=1.0)
+    P, c, G, h = g["full/P"], g["full/c"], g["full/G"], g["full/h"]
+    set_default_solver(request.getfixturevalue("emu" if where == "emu" else "gpu_solver"))
+    try:
+        pr = pink_amd.build_ik(cfg, tasks, dt, damping=1e-12, limits=limits, barriers=[bar])
+        assert np.abs(pr.P - P).max() < 1e-9 * np.abs(P).max() and np.abs(pr.q - c).max() < 1e-9 * max(1.0, np.abs(c).max())
+        assert pr.G.shape == G.shape and np.abs(pr.G - G).max() < 1e-11 * max(1.0, np.abs(G).max()) and np.abs(pr.h - h).max() < 1e-12
+        # the device route: everything above formed on chip from q, the targets and tables
+        cb = ConfigurationBatch(m, np.tile(cfg.q, (2, 1)))
+        V = solve_ik_batch(cb, tasks, dt, limits=limits, barriers=[bar], device_kinematics=True)
+        assert pink_amd.last_solve_stats()["route"] == "device"
+        x = V[0] * dt
+        stat, viol, _ = po.kkt_residuals(P, c, G, h, x)
+        scale = max(1.0, float(np.abs(c).max()), float(np.abs(P).max() * np.abs(x).max()))
+        assert viol < 1e-9 and stat < 1e-7 * scale, (stat, viol)  # (the reference's P holds a 1e-11 Jlog6: cond(P) amplifies it)
+        x_ref, st, _, _ = c_oracle.gi_solve(P, c, G, h)  # the reference's QP through the C restatement of Goldfarb-Idnani
+        assert st == 0 and np.abs(x - x_ref).max() < 1e-7 * max(1e-3, np.abs(x_ref).max()), np.abs(x - x_ref).max()
+        assert np.abs(V[1] - V[0]).max() == 0.0
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
