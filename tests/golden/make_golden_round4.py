@@ -342,6 +342,43 @@ def main():
     for k, v in targets.items():
         out[f"full/target_{k}"] = v
     out["full/P"], out["full/c"], out["full/G"], out["full/h"] = problem.P, problem.q, problem.G, problem.h
+    # ... and a fixed-base arm with the identity-Jacobian tasks that carry state of the previous step (LowAccelerationTask,
+    # JointVelocityTask -- whose error sign the first run of this file corrected) under ConfigurationLimit + VelocityLimit +
+    # AccelerationLimit: the reference's build_ik again
+    m = build_chain(7, free_flyer=False, seed=31, limit=2.2, velocity=5.0)
+    q = m.neutral()
+    for j in m.joints:
+        q[j.idx_q] = rng.uniform(-0.9, 0.9)
+    cfg = Configuration(m, q)
+    view = ModelView(m)
+    view.lowerPositionLimit, view.upperPositionLimit, view.velocityLimit = m.lowerPositionLimit, m.upperPositionLimit, m.velocityLimit
+    view.hasConfigurationLimit = lambda: np.isfinite(m.upperPositionLimit)
+    ref_cfg = types.SimpleNamespace(q=cfg.q, model=view, tangent=cfg.tangent, data=cfg, get_transform_frame_to_world=cfg.get_transform_frame_to_world,
+                                    get_transform=cfg.get_transform, get_frame_jacobian=cfg.get_frame_jacobian)
+    dt = 1e-2
+    ft = FrameTask("tool0", position_cost=[1.0, 1.0, 2.0], orientation_cost=0.2, lm_damping=1e-2, gain=0.7)
+    tgt = cfg.get_transform_frame_to_world("tool0") * exp6(0.08 * rng.normal(size=6))
+    ft.set_target(tgt)
+    ft2 = FrameTask("joint_4", position_cost=0.5, orientation_cost=0.0)
+    tgt2 = cfg.get_transform_frame_to_world("joint_4") * exp6(0.04 * rng.normal(size=6))
+    ft2.set_target(tgt2)
+    po = PostureTask(cost=5e-2, gain=0.8)
+    q_star = rng.uniform(-0.3, 0.3, size=m.nq)
+    po.set_target(q_star)
+    v_prev = rng.normal(size=m.nv) * 0.4
+    la = LowAccelerationTask(cost=0.05)
+    la.set_last_integration(v_prev, dt)
+    jv = JointVelocityTask(cost=0.08)
+    v_t = rng.normal(size=m.nv) * 0.3
+    jv.set_target(v_t, dt)
+    a_max = rng.uniform(30.0, 200.0, size=m.nv)
+    acc = AccelerationLimit(view, a_max.copy())
+    acc.set_last_integration(v_prev, dt)
+    problem = pink.build_ik(ref_cfg, [ft, ft2, po, la, jv], dt, damping=1e-12, limits=[ConfigurationLimit(view), VelocityLimit(view), acc])
+    out["arm/q"], out["arm/dt"], out["arm/q_star"], out["arm/v_prev"], out["arm/v_t"], out["arm/a_max"] = q, dt, q_star, v_prev, v_t, a_max
+    out["arm/target0"] = np.r_[np.asarray(tgt.rotation).ravel(), tgt.translation]
+    out["arm/target1"] = np.r_[np.asarray(tgt2.rotation).ravel(), tgt2.translation]
+    out["arm/P"], out["arm/c"], out["arm/G"], out["arm/h"] = problem.P, problem.q, problem.G, problem.h
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

@@ -434,3 +434,49 @@ def test_whole_stack_against_the_references_build_ik(golden4, where, request):
     finally:
         pink_amd.clear_device_cache()
         set_default_solver(None)
+
+
+@pytest.mark.parametrize("where", ["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_arm_stack_with_previous_step_state_against_the_references_build_ik(golden4, where, request):
+    """The reference's build_ik over its own FrameTask x 2, PostureTask, LowAccelerationTask, JointVelocityTask (the class
+    whose error sign this file's generator corrected) under ConfigurationLimit + VelocityLimit + AccelerationLimit on a
+    7-joint arm: pink_amd.build_ik row for row, and the device route's velocity as the minimiser of that QP (the arm runs
+    the whole-step kernel at NV = 12 because the stack needs it)."""
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.lie import SE3
+    from pink_amd.limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
+    from pink_amd.runtime import set_default_solver
+    from pink_amd.tasks import JointVelocityTask, LowAccelerationTask
+
+    g = golden4
+    m = build_chain(7, free_flyer=False, seed=31, limit=2.2, velocity=5.0)
+    cfg, dt = Configuration(m, g["arm/q"].copy()), float(g["arm/dt"])
+    se3 = lambda v: SE3(v[:9].reshape(3, 3), v[9:])  # noqa: E731
+    ft = FrameTask("tool0", [1.0, 1.0, 2.0], 0.2, lm_damping=1e-2, gain=0.7)
+    ft.set_target(se3(g["arm/target0"]))
+    ft2 = FrameTask("joint_4", 0.5, 0.0)
+    ft2.set_target(se3(g["arm/target1"]))
+    posture = PostureTask(cost=5e-2, gain=0.8)
+    posture.set_target(g["arm/q_star"])
+    la = LowAccelerationTask(cost=0.05)
+    la.set_last_integration(g["arm/v_prev"], dt)
+    jv = JointVelocityTask(cost=0.08)
+    jv.set_target(g["arm/v_t"], dt)
+    acc = AccelerationLimit(m, g["arm/a_max"].copy())
+    acc.set_last_integration(g["arm/v_prev"], dt)
+    tasks, limits = [ft, ft2, posture, la, jv], [ConfigurationLimit(m), VelocityLimit(m), acc]
+    P, c, G, h = g["arm/P"], g["arm/c"], g["arm/G"], g["arm/h"]
+    set_default_solver(request.getfixturevalue("emu" if where == "emu" else "gpu_solver"))
+    try:
+        pr = pink_amd.build_ik(cfg, tasks, dt, damping=1e-12, limits=limits)
+        assert np.abs(pr.P - P).max() < 1e-9 * np.abs(P).max() and np.abs(pr.q - c).max() < 1e-9 * max(1.0, np.abs(c).max())
+        assert pr.G.shape == G.shape and np.abs(pr.G - G).max() < 1e-12 and np.abs(pr.h - h).max() < 1e-13
+        V = solve_ik_batch(ConfigurationBatch(m, np.tile(cfg.q, (3, 1))), tasks, dt, limits=limits, device_kinematics=True)
+        assert pink_amd.last_solve_stats()["route"] == "device"
+        x = V[0] * dt
+        x_ref, st, _, _ = c_oracle.gi_solve(P, c, G, h)
+        assert st == 0 and np.abs(x - x_ref).max() < 1e-8 * max(1e-3, np.abs(x_ref).max()), np.abs(x - x_ref).max()
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
