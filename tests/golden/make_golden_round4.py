@@ -379,6 +379,13 @@ def main():
     out["arm/target0"] = np.r_[np.asarray(tgt.rotation).ravel(), tgt.translation]
     out["arm/target1"] = np.r_[np.asarray(tgt2.rotation).ravel(), tgt2.translation]
     out["arm/P"], out["arm/c"], out["arm/G"], out["arm/h"] = problem.P, problem.q, problem.G, problem.h
+    # ... and equality constraints (pink/solve_ik.py:125-149): the same arm, constraints=[FrameTask] next to a FrameTask and a posture
+    hold = FrameTask("joint_6", position_cost=1.0, orientation_cost=1.0, gain=0.6)
+    hold_t = cfg.get_transform_frame_to_world("joint_6") * exp6(2e-4 * rng.normal(size=6))
+    hold.set_target(hold_t)
+    problem = pink.build_ik(ref_cfg, [ft, po], dt, damping=1e-12, limits=[ConfigurationLimit(view), VelocityLimit(view)], constraints=[hold])
+    out["eq/hold_target"] = np.r_[np.asarray(hold_t.rotation).ravel(), hold_t.translation]
+    out["eq/P"], out["eq/c"], out["eq/G"], out["eq/h"], out["eq/A"], out["eq/b"] = problem.P, problem.q, problem.G, problem.h, problem.A, problem.b
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

@@ -480,3 +480,43 @@ def test_arm_stack_with_previous_step_state_against_the_references_build_ik(gold
     finally:
         pink_amd.clear_device_cache()
         set_default_solver(None)
+
+
+@pytest.mark.parametrize("where", ["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_equality_constraints_against_the_references_build_ik(golden4, where, request):
+    """pink.build_ik(..., constraints=[FrameTask]) of the reference (solve_ik.py:125-149) on the 7-joint arm: A, b of
+    pink_amd.build_ik row for row; the hybrid route (frame rows and the constraint's rows formed on the device) returns the
+    minimiser of that equality-constrained QP."""
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.lie import SE3
+    from pink_amd.limits import ConfigurationLimit, VelocityLimit
+    from pink_amd.runtime import set_default_solver
+
+    g = golden4
+    m = build_chain(7, free_flyer=False, seed=31, limit=2.2, velocity=5.0)
+    cfg, dt = Configuration(m, g["arm/q"].copy()), float(g["arm/dt"])
+    se3 = lambda v: SE3(v[:9].reshape(3, 3), v[9:])  # noqa: E731
+    ft = FrameTask("tool0", [1.0, 1.0, 2.0], 0.2, lm_damping=1e-2, gain=0.7)
+    ft.set_target(se3(g["arm/target0"]))
+    posture = PostureTask(cost=5e-2, gain=0.8)
+    posture.set_target(g["arm/q_star"])
+    hold = FrameTask("joint_6", 1.0, 1.0, gain=0.6)
+    hold.set_target(se3(g["eq/hold_target"]))
+    limits = [ConfigurationLimit(m), VelocityLimit(m)]
+    P, c, G, h, A, b = (g[f"eq/{k}"] for k in ("P", "c", "G", "h", "A", "b"))
+    set_default_solver(request.getfixturevalue("emu" if where == "emu" else "gpu_solver"))
+    try:
+        pr = pink_amd.build_ik(cfg, [ft, posture], dt, damping=1e-12, limits=limits, constraints=[hold])
+        assert np.abs(pr.P - P).max() < 1e-9 * np.abs(P).max() and np.abs(pr.q - c).max() < 1e-9 * max(1.0, np.abs(c).max())
+        assert np.abs(pr.G - G).max() < 1e-12 and np.abs(pr.h - h).max() < 1e-13
+        assert np.abs(pr.A - A).max() < 1e-9 and np.abs(pr.b - b).max() < 1e-11
+        x_ref, st, _, _ = c_oracle.gi_solve(P, c, np.vstack([A, G]), np.hstack([b, h]), meq=A.shape[0])
+        assert st == 0
+        B = 70  # (the hybrid route is the automatic choice from 64 configurations on)
+        V = solve_ik_batch(ConfigurationBatch(m, np.tile(cfg.q, (B, 1))), [ft, posture], dt, limits=limits, constraints=[hold])
+        assert pink_amd.last_solve_stats()["route"] == "hybrid"
+        assert np.abs(V[0] * dt - x_ref).max() < 1e-8 * max(1e-3, np.abs(x_ref).max()) and np.abs(V - V[0]).max() == 0.0
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
