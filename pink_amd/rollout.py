@@ -70,7 +70,7 @@ class ModelArrays:
     ``frames`` lists the frame names the rollout needs (their order is the frame index).  An entry ``(frame, root)``
     is a relative slot: the pose of ``frame`` in ``root`` (``pink/tasks/relative_frame_task.py``)."""
 
-    def __init__(self, model: Model, frames: Sequence):
+    def __init__(self, model: Model, frames: Sequence, velocity_limit: Optional[np.ndarray] = None):
         self.model = model
         self.roots = [f[1] if isinstance(f, tuple) else None for f in frames]
         self.frames = [f[0] if isinstance(f, tuple) else f for f in frames]
@@ -88,7 +88,10 @@ class ModelArrays:
                                 if fr else np.zeros((1, 12)))
         self.q_min = np.ascontiguousarray(model.lowerPositionLimit, dtype=np.float64)
         self.q_max = np.ascontiguousarray(model.upperPositionLimit, dtype=np.float64)
-        self.v_max = np.ascontiguousarray(model.velocityLimit, dtype=np.float64)
+        # (a VelocityLimit with its own vector, pink/limits/velocity_limit.py:46-58: the table the kernels read)
+        self.v_max = np.ascontiguousarray(model.velocityLimit if velocity_limit is None else velocity_limit, dtype=np.float64)
+        if self.v_max.shape != (model.nv,):
+            raise ValueError(f"velocity_limit must have shape ({model.nv},)")
         d = ModelDesc()
         d.nj, d.nq, d.nv, d.nf = len(js), model.nq, model.nv, len(fr)
         d.root_nv = get_root_joint_dim(model)[1]
@@ -156,13 +159,15 @@ class DeviceRollout:
                  config_limit_gain: float = 0.5, q_posture: Optional[np.ndarray] = None, max_iter: int = 0,
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
                  position_barriers: Sequence = (), floating_base_limit=None, const_tasks: Sequence = (),
-                 diag_tasks: Sequence = (), acceleration_limit: Optional[np.ndarray] = None):
+                 diag_tasks: Sequence = (), acceleration_limit: Optional[np.ndarray] = None,
+                 velocity_limit: Optional[np.ndarray] = None):
         """``const_tasks``: dense tasks with a constant Jacobian, ``(A [k, nv], b [k], q_0 [nq], cost, gain, lm_damping)``
         each (LinearHolonomicTask / JointCouplingTask on vector-space joints); ``diag_tasks``: identity-Jacobian tasks
         with batch-constant errors, ``(col0, e [k], cost, gain, lm_damping)`` each (DampingTask, LowAccelerationTask,
         JointVelocityTask).  ``acceleration_limit``: ``[3, nv]`` -- ``a_max`` (0: no bound on that coordinate),
         ``Delta_q_prev``, ``has_configuration_limit`` per tangent coordinate of an AccelerationLimit on the joints behind
-        the root (``pink/limits/acceleration_limit.py:158-199``), folded into the box on chip.  All three need the
+        the root (``pink/limits/acceleration_limit.py:158-199``), folded into the box on chip; ``velocity_limit``: the
+        vector of a VelocityLimit built with its own numbers (the device model then carries it).  The first three need the
         whole-step kernel (``fused="kernel"``).  The tables are the same for every robot and stay what they are over
         :meth:`run`: state that follows the previous step of each robot (``LowAccelerationTask.set_last_integration``,
         ``AccelerationLimit.set_last_integration``) is the caller's to refresh between steps
@@ -174,7 +179,7 @@ class DeviceRollout:
         self.nv, self.nq = model.nv, model.nq
         # (a frame task (frame, ...) regulates the frame in the world; ((frame, root), ...) the pose of frame in root --
         # a RelativeFrameTask, pink/tasks/relative_frame_task.py: a relative slot of the device model)
-        self.arrays = ModelArrays(model, [ft[0] for ft in frame_tasks])
+        self.arrays = ModelArrays(model, [ft[0] for ft in frame_tasks], velocity_limit=velocity_limit)
         self.frames = self.arrays.frames
         if any(r is not None for r in self.arrays.roots) and self.fused != "kernel":
             raise ValueError('relative frame tasks need the whole-step kernel: fused="kernel"')

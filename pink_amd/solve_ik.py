@@ -388,7 +388,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     lim = _default_limits_gain(model, limits)
     if lim is None:
         return None
-    gain, acc = lim
+    gain, acc, vmax = lim
     for bar in barriers or ():
         # position barriers with the default class-K function and no safe displacement of their own are formed on chip
         if (type(bar) is not PositionBarrier or not bar.identity_gain_function
@@ -399,9 +399,9 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         frames = [sp[0] for sp in plan[2] if not isinstance(sp[0], tuple)]  # (ordinary slots: a barrier needs the world pose)
         if any(bar.frame not in frames for bar in barriers):
             return None
-        plan = plan + (tuple(barriers), gain, acc)
+        plan = plan + (tuple(barriers), gain, acc, vmax)
     elif plan is not None:
-        plan = plan + ((), gain, acc)
+        plan = plan + ((), gain, acc, vmax)
     return plan
 
 
@@ -418,7 +418,7 @@ def _default_limits_gain(model, limits):
         return None
     model.ensure_limits()
     if limits is None:
-        return float(model.configuration_limit.config_limit_gain), None
+        return float(model.configuration_limit.config_limit_gain), None, None
     fb = getattr(model, "floating_base_velocity_limit", None)
     cl = [l for l in limits if type(l) is ConfigurationLimit]
     vl = [l for l in limits if type(l) is VelocityLimit]
@@ -428,8 +428,13 @@ def _default_limits_gain(model, limits):
         return None
     if rest != ([] if fb is None else [fb]):
         return None
+    # (a VelocityLimit built with its own vector -- how joints without a model limit get one, velocity_limit.py:46-58 --
+    # is the same table with other numbers: the device model of the call carries that vector instead of the model's)
+    vmax = None
     if not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
-        return None
+        vmax = np.ascontiguousarray(vl[0].velocity_limit, dtype=np.float64)
+        if any(j.kind == "free_flyer" and np.any((vmax[j.idx_v:j.idx_v + 6] < 1e20) & (vmax[j.idx_v:j.idx_v + 6] > 1e-10)) for j in model.joints):
+            return None  # (a bound on the floating base's twist coordinates: not a table entry of the kernels)
     acc = None
     if al:
         a = al[0]
@@ -438,7 +443,7 @@ def _default_limits_gain(model, limits):
         if a.projection_matrix is not None:
             acc = np.zeros((3, model.nv))  # rows: a_max (0 = no bound on the coordinate), Delta_q_prev, has_configuration_limit
             acc[0, a.indices], acc[1, a.indices], acc[2, a.indices] = a.a_max, a.Delta_q_prev, a.has_configuration_limit
-    return float(cl[0].config_limit_gain), acc
+    return float(cl[0].config_limit_gain), acc, vmax
 
 
 def _barrier_key(bar):
@@ -652,14 +657,15 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, extras, bars, limit_gain, acc = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
     fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
     fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
     key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
            int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras),
-           None if acc is None else (acc[0].tobytes(), acc[2].tobytes()))  # (the previous displacement moves per call)
+           None if acc is None else (acc[0].tobytes(), acc[2].tobytes()),  # (the previous displacement moves per call)
+           None if vmax is None else vmax.tobytes())
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     fresh = False
@@ -670,7 +676,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb,
                            const_tasks=[x[1:] for x in extras if x[0] == "const"], diag_tasks=[x[1:] for x in extras if x[0] == "diag"],
-                           acceleration_limit=acc, **kw)
+                           acceleration_limit=acc, velocity_limit=vmax, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
         ro.velocity_out = True  # (the whole-step kernel hands out dq / dt: no division over the array afterwards)
         fresh = True
@@ -699,11 +705,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, extras, bars, limit_gain, acc = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc
+    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc, vmax
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,

@@ -560,3 +560,40 @@ def test_equality_constraints_made_of_frame_tasks_on_the_hybrid_route(backend, f
             assert np.abs(V[b] - v).max() < 1e-7 * max(1.0, np.abs(v).max()), (name, b)
             for c_ in mine:  # J dq = -gain e
                 assert np.abs(c_.compute_jacobian(cfgs[b]) @ (V[b] * dt) + c_.gain * c_.compute_error(cfgs[b])).max() < 1e-9, (name, b)
+
+
+@pytest.mark.parametrize("free_flyer", [False, True])
+def test_velocity_limit_with_its_own_vector_stays_on_the_device_route(backend, free_flyer):
+    """VelocityLimit(model, velocity_limit=...) (pink/limits/velocity_limit.py:46-58: how joints without a model limit get
+    one): the device model of the call carries that vector; a joint it leaves unbounded is unbounded; same velocities as
+    the all-host evaluation and as solve_ik per configuration; the limit binds."""
+    m = build_chain(8, free_flyer=free_flyer, seed=6, limit=2.8, velocity=50.0)
+    rng = np.random.default_rng(81)
+    B, dt = 9, 5e-3
+    q = _draw_q(m, B, rng)
+    cfgs = [Configuration(m, q[b]) for b in range(B)]
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    R, t = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    for b, c in enumerate(cfgs):
+        T = c.get_transform_frame_to_world("tool0") * exp6(0.3 * rng.normal(size=6))
+        R[b], t[b] = T.rotation, T.translation
+    ft.set_target_poses(R, t)
+    po = PostureTask(cost=5e-2)
+    po.set_target(m.neutral())
+    r = 6 if free_flyer else 0
+    vec = np.r_[np.full(r, np.inf), rng.uniform(0.5, 3.0, size=8)]
+    vec[r + 3] = np.inf  # (no velocity bound on this joint)
+    limits = [ConfigurationLimit(m), VelocityLimit(m, vec)]
+    cb = ConfigurationBatch(m, q)
+    V = solve_ik_batch(cb, [ft, po], dt, limits=limits, device_kinematics=True)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    V_host = solve_ik_batch(cb, [ft, po], dt, limits=limits, device_kinematics=False, gpu_frame_tasks=False)
+    V_model = solve_ik_batch(cb, [ft, po], dt, device_kinematics=True)  # the model's own (loose) velocity limits
+    scale = max(1.0, np.abs(V_host).max())
+    assert np.abs(V - V_host).max() < 1e-8 * scale and np.abs(V - V_model).max() > 1e-2
+    assert (np.abs(V[:, r:][:, np.isfinite(vec[r:])]) <= vec[r:][np.isfinite(vec[r:])] + 1e-9).all()
+    for b in range(3):
+        own = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+        own.set_target(SE3(R[b], t[b]))
+        v = solve_ik(cfgs[b], [own, po], dt, limits=limits)
+        assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
