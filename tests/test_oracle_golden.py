@@ -128,7 +128,7 @@ def test_acceleration_limit_matches_the_reference_class(golden4, n):
     G, h = acc.compute_qp_inequalities(cfg, dt)
     assert np.array_equal(G, g[f"{n}/acc_G"]) and np.abs(h - g[f"{n}/acc_h"]).max() < 1e-15
     # the device's tables (pinkhip_rollout_step.acc_limit) carry the same box: upper bounds then lower bounds of G dq <= h
-    gain, tables = sys.modules["pink_amd.solve_ik"]._default_limits_gain(m, [ConfigurationLimit(m), VelocityLimit(m), acc])
+    gain, tables, _ = sys.modules["pink_amd.solve_ik"]._default_limits_gain(m, [ConfigurationLimit(m), VelocityLimit(m), acc])
     idx, k = acc.indices, len(acc.indices)
     a, dqp, has = tables[0, idx], tables[1, idx], tables[2, idx] != 0
     with np.errstate(invalid="ignore"):

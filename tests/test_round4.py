@@ -114,7 +114,13 @@ def test_explicit_default_limits_take_the_device_route(backend):
     V_half = solve_ik_batch(batch, [ft, po], dt, limits=[ConfigurationLimit(m, 0.5), VelocityLimit(m)])
     assert np.array_equal(V_none, V_half)
     assert np.abs(V_none - V_dev).max() > 1e-6  # (the gain matters on this batch)
-    for lim in ([ConfigurationLimit(m)], [ConfigurationLimit(m), VelocityLimit(m, np.full(m.nv, 0.7))]):
+    # a VelocityLimit with its own vector is the same table with other numbers: still the whole-step kernel
+    lim = [ConfigurationLimit(m), VelocityLimit(m, np.full(m.nv, 0.7))]
+    v_d = solve_ik_batch(batch, [ft, po], dt, limits=lim)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    v_a = solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=False)
+    assert np.abs(v_d - v_a).max() < 1e-8 * max(1.0, np.abs(v_a).max())
+    for lim in ([ConfigurationLimit(m)],):  # (a list that is not the defaults: no VelocityLimit)
         v_h = solve_ik_batch(batch, [ft, po], dt, limits=lim)
         # (not the whole-step kernel: the limits are evaluated on the host, the FrameTask rows formed on the device)
         assert pink_amd.last_solve_stats()["route"] == "hybrid"
