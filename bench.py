@@ -180,6 +180,8 @@ def kernel_ms_of(solver, dev, steps: int, stack: bool = False, repeats: int = 3)
     """Median over `repeats` of the HIP-event time of `steps` back-to-back launches (auxiliary figures only: the
     headline is timed once, over exactly K steps, in main())."""
     run = solver.stack_device if stack else solver.solve_device
+    if getattr(solver, "device_info", None) and solver.device_info().get("gcn_arch") == "cpu-emulator":
+        steps, repeats = 1, 1  # (the CPU dry runs of tests/test_bench_dryrun.py: control flow, not timing)
     run(dev)
     solver.sync()
     out = []
@@ -835,7 +837,7 @@ def main() -> None:
             # Pink's own calling pattern, batched: solve_ik_batch on Configuration objects (BASELINE config 2's shape:
             # 6-dof arm, 1 FrameTask + PostureTask, one target per instance)
             try:
-                extra["api_solve_ik_batch"] = api_level(solver, Bh=65536 if B >= 4096 else B)
+                extra["api_solve_ik_batch"] = api_level(solver, B=4096 if B >= 4096 else 64, Bh=65536 if B >= 4096 else B)  # (small: the CPU dry runs of tests/)
             except Exception as exc:  # noqa: BLE001  never lose the bench line
                 extra["api_solve_ik_batch"] = {"failed": repr(exc)}
 
