@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -604,6 +605,87 @@ def self_launch(n: int) -> int:
     return rc
 
 
+# keys of the ONE stdout line (the driver keeps a bounded tail of stdout and parses the last line: round 4's line had
+# grown to 22.6 KB and did not parse).  Everything else goes to the detail file + stderr.
+_HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data")
+_HEADLINE_LIMIT = 4096
+
+
+def _finite(x):
+    """NaN / inf have no JSON spelling: None in the emitted objects (json.dumps(allow_nan=False) then holds)."""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, np.generic):
+        return _finite(x.item())
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline_of(line: dict, detail_path) -> dict:
+    """The bounded stdout line: BASELINE.json's metric, the workload, the roofline of the dominant kernel, the CPU
+    baseline and the whole-batch parity figures -- and a pointer to the detail file."""
+    cfg = dict(_pick(line["config"], ("workload", "batch_per_gpu", "global_batch", "nv", "Kd", "K", "md", "parallelism")),
+               solver="dual active set on a register-resident sweep tableau, fp64, W lanes per QP, KKT-certified; GI kernel as fallback")
+    out = _pick(line, _HEADLINE_KEYS)
+    out["config"] = cfg
+    out["roofline"] = _pick(line["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_qp"))
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = _pick(line["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu_model", "sample"))
+        out["cpu_baseline"]["label"] = line["cpu_baseline"].get("label", "")[:100]
+    if "parity" in line:
+        out["parity"] = _pick(line["parity"], ("instances_compared", "max_abs_err", "status_mismatch", "active_set_equal_frac", "tolerance"))
+        out["parity"]["note"] = line["parity"].get("note", "")[:110]
+    if line.get("n_gpus", 1) > 1:
+        out["per_rank_kernel_ms"] = line.get("per_rank_kernel_ms")
+        g = line.get("gather") or {}
+        out["gather"] = _pick(g, ("ms", "bytes_per_rank", "rank0_shard_intact", "failed"))
+        out["gather"]["transport"] = str(g.get("transport", ""))[:48]
+        out["comm_note"] = None if line.get("comm_note") is None else str(line["comm_note"])[:160]
+    # the other bounds of the same launches and the regime a control loop runs in (kernel time only), one number each
+    also = {"fp64_frac": (line.get("roofline_fp64") or {}).get("frac"), "valu_issue_frac": (line.get("roofline_valu_issue") or {}).get("frac"),
+            "stack_only_hbm_frac": (line.get("stack_only") or {}).get("frac"),
+            "tracking_regime_kernel_ms": ((line.get("other_regimes") or {}).get("tracking_small_errors") or {}).get("kernel_ms"),
+            "failed": (line.get("solver_stats") or {}).get("failed")}
+    out["also"] = {k: v for k, v in also.items() if v is not None}
+    out["detail"] = detail_path
+    return out
+
+
+def _headline_and_detail(line: dict) -> str:
+    """Writes the full record to the detail file (+ stderr) and returns the bounded stdout line."""
+    line = _finite(line)
+    path = os.environ.get("PINK_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    full = json.dumps(line, allow_nan=False)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(full + "\n")
+        shown = os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+    except OSError as exc:  # a read-only checkout: the detail still goes to stderr
+        shown = f"stderr only ({exc.__class__.__name__})"
+    print("bench detail: " + full, file=sys.stderr, flush=True)
+    head = headline_of(line, shown)
+    text = json.dumps(head, allow_nan=False)
+    if len(text) > _HEADLINE_LIMIT:  # never again an unparseable line: drop the free-text fields first
+        head["config"]["solver"] = head["config"]["solver"][:40]
+        head["config"]["workload"] = head["config"]["workload"][:120]
+        for k in ("cpu_baseline", "parity"):
+            if k in head:
+                head[k].pop("label", None), head[k].pop("note", None), head[k].pop("sample", None)
+        text = json.dumps(head, allow_nan=False)
+    assert len(text) <= _HEADLINE_LIMIT, len(text)
+    return text
+
+
+
 _RESULT_FD = None
 
 
@@ -897,7 +979,7 @@ def main() -> None:
             base, _, _ = cpu_baseline(terms)
             line["cpu_baseline"] = base
             line["parity"] = full_parity(terms, batch, res)  # every instance of rank 0's batch
-        _emit(json.dumps(line))
+        _emit(_headline_and_detail(line))
     if abandoned:  # a thread of this process may still sit inside an RCCL call: no orderly teardown
         sys.stdout.flush()
         os._exit(0)

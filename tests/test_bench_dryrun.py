@@ -81,19 +81,48 @@ def _run(tmp_path, extra):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), PINK_BENCH_DETAIL=str(tmp_path / "detail.json"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
-    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
-    return json.loads(lines[0])
+    assert not outs[1][0].strip(), "only rank 0 prints"
+    head = _strict_headline(outs[0][0])
+    assert "bench detail: {" in outs[0][1]  # the full record also goes to stderr
+    detail = json.loads((tmp_path / "detail.json").read_text(), parse_constant=_no_constants)
+    for key in head:  # the headline is a projection of the detail record
+        if key not in ("detail", "config", "roofline", "cpu_baseline", "parity", "gather", "comm_note"):
+            assert head[key] == detail[key], key
+    return head, detail
+
+
+def _no_constants(name):
+    raise AssertionError(f"{name} in the bench output: not JSON")
+
+
+def _strict_headline(stdout: str) -> dict:
+    """What the driver does with stdout: the LAST line, strict JSON, well inside its 8 KB tail."""
+    lines = stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:3]
+    assert len(lines[0]) < 4096, len(lines[0])  # (round 4's line was 22.6 KB: the driver could not parse it)
+    head = json.loads(lines[0], parse_constant=_no_constants)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "detail"):
+        assert key in head, key
+    assert head["metric"] == "ik_qp_solves_per_s" and head["unit"] == "solves/s" and head["dtype"] == "f64"
+    assert set(head["config"]) >= {"workload", "batch_per_gpu", "global_batch", "nv", "Kd", "K", "md", "parallelism", "solver"}
+    assert "model" not in head["config"] and len(head["config"]["solver"]) <= 120
+    assert set(head["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_qp"}
+    return head
 
 
 def test_two_rank_bench_control_flow(built, tmp_path):
-    line = _run(tmp_path, [])
+    head, line = _run(tmp_path, [])
+    assert head["n_gpus"] == 2 and head["value"] == line["value"] and head["roofline"]["frac"] == line["roofline"]["frac"]
+    assert set(head["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and head["cpu_baseline"]["kind"] == "port"
+    assert head["parity"]["instances_compared"] == 6 and head["parity"]["max_abs_err"] < 1e-10 and head["parity"]["tolerance"] == 1e-8
+    assert len(head["per_rank_kernel_ms"]) == 2 and head["gather"]["rank0_shard_intact"] is True
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 12 and line["value"] > 0
     assert isinstance(line["gather"]["ms"], float) and line["gather"]["rank0_shard_intact"] is True
@@ -113,7 +142,8 @@ def test_two_rank_bench_control_flow(built, tmp_path):
 
 
 def test_two_rank_strong_scaling_splits_the_global_batch(built, tmp_path):
-    line = _run(tmp_path, ["--scaling", "strong", "--global-batch", "10", "--headline-only", "--no-cpu-baseline"])
+    line, detail = _run(tmp_path, ["--scaling", "strong", "--global-batch", "10", "--headline-only", "--no-cpu-baseline"])
+    assert "cpu_baseline" not in line and "parity" not in line and detail["gather"]["bytes_per_rank"] == 8 * 5 * 6
     assert line["scaling"] == "strong" and line["config"]["global_batch"] == 10 and line["config"]["batch_per_gpu"] == 5
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather"]["bytes_per_rank"] == 8 * 5 * 6
 
@@ -124,11 +154,10 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(built, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "extra": ["--headline-only", "--no-cpu-baseline"]})
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PINK_BENCH_DETAIL"] = str(tmp_path / "detail.json")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    line = _strict_headline(out.stdout)
     assert line["n_gpus"] == 2 and len(line["per_rank_kernel_ms"]) == 2 and line["config"]["global_batch"] == 12
 
 
