@@ -92,7 +92,7 @@ def _run(tmp_path, extra):
     assert "bench detail: {" in outs[0][1]  # the full record also goes to stderr
     detail = json.loads((tmp_path / "detail.json").read_text(), parse_constant=_no_constants)
     for key in head:  # the headline is a projection of the detail record
-        if key not in ("detail", "config", "roofline", "cpu_baseline", "parity", "gather", "comm_note"):
+        if key not in ("detail", "also", "config", "roofline", "cpu_baseline", "parity", "gather", "comm_note"):
             assert head[key] == detail[key], key
     return head, detail
 
