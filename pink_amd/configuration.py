@@ -335,15 +335,15 @@ class ConfigurationBatch:
         if q.ndim != 2 or q.shape[1] != model.nq:
             raise ValueError(f"q must have shape [B, nq = {model.nq}], got {q.shape}")
         self.model, self.q = model.ensure_limits(), q
-        self._kin = None
 
     def kinematics(self):
-        """Forward kinematics of the whole batch (:class:`pink_amd.kinematics_batch.BatchKinematics`), evaluated once."""
-        if self._kin is None:
-            from .kinematics_batch import BatchKinematics
+        """Forward kinematics of the whole batch (:class:`pink_amd.kinematics_batch.BatchKinematics`) at the CURRENT
+        ``q``, evaluated afresh by every call: ``q`` aliases the caller's array, which is refilled in place between
+        two ``solve_ik_batch`` calls (``pinned_empty``), so nothing derived from it is kept here.  The object returned
+        works on its own copy of ``q`` (one call sees one state)."""
+        from .kinematics_batch import BatchKinematics
 
-            self._kin = BatchKinematics(self.model, self.q)
-        return self._kin
+        return BatchKinematics(self.model, self.q.copy())
 
     def __len__(self) -> int:
         return self.q.shape[0]

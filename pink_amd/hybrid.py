@@ -137,6 +137,8 @@ def solve(state: HybridState, kin_q: np.ndarray, kin, slots: Sequence, frame_slo
                     equality_rows=eq)
     # the FrameTask part of the descriptor: one dense task of six rows per slot, in slot order
     fcols = [slots[k] for k in frame_slots]
+    for col in fcols:  # (gain / lm_damping are read off the first task of a slot: the same refusal as the host route)
+        be._check_slot(col)
     Kd, K = 6 * nf, 6 * nf + b0.K
     fcost = [be._costs(col, 6) for col in fcols]
     batched = b0.cost.ndim == 2 or any(np.ndim(c) == 2 for c in fcost)

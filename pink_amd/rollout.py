@@ -527,8 +527,16 @@ class DeviceRollout:
         self.steps_done = 1
         self._pipelined = res
         # Configuration.check_limits on the whole batch (pink/solve_ik.py:260), after the fact: the velocities of a
-        # batch that violates its limits are never handed out
-        self._check_limits_device(q0, safety_break)
+        # batch that violates its limits are never handed out -- the copies into a page-locked `out` are already in
+        # flight at this point, so a refusal waits for them and blanks the array before it propagates
+        try:
+            self._check_limits_device(q0, safety_break)
+        except BaseException:
+            a.sync()
+            if back:
+                out.fill(np.nan)
+            self._pipelined = None
+            raise
         return True
 
     def _one_kernel_step(self, integrate: bool = True, lo: int = 0, hi: Optional[int] = None) -> bool:

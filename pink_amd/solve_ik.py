@@ -495,8 +495,37 @@ def _extras_key(extras):
     return tuple(out)
 
 
+def _admissible_plan(plan):
+    """Last look at a task plan before the device model is built from it: what the device route's tables cannot hold is
+    declined here (``None``: the hybrid / host routes serve the call) instead of surfacing as a constructor error.
+
+    * relative slots live among the first 16 frames of a device model (``csrc/model_tables.h``);
+    * constant-row tasks share one reference configuration on chip (``pink_amd/rollout.py``): several
+      LinearHolonomicTask / JointCouplingTask objects with different ``q_0`` are brought to the first one's,
+      ``A (q - q0_i) - b_i = A (q - q0_0) - (b_i + A (q0_i - q0_0))`` (``pink/tasks/linear_holonomic_task.py:117-148``;
+      ``A`` has no entry on free-flyer coordinates, where the difference is not a subtraction)."""
+    if plan is None:
+        return None
+    model, q, specs, targets, posture, extras = plan
+    if any(isinstance(sp[0], tuple) and i >= 16 for i, sp in enumerate(specs)):
+        return None
+    const = [x for x in extras if x[0] == "const"]
+    if len(const) > 1 and any(not np.array_equal(x[3], const[0][3]) for x in const):
+        q00, out = const[0][3], []
+        for x in extras:
+            if x[0] == "const" and not np.array_equal(x[3], q00):
+                x = ("const", x[1], x[2] + x[1] @ model.difference(q00, x[3]), q00) + tuple(x[4:])
+            out.append(x)
+        extras = tuple(out)
+    return model, q, specs, targets, posture, extras
+
+
 def _device_kinematics_plan_tasks(configurations, tasks):
     """The task half of :func:`_device_kinematics_plan`: ``(model, q, specs, targets, posture, extras)`` or ``None``."""
+    return _admissible_plan(_device_kinematics_plan_tasks_raw(configurations, tasks))
+
+
+def _device_kinematics_plan_tasks_raw(configurations, tasks):
     from .configuration import ConfigurationBatch
     from .exceptions import TargetNotSet
     from .tasks.frame_task import FrameTask
@@ -696,6 +725,10 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
         api.sync()
         out = ro.last_step() + (ro.last_path, bool(getattr(ro, "scaled", False)))
     except BaseException:
+        try:
+            api.sync()  # (asynchronous copies of the failed call may still read / write the buffers released below)
+        except Exception:  # noqa: BLE001
+            pass
         ro.free()
         raise
     cache[key] = ro  # most recently used last
