@@ -808,7 +808,11 @@ def main() -> None:
     abandoned = False  # a watchdog fired: a thread may still sit in a collective -> leave through os._exit
     if world > 1:
         comm = HostComm(rdzv)
-        if hasattr(solver, "comm_unique_id"):
+        shared = world > max(_device_count(), 1)  # (PINKHIP_ALLOW_SHARED_DEVICE=1: several ranks on one device)
+        if shared:
+            comm_note = ("ranks share a device (RCCL refuses duplicate devices in one communicator): dq gathered over the TCP "
+                         "rendezvous; no N > 1 RCCL run exists on this pool (1-GPU boxes)")
+        if hasattr(solver, "comm_unique_id") and not shared:
             try:
                 barrier()
                 comm = _with_timeout(lambda: RcclComm(solver, rdzv), 60.0, "RCCL communicator")

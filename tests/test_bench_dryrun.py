@@ -168,3 +168,24 @@ def test_gpus_n_refuses_when_devices_are_missing(built, tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode != 0 and "device(s) visible" in out.stderr
 
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_real_device(built, tmp_path):
+    """The N > 1 control flow on real HIP: `bench.py --gpus 2` with both ranks on device 0 (the pool's boxes have one
+    GPU; PINKHIP_ALLOW_SHARED_DEVICE=1) -- self-launch, TCP rendezvous, two library handles on one device, barrier +
+    max-over-ranks timing, gather of dq to rank 0 (over the rendezvous: RCCL refuses duplicate devices), one bounded JSON
+    line, clean exit without the watchdog.  The closest thing to an 8-GPU dry run this pool offers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PINKHIP_ALLOW_SHARED_DEVICE="1", PINK_BENCH_DETAIL=str(tmp_path / "detail.json"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+                          "--headline-only", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _strict_headline(out.stdout)
+    detail = json.loads((tmp_path / "detail.json").read_text(), parse_constant=_no_constants)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8192 and line["value"] > 0
+    assert len(line["per_rank_kernel_ms"]) == 2 and all(ms > 0 for ms in line["per_rank_kernel_ms"])
+    assert line["gather"]["rank0_shard_intact"] is True and line["gather"]["bytes_per_rank"] == 8 * 4096 * 30
+    assert "share a device" in line["comm_note"] and "no N > 1 RCCL run" in line["comm_note"]
+    assert detail["solver_stats"]["failed"] == 0 and detail["device"].startswith("gfx")
+    assert "watchdog" not in out.stderr.lower() and "Traceback" not in out.stderr
