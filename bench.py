@@ -648,7 +648,7 @@ def headline_of(line: dict, detail_path) -> dict:
         g = line.get("gather") or {}
         out["gather"] = _pick(g, ("ms", "bytes_per_rank", "rank0_shard_intact", "failed"))
         out["gather"]["transport"] = str(g.get("transport", ""))[:48]
-        out["comm_note"] = None if line.get("comm_note") is None else str(line["comm_note"])[:160]
+        out["comm_note"] = None if line.get("comm_note") is None else str(line["comm_note"])[:220]
     # the other bounds of the same launches and the regime a control loop runs in (kernel time only), one number each
     also = {"fp64_frac": (line.get("roofline_fp64") or {}).get("frac"), "valu_issue_frac": (line.get("roofline_valu_issue") or {}).get("frac"),
             "stack_only_hbm_frac": (line.get("stack_only") or {}).get("frac"),
