@@ -46,6 +46,38 @@ def jlog6_fd(T: np.ndarray, h: float = 1e-6) -> np.ndarray:
     return J
 
 
+def jlog6_mp(T: np.ndarray, digits: int = 50) -> np.ndarray:
+    """The same derivative to ~1e-15: matrix logarithm and exponential in ``digits``-digit arithmetic (mpmath's
+    ``logm`` / ``expm``: inverse scaling and squaring, no closed form of SE(3)), central differences with a step of
+    1e-15 (truncation 1e-30).  Slow (a second per call): the generator of ``tests/golden/pink_round4.npz`` uses it so
+    that the reference's ``build_ik`` output can be held to 1e-10 (``pink/tasks/frame_task.py:217-227``)."""
+    import mpmath as mp
+
+    with mp.workdps(digits):
+        Tm = mp.matrix(np.asarray(T, dtype=float).tolist())
+        h = mp.mpf(10) ** -15
+
+        def log6m(M):
+            L = mp.logm(M)
+            return [L[0, 3], L[1, 3], L[2, 3], (L[2, 1] - L[1, 2]) / 2, (L[0, 2] - L[2, 0]) / 2, (L[1, 0] - L[0, 1]) / 2]
+
+        def exp6m(k, s):
+            X = mp.zeros(4, 4)
+            if k < 3:
+                X[k, 3] = s
+            else:
+                a, b = [(2, 1), (0, 2), (1, 0)][k - 3]
+                X[a, b], X[b, a] = s, -s
+            return mp.expm(X)
+
+        J = np.zeros((6, 6))
+        for k in range(6):
+            fp, fm = log6m(Tm * exp6m(k, h)), log6m(Tm * exp6m(k, -h))
+            for r in range(6):
+                J[r, k] = float(mp.re((fp[r] - fm[r]) / (2 * h)))
+    return J
+
+
 def frame_task_terms(T_frame: np.ndarray, T_target: np.ndarray, J_body: np.ndarray):
     """Per-instance loop; returns ``(e [B, 6], J [B, 6, nv])`` (J accurate to ~1e-8: finite differences)."""
     B = J_body.shape[0]

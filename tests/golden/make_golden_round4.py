@@ -210,8 +210,9 @@ def main():
         out[f"fb/{name}/G"], out[f"fb/{name}/h"] = G, h
     # FrameTask / RelativeFrameTask (pink/tasks/frame_task.py:148-227, relative_frame_task.py:142-231): the reference's
     # classes decide WHICH transforms are composed and with which sign; pin.log / pin.Jlog6 are stubbed with the
-    # independent SE(3) maps of oracle/se3_oracle.py (matrix logarithm through SciPy, Jacobian by central differences:
-    # 1e-8 on J) -- not with the closed forms the product uses.
+    # independent SE(3) maps of oracle/se3_oracle.py (matrix logarithm through SciPy; Jacobian by central differences of
+    # mpmath's 50-digit matrix logarithm, good to 1e-15: round 5, the second-order double-precision difference of round 4
+    # was good to 1e-8) -- not with the closed forms the product uses.
     from oracle import se3_oracle
 
     from pink.tasks import FrameTask, RelativeFrameTask
@@ -222,7 +223,7 @@ def main():
         return M
 
     pin.log = lambda T: types.SimpleNamespace(vector=se3_oracle.log6(mat(T)))
-    pin.Jlog6 = lambda T: se3_oracle.jlog6_fd(mat(T))
+    pin.Jlog6 = lambda T: se3_oracle.jlog6_mp(mat(T))
     m = build_chain(8, free_flyer=True, seed=11)
     m.add_frame("mid", m.getJointId("joint_4"), SE3(np.eye(3), [0.0, 0.05, 0.1]))
     q = m.neutral()
@@ -276,19 +277,9 @@ def main():
     # The whole stacking path at once: the reference's OWN pink.build_ik (pink/solve_ik.py:152-203) over the reference's OWN
     # FrameTask x 3, RelativeFrameTask, PostureTask, JointCouplingTask x 2, DampingTask, ConfigurationLimit, VelocityLimit,
     # AccelerationLimit, FloatingBaseVelocityLimit and PositionBarrier objects -- the stack of examples/humanoid_draco3.py and
-    # then some -- on a floating-base robot whose kinematics come from this repo's stand-in.  pin.Jlog6 by a fourth-order
-    # difference of the matrix logarithm (1e-11), so that the QP it builds can be held to 1e-9.
-    def jlog6_4th(T, h=1e-3):
-        Tm = mat(T)
-        J = np.zeros((6, 6))
-        f = lambda d: se3_oracle.log6(Tm @ se3_oracle.exp6(d))  # noqa: E731
-        for k in range(6):
-            d = np.zeros(6)
-            d[k] = h
-            J[:, k] = (-f(2 * d) + 8 * f(d) - 8 * f(-d) + f(-2 * d)) / (12 * h)
-        return J
-
-    pin.Jlog6 = jlog6_4th
+    # then some -- on a floating-base robot whose kinematics come from this repo's stand-in.  pin.Jlog6 stays the 50-digit
+    # difference of the matrix logarithm set above (1e-15; round 4 used a fourth-order double-precision difference, 1e-11,
+    # which cond(P) amplified to 1e-8 on the minimiser), so that the QP the reference builds can be held to 1e-10.
     pin.difference = lambda model, q0, q1: model.m.difference(np.asarray(q0, dtype=float), np.asarray(q1, dtype=float))
     pin.neutral = lambda model: model.m.neutral()
     pin.dDifference = lambda model, q0, q1, arg: model.m.d_difference(np.asarray(q0, dtype=float), np.asarray(q1, dtype=float))
