@@ -194,16 +194,30 @@ def kernel_ms_of(solver, dev, steps: int, stack: bool = False, repeats: int = 3)
     return statistics.median(out)
 
 
-def full_parity(terms, batch, res) -> dict:
+def full_parity(terms, batch, res, n_exact: int = 4) -> dict:
     """SURVEY.md 8(d) parity procedure over EVERY instance of the batch (oracle/parity_report.py: the C oracle on the
     host cores, the checker -- never the thing measured)."""
     from oracle.parity_report import parity_report
     from pink_amd import synthetic
 
     t0 = time.perf_counter()
+    dq_ref = np.full_like(res.dq, np.nan)
     rep = parity_report(lambda lo, hi: synthetic.pink_form(terms.slice(lo, hi)), batch, res.dq, res.status,
-                        nthreads=min(usable_cores(), 64))
+                        nthreads=min(usable_cores(), 64), dq_ref_out=dq_ref)
     rep["max_abs_dq_err_vs_oracle"] = rep["max_abs_err"]
+    # ... and both against the EXACT minimiser (50-digit KKT solve, oracle/exact_qp.py) where they differ most: what anchors
+    # the QP half in the absence of quadprog, and says which fp64 answer is nearer where dq is weakly determined
+    try:
+        from oracle.exact_qp import anchor_report
+
+        okk = (res.status == 0) & np.isfinite(dq_ref).all(axis=1)
+        t1 = time.perf_counter()
+        rep["exact_anchor"] = anchor_report(lambda lo, hi: synthetic.pink_form(terms.slice(lo, hi)), terms.damping, res.dq,
+                                            np.nan_to_num(dq_ref), n_exact, n_exact, ok=okk)
+        rep["exact_anchor"]["seconds"] = time.perf_counter() - t1
+    except Exception as exc:  # noqa: BLE001  (mpmath missing on a box: the report says so)
+        rep["exact_anchor"] = {"failed": repr(exc)}
+    del dq_ref
     # what the tasks see: the weighted rows of the dense tasks, W J (dq - dq_ref), on a sample -- the quantity that stays
     # within the tolerance where dq itself is only weakly determined (flat directions of a weakly regularised H)
     from oracle import c_oracle
@@ -643,6 +657,9 @@ def headline_of(line: dict, detail_path) -> dict:
     if "parity" in line:
         out["parity"] = _pick(line["parity"], ("instances_compared", "max_abs_err", "status_mismatch", "active_set_equal_frac", "tolerance"))
         out["parity"]["note"] = line["parity"].get("note", "")[:110]
+        ex = line["parity"].get("exact_anchor") or {}
+        if "max_abs_err_vs_exact" in ex:  # 50-digit minimiser on a sample (oracle/exact_qp.py)
+            out["parity"]["exact"] = _pick(ex, ("instances", "max_abs_err_vs_exact", "oracle_max_abs_err_vs_exact"))
     if line.get("n_gpus", 1) > 1:
         out["per_rank_kernel_ms"] = line.get("per_rank_kernel_ms")
         g = line.get("gather") or {}
@@ -982,7 +999,7 @@ def main() -> None:
         if not args.no_cpu_baseline:
             base, _, _ = cpu_baseline(terms)
             line["cpu_baseline"] = base
-            line["parity"] = full_parity(terms, batch, res)  # every instance of rank 0's batch
+            line["parity"] = full_parity(terms, batch, res, n_exact=8)  # every instance of rank 0's batch
         _emit(_headline_and_detail(line))
     if abandoned:  # a thread of this process may still sit inside an RCCL call: no orderly teardown
         sys.stdout.flush()

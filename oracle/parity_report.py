@@ -78,7 +78,7 @@ def kkt_residuals(H, c, lb, ub, dq, Gd=None, hd=None, n_eq: int = 0):
 
 
 def parity_report(pf, batch, dq: np.ndarray, status: np.ndarray, nthreads: int = 0, chunk: int = 8192,
-                  H_gpu: Optional[np.ndarray] = None) -> dict:
+                  H_gpu: Optional[np.ndarray] = None, dq_ref_out: Optional[np.ndarray] = None) -> dict:
     """Compare EVERY instance of ``(dq, status)`` with the C oracle solving ``pf`` -- the Pink-form arrays of the same
     batch (``synthetic.pink_form`` / ``tests.cases``), or a callable ``pf(lo, hi)`` that builds them for a slice
     (the Pink form of 65 536 JVRC-shaped instances is ~7 GB: every limit as dense ``[P; -P]`` rows); ``batch`` is the
@@ -98,6 +98,8 @@ def parity_report(pf, batch, dq: np.ndarray, status: np.ndarray, nthreads: int =
         ref = c_oracle.solve_ik_batch(**pfc, want_Hc=True, nthreads=nthreads, meq=n_eq)
         del pfc
         hist_ref += np.bincount(ref["status"], minlength=4)[:4]
+        if dq_ref_out is not None:  # (the caller wants the oracle's points too: oracle/exact_qp.anchor_report)
+            dq_ref_out[lo:hi] = np.where((ref["status"] == 0)[:, None], ref["dq"], np.nan)
         it_sum += int(ref["iters"].sum())
         x, st = dq[lo:hi], status[lo:hi]
         rep["status_mismatch"] += int((st != ref["status"]).sum())
