@@ -71,6 +71,82 @@ __device__ __forceinline__ double transpose_reduce(F v) {
   }
 }
 
+// The tableau row of a lane as register TUPLES (16 doubles = one 1024-bit VGPR tuple each) instead of NT independent
+// registers: entry p for a wave-uniform RUN-TIME p is then two v_mov_b32 under s_set_gpr_idx_on (the VGPR index mode of
+// gfx9: register number + M0) instead of NT broadcast-FMAs against the indicator of p.  Entries with compile-time
+// indices stay what they were: sub-registers of the tuple, updated in place by the broadcast-FMAs.
+typedef double TabVec16 __attribute__((vector_size(128)));
+template <int NT>
+struct TabRegs {
+  static constexpr int NVEC = (NT + 15) / 16;
+  static_assert(NVEC >= 1 && NVEC <= 4, "at most 64 tableau columns");
+  TabVec16 v0, v1, v2, v3;  // (named members, whole-tuple reads and writes only: they must stay SSA values)
+  template <int K>
+  __device__ __forceinline__ TabVec16 tuple() const {
+    if constexpr (K == 0) return v0;
+    else if constexpr (K == 1) return v1;
+    else if constexpr (K == 2) return v2;
+    else return v3;
+  }
+  template <int J>
+  __device__ __forceinline__ double get() const {
+    static_assert(J >= 0 && J < NT, "tableau column");
+    const TabVec16 t = tuple<J / 16>();
+    return t[J % 16];
+  }
+  template <int J>
+  __device__ __forceinline__ void set(double x) {
+    static_assert(J >= 0 && J < NT, "tableau column");
+    TabVec16 t = tuple<J / 16>();
+    t[J % 16] = x;
+    if constexpr (J / 16 == 0) v0 = t;
+    else if constexpr (J / 16 == 1) v1 = t;
+    else if constexpr (J / 16 == 2) v2 = t;
+    else v3 = t;
+  }
+  __device__ __forceinline__ void clear() {
+    const TabVec16 z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    v0 = v1 = v2 = v3 = z;
+  }
+  // entry p of this lane's row, p the same in every lane of the wave (0 <= p < 16 NVEC): every tuple is read at p % 16
+  // and a scalar condition selects (a scalar BRANCH around the reads sent the tuples to scratch memory: measured)
+  __device__ __forceinline__ double at_uniform(int p) const {
+    const int hi = p >> 4, lo = p & 15;
+    const TabVec16 t0 = v0;
+    double r = t0[lo];
+    if constexpr (NVEC > 1) {
+      const TabVec16 t1 = v1;
+      const double r1 = t1[lo];
+      r = (hi == 1) ? r1 : r;
+    }
+    if constexpr (NVEC > 2) {
+      const TabVec16 t2 = v2;
+      const double r2 = t2[lo];
+      r = (hi == 2) ? r2 : r;
+    }
+    if constexpr (NVEC > 3) {
+      const TabVec16 t3 = v3;
+      const double r3 = t3[lo];
+      r = (hi == 3) ? r3 : r;
+    }
+    return r;
+  }
+  // entry p of this lane's row for a p that is uniform over each group of W lanes (p < 0: none, 0.0)
+  template <int W>
+  __device__ __forceinline__ double at_group_uniform(int p) const {
+    constexpr int G = kWave / W;
+    static_assert(G == 1 || G == 2, "one or two reads per wave");
+    const int p0 = bcast_i(p, 0);  // v_readlane: a scalar
+    double c = at_uniform(p0 < 0 ? 0 : p0);
+    if constexpr (G == 2) {
+      const int p1 = bcast_i(p, W);
+      const double c1 = at_uniform(p1 < 0 ? 0 : p1);
+      c = (lane_id() >= W) ? c1 : c;
+    }
+    return (p >= 0) ? c : 0.0;
+  }
+};
+
 // two doubles written / read as one 16-byte LDS access
 struct alignas(16) Pair {
   double a, b;

@@ -70,6 +70,12 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #ifndef PINKHIP_STACK_DEPTH_WIDE  // (instantiations at two waves per SIMD: 256 registers)
 #define PINKHIP_STACK_DEPTH_WIDE 2
 #endif
+// Column p of the tableau (group-uniform run-time p) read with the VGPR index mode from register tuples (TabRegs,
+// ik_common.h) instead of NT broadcast-FMAs against the indicator of p: groups of 32 and 64 lanes (one or two reads per
+// wave; four groups of 16 lanes would pay as much as the FMAs they replace)
+#ifndef PINKHIP_SWEEP_INDEXED_COLUMN
+#define PINKHIP_SWEEP_INDEXED_COLUMN 1
+#endif
 #ifndef PINKHIP_SWEEP_ROUTE_COND
 #define PINKHIP_SWEEP_ROUTE_COND 1e10
 #endif
@@ -408,9 +414,35 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // in its registers.  Either lane p hands it over through LDS (NT / 2 16-byte writes by one lane, one read per lane:
   // the LDS pipe is otherwise idle and the VALU is what the kernel is short of), or every lane multiplies its row
   // with the indicator of p (NT broadcast-FMAs, no LDS round trip on the dependent chain).
+  // The unmaintained copy of the diagonal entry inside the row, T[li][li] as the pivots' generic FMAs leave it: followed in
+  // a register of its own (one FMA per pivot, the same operation on the same operands: bit-identical) -- the closing
+  // trips need it to take it out of their product with T, and picking "register li of lane li" there cost 2 NT selects
+  double sdiag_run = tdiag;
   double *rowbuf = sm + SL::oR;
+  // From here on the row lives in register tuples when the column is read by index (same registers, renamed)
+  constexpr bool IDX = PINKHIP_SWEEP_INDEXED_COLUMN && !PINKHIP_SWEEP_LDS_COLUMN && W >= 32;
+  TabRegs<IDX ? NT : 1> R;
+  R.clear();
+  if constexpr (IDX) {
+    static_for<0, NT>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      R.template set<j>(T[j]);
+    });
+  }
+  auto tget = [&](auto Jc) -> double {
+    constexpr int j = decltype(Jc)::value;
+    if constexpr (IDX) return R.template get<j>();
+    else return T[j];
+  };
+  auto tset = [&](auto Jc, double v) {
+    constexpr int j = decltype(Jc)::value;
+    if constexpr (IDX) R.template set<j>(v);
+    else T[j] = v;
+  };
   auto column_of = [&](int p) -> double {
-    if constexpr (PINKHIP_SWEEP_LDS_COLUMN) {
+    if constexpr (IDX) {
+      return R.template at_group_uniform<W>(p);
+    } else if constexpr (PINKHIP_SWEEP_LDS_COLUMN) {
       if (li == p) {
         Pair *dst = reinterpret_cast<Pair *>(__builtin_assume_aligned(rowbuf, 16));
 #pragma unroll
@@ -427,7 +459,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       double c[NC] = {};
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, T[j]);
+        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, tget(Jc));
       });
       if constexpr (NC == 4) return (c[0] + c[1]) + (c[2] + c[3]);
       else return c[0] + c[1];
@@ -507,7 +539,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
 
     // (b) column src of T: col_m = sum_j T[m][j] [j == src]; for a finishing group the product T r instead
     double col;
-    if (!PINKHIP_SWEEP_LDS_COLUMN || closing) {
+    if (!(PINKHIP_SWEEP_LDS_COLUMN || IDX) || closing) {
       BcT eb = bcast_indicator<W>(act ? src : -1);
       double rres = 0.0, sdiag = 0.0;
       bool cert_fails = false;
@@ -516,16 +548,14 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         cert_fails = group_first_lane<W>(cert_fails) < W;
         if (!ref || status != STATUS_OPTIMAL) rres = 0.0;
         // (the product below meets the unmaintained copy of the diagonal inside T: replaced by the maintained one)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          if (j == li) sdiag = T[j];
+        sdiag = sdiag_run;
         eb = bcast_select<W>(ref, bcast_prepare<W>(rres), eb);
       }
       constexpr int NC = PINKHIP_SWEEP_COLUMN_CHAINS(NT);
       double c[NC] = {};
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, T[j]);
+        c[j % NC] = fma_bcast<W, j>(c[j % NC], eb, tget(Jc));
       });
       if constexpr (NC == 4) col = (c[0] + c[1]) + (c[2] + c[3]);
       else col = c[0] + c[1];
@@ -715,8 +745,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       const double nt = -t;
       static_for<0, NT>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        T[j] = fma_bcast<W, j>(T[j], xb, nt);
+        tset(Jc, fma_bcast<W, j>(tget(Jc), xb, nt));
       });
+      sdiag_run = fma(cp, nt, sdiag_run);  // (what the broadcast-FMA above just made of this lane's register li)
       tdiag = (li == pi) ? -rp : tdiag - t * col;
     }
     PINKHIP_TICK(7);  // pivot

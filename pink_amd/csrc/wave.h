@@ -139,6 +139,10 @@ __device__ __forceinline__ void pin(T &x) {
   asm volatile("" : "+v"(x) : : "memory");
 }
 
+// A value the compiler cannot see through (no memory clobber): keeps the two arms of a scalar branch from being merged
+// into a select.  Emits no instruction.
+__device__ __forceinline__ void opaque(double &x) { asm volatile("" : "+v"(x)); }
+
 // Pin two groups of eight values at once: the sixteen loads that produce them are all issued
 // before this point and waited for once (hipcc otherwise issues the LDS reads of an accumulation
 // chain pairwise, right before their use, and every pair pays the full LDS latency).

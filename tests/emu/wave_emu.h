@@ -110,6 +110,7 @@ inline void pin16(const double (&)[8], const double (&)[8]) {}
 inline void pin8(const double (&)[4], const double (&)[4]) {}
 template <typename T>
 inline void pin(T &) {}
+inline void opaque(double &) {}
 template <class Args>
 inline const Args *kernarg_reload(const Args &a) {
   return &a;
