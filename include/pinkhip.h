@@ -341,6 +341,21 @@ typedef struct pinkhip_rollout_step {
    * (0 / 1) -- or NULL:  dq <= min(a dt^2 + dq_prev, dt sqrt(2 a (q_max - q))),  -dq <= min(a dt^2 - dq_prev,
    * dt sqrt(2 a (q - q_min))), the braking-distance terms only where the joint has a configuration limit. */
   const double *acc_limit;
+  /* Equality constraints made of frame tasks, `constraints=[FrameTask ...]` of pink.build_ik (pink/solve_ik.py:125-149:
+   * A = J, b = -gain e): the LEADING 6 n_constraint_frames rows of the desc.md dense rows (desc.n_eq of them), in front of
+   * the limit rows and the barrier rows; desc.barrier_rows offsets start at desc.n_eq + n_limit_rows.  Constraint c is the
+   * FrameTask of model frame constraint_frame[c] ([n] device; its target in T_target like any frame's; a frame that
+   * carries no task of the objective gets zero cost: pink/tasks/task.py:148-166 then adds nothing for it) with gain
+   * constraint_gain[c] ([n] device).  At most 2. */
+  int32_t n_constraint_frames;
+  const int32_t *constraint_frame;
+  const double *constraint_gain;
+  /* BodySphericalBarrier rows (pink/barriers/body_spherical_barrier.py:73-143): a barrier row d with barrier_axis[d] = 3
+   * keeps |p_f - p_f2|^2 - d_min^2 >= 0 between the origins of model frames f = barrier_frame[d] and f2 =
+   * barrier_frame2[d], with barrier_bound[d] = d_min^2 and the class's class-K function h / (1 + |h|):
+   * G_d = -2 (p_f - p_f2)^T (R J_lin,f - R J_lin,f2) / dt,  h_d = gain_d alpha(h)  (pink/barriers/barrier.py:246-254).
+   * [md - n_eq - n_limit_rows] device; may be NULL when no row has axis 3. */
+  const int32_t *barrier_frame2;
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,
                                 const pinkhip_rollout_step *args);

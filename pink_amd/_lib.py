@@ -112,6 +112,8 @@ class RolloutStep(ctypes.Structure):
         ("limit_h", ctypes.c_void_p), ("dq_scale", ctypes.c_double),
         ("n_const_rows", ctypes.c_int32), ("const_rows", ctypes.c_void_p), ("const_q0", ctypes.c_void_p), ("const_b", ctypes.c_void_p),
         ("posture_task", ctypes.c_int32), ("diag_error", ctypes.c_void_p), ("acc_limit", ctypes.c_void_p),
+        ("n_constraint_frames", ctypes.c_int32), ("constraint_frame", ctypes.c_void_p), ("constraint_gain", ctypes.c_void_p),
+        ("barrier_frame2", ctypes.c_void_p),
     ]
 
 

@@ -129,7 +129,10 @@ constexpr int max3(int a, int b, int c) { return (a > b ? a : b) > c ? (a > b ? 
 
 // World positions of the nf task frames, kept BEHIND the area the kinematics and the two solvers share: the rows of
 // position barriers are formed from them while the Goldfarb-Idnani code (hand-over) is already writing its staged rows.
-constexpr int rollout_tail_doubles(int nf) { return (3 * nf + 1) & ~1; }
+// ... and, for up to kRolloutMaxEqFrames equality constraints made of frame tasks, U / V of their frames and their six errors
+// (24 doubles each): the Goldfarb-Idnani code forms those rows too while the shared area is being overwritten.
+constexpr int kRolloutMaxEqFrames = 2;
+constexpr int rollout_tail_doubles(int nf) { return ((3 * nf + 1) & ~1) + 24 * kRolloutMaxEqFrames; }
 
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger (+ the frame positions behind it when dense rows are formed on chip).

@@ -111,7 +111,11 @@ struct TabRegs {
   // entry p of this lane's row, p the same in every lane of the wave (0 <= p < 16 NVEC): every tuple is read at p % 16
   // and a scalar condition selects (a scalar BRANCH around the reads sent the tuples to scratch memory: measured)
   __device__ __forceinline__ double at_uniform(int p) const {
-    const int hi = p >> 4, lo = p & 15;
+    const int hi = p >> 4;
+    // (the element index behind an empty asm: an index the optimiser can prove in range lets it turn "load the tuple,
+    // extract element lo" into a scalar load at a run-time address while the tuples still sit in an alloca -- which then
+    // never becomes registers: the ik_sweepx.h instantiations ended up reading their tableau from scratch memory)
+    const int lo = opaque_uniform(p & 15);
     const TabVec16 t0 = v0;
     double r = t0[lo];
     if constexpr (NVEC > 1) {

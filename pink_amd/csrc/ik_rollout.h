@@ -35,6 +35,16 @@ struct RolloutArgs {
   // tables are indexed by d - n_lim.
   int n_lim = 0;
   const double *lim_rows = nullptr, *lim_h = nullptr;
+  // Equality constraints made of frame tasks (pink/solve_ik.py:125-149: A = J, b = -gain e): the LEADING 6 n_eqf dense rows
+  // (k.n_eq of them), in front of the limit rows; constraint c is the FrameTask of model frame eq_frame[c] -- formed like
+  // any frame task's rows, which is why the frame sits in the model (with zero cost when it carries no task)
+  int n_eqf = 0;
+  const int *eq_frame = nullptr;
+  const double *eq_gain = nullptr;
+  // BodySphericalBarrier rows (pink/barriers/body_spherical_barrier.py:73-143): a barrier row with bar_axis = 3 keeps
+  // |p_f - p_f2|^2 - bound >= 0 (bound = d_min^2) with the class-K function h / (1 + |h|) of the reference's class:
+  // G = -2 (p_f - p_f2)^T (R J_lin,f - R J_lin,f2) / dt,  h = gain alpha(|p_f - p_f2|^2 - d_min^2)
+  const int *bar_frame2 = nullptr;
   // Dense tasks with a constant Jacobian (LinearHolonomicTask / JointCouplingTask on vector-space joints,
   // pink/tasks/linear_holonomic_task.py:103-148: e = A (q (-) q_0) - b, J = A): n_crow rows BEHIND the 6 nf FrameTask
   // rows of the dense block (k.Kd = 6 nf + n_crow); A [n_crow, nv], q_0 [nq], b [n_crow] in device memory
@@ -105,20 +115,62 @@ struct FkTerms {
   double inv_dt = 0.0;
   int n_lim = 0, root_sub = -1;  // constant rows of the floating-base limit; this lane's coordinate of the root joint
   const double *lim_rows = nullptr, *lim_h = nullptr;
+  // equality rows of constraint frame tasks: 24 doubles per constraint in the tail of the robot's LDS (a copy, like pfs):
+  // U (9), V (9) of the frame and its six errors
+  int n_eqr = 0;  // 6 x constraints
+  const int *eq_frame = nullptr;
+  const double *eq_gain = nullptr, *eqs = nullptr;
+  const int *bar_frame2 = nullptr;
+  // world velocity of frame f's origin per unit velocity of this lane's tangent column (zero unless an ancestor)
+  __device__ __forceinline__ void origin_velocity(int f, double (&v)[3]) const {
+    const double *pf = pfs + 3 * f;
+    const double on = (((anc >> f) & 1u) != 0) ? 1.0 : 0.0;
+    v[0] = on * (lin[0] + ang[1] * pf[2] - ang[2] * pf[1]);
+    v[1] = on * (lin[1] + ang[2] * pf[0] - ang[0] * pf[2]);
+    v[2] = on * (lin[2] + ang[0] * pf[1] - ang[1] * pf[0]);
+  }
   __device__ __forceinline__ double dense_col(int d) const {
+    if (d < n_eqr) {
+      // row i of the FrameTask Jacobian of constraint c (frame_rows(), from the tail copy of U, V)
+      const int c = d / 6, i = d - 6 * c, f = eq_frame[c];
+      const double *u = eqs + 24 * c;
+      const double sgn = (double)((int)((ancr >> f) & 1u) - (int)((anc >> f) & 1u));
+      const int r = i < 3 ? i : i - 3;
+      const double bot = u[3 * r] * ang[0] + u[3 * r + 1] * ang[1] + u[3 * r + 2] * ang[2];
+      const double top = u[3 * r] * lin[0] + u[3 * r + 1] * lin[1] + u[3 * r + 2] * lin[2] + u[9 + 3 * r] * ang[0] + u[9 + 3 * r + 1] * ang[1] +
+                         u[9 + 3 * r + 2] * ang[2];
+      return sgn * (i < 3 ? top : bot);
+    }
+    d -= n_eqr;
     if (d < n_lim) return root_sub >= 0 ? lim_rows[6 * d + root_sub] : 0.0;
     d -= n_lim;
     const int f = bar_frame[d], i = bar_axis[d];
-    const double *pf = pfs + 3 * f;
-    const double v0 = lin[0] + ang[1] * pf[2] - ang[2] * pf[1];
-    const double v1 = lin[1] + ang[2] * pf[0] - ang[0] * pf[2];
-    const double v2 = lin[2] + ang[0] * pf[1] - ang[1] * pf[0];
-    const double vi = i == 0 ? v0 : (i == 1 ? v1 : v2);
-    return (((anc >> f) & 1u) != 0) ? -bar_sign[d] * vi * inv_dt : 0.0;
+    double v[3];
+    origin_velocity(f, v);
+    if (i == 3) {  // BodySphericalBarrier: -2 (p_f - p_f2) . (v_f - v_f2) / dt
+      const int f2 = bar_frame2[d];
+      double w[3];
+      origin_velocity(f2, w);
+      const double *p1 = pfs + 3 * f, *p2 = pfs + 3 * f2;
+      return -2.0 * inv_dt * ((p1[0] - p2[0]) * (v[0] - w[0]) + (p1[1] - p2[1]) * (v[1] - w[1]) + (p1[2] - p2[2]) * (v[2] - w[2]));
+    }
+    const double vi = i == 0 ? v[0] : (i == 1 ? v[1] : v[2]);
+    return -bar_sign[d] * vi * inv_dt;
   }
   __device__ __forceinline__ double dense_h(int d) const {
+    if (d < n_eqr) {
+      const int c = d / 6;
+      return -eq_gain[c] * eqs[24 * c + 18 + (d - 6 * c)];  // b = -gain e (pink/solve_ik.py:147)
+    }
+    d -= n_eqr;
     if (d < n_lim) return lim_h[d];
     d -= n_lim;
+    if (bar_axis[d] == 3) {
+      const double *p1 = pfs + 3 * bar_frame[d], *p2 = pfs + 3 * bar_frame2[d];
+      const double dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
+      const double hb = dx * dx + dy * dy + dz * dz - bar_bound[d];
+      return bar_gain[d] * hb / (1.0 + fabs(hb));  // (barrier.py:246-254 with the class's gain function)
+    }
     return bar_gain[d] * bar_sign[d] * (pfs[3 * bar_frame[d] + bar_axis[d]] - bar_bound[d]);
   }
 };
@@ -148,6 +200,8 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
       tt.pfs = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
       tt.inv_dt = 1.0 / ra.k.dt;
       tt.n_lim = ra.n_lim, tt.lim_rows = ra.lim_rows, tt.lim_h = ra.lim_h;
+      tt.n_eqr = 6 * ra.n_eqf, tt.eq_frame = ra.eq_frame, tt.eq_gain = ra.eq_gain, tt.bar_frame2 = ra.bar_frame2;
+      tt.eqs = tt.pfs + ((3 * mm.nf + 1) & ~1);
       if (ra.n_lim > 0 && mm.root_nv == 6) {  // (the free-flyer is the first joint after the universe: columns 0 .. 5)
         const int jt = mm.dof_joint[li < mm.nv ? li : 0];
         if (li < mm.nv && mm.jtype[jt] == JOINT_FREE_FLYER) tt.root_sub = li - mm.idx_v[jt];
@@ -161,6 +215,14 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
       const ModelDev &mm = ra.fk.m;
       double *tail = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
       for (int i = li; i < 3 * mm.nf; i += W) tail[i] = sm[12 * (mm.nj + i / 3) + 9 + i % 3];
+      if (ra.n_eqf > 0) {  // (kernel argument: wave-uniform)
+        double *eqt = tail + ((3 * mm.nf + 1) & ~1);
+        const double *UVs = sm + 12 * (mm.nj + mm.nf) + ((mm.nj + 1) & ~1), *ess = sm + fk_lds_doubles(mm.nj, mm.nf);
+        for (int i = li; i < 24 * ra.n_eqf; i += W) {
+          const int c = i / 24, k = i - 24 * c, f = ra.eq_frame[c];
+          eqt[i] = k < 18 ? UVs[36 * f + k] : ess[6 * f + (k - 18)];
+        }
+      }
       wave_sync();
     }
   };

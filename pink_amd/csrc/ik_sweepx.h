@@ -245,6 +245,28 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   int nref = 0;
   double dprev = 0.0;
 
+  // From here on the row lives in register tuples when columns are read by index (ik_sweep.h, TabRegs)
+  constexpr bool IDX = PINKHIP_SWEEP_INDEXED_COLUMN && W >= 32;
+  TabRegs<IDX ? NT : 1> R;
+  R.clear();
+  if constexpr (IDX) {
+    static_for<0, NT>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      R.template set<j>(T[j]);
+    });
+  }
+  auto tget = [&](auto Jc) -> double {
+    constexpr int j = decltype(Jc)::value;
+    if constexpr (IDX) return R.template get<j>();
+    else return T[j];
+  };
+  auto tset = [&](auto Jc, double v) {
+    constexpr int j = decltype(Jc)::value;
+    if constexpr (IDX) R.template set<j>(v);
+    else T[j] = v;
+  };
+  // the stale copies of the diagonal entries inside the rows, followed in registers (ik_sweep.h)
+  double sdiag_run = tdiag, sdd_run = ddiag;
   // row m of the stated H times a vector held one entry per coordinate lane (packed triangle in LDS)
   auto hrow_times = [&](double v) -> double {
     const BcT vb = bcast_prepare<W>(v);
@@ -272,9 +294,11 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     rowsel ^= SL::RB;
     if (li == p) {
       Pair *dst = reinterpret_cast<Pair *>(__builtin_assume_aligned(rowbuf, 16));
-#pragma unroll
-      for (int d = 0; d + 1 < MD; d += 2) dst[d >> 1] = Pair{T[NV + d], T[NV + d + 1]};
-      if constexpr (MD % 2) rowbuf[MD - 1] = T[NV + MD - 1];
+      static_for<0, MD / 2>([&](auto Hc) {
+        constexpr int d = 2 * decltype(Hc)::value;
+        dst[d >> 1] = Pair{tget(std::integral_constant<int, NV + d>{}), tget(std::integral_constant<int, NV + d + 1>{})};
+      });
+      if constexpr (MD % 2) rowbuf[MD - 1] = tget(std::integral_constant<int, NV + MD - 1>{});
     }
     wave_sync();
     const double v = rowbuf[li < MD ? li : 0];
@@ -288,19 +312,29 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     // (the hand-over through LDS first: its round trip runs under the broadcast-FMAs below)
     double tr = 0.0;
     if (wave_any(pc >= 0)) tr = dense_part_of_row(pc);
-    const BcT eb = bcast_indicator<W>(pc);
-    double c0 = 0.0, c1 = 0.0, cx = 0.0, dx = 0.0;
-    static_for<0, NV>([&](auto Jc) {
-      constexpr int j = decltype(Jc)::value;
-      if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
-      else c1 = fma_bcast<W, j>(c1, eb, T[j]);
-    });
-    static_for<0, MD>([&](auto Dc) {
-      constexpr int d = decltype(Dc)::value;
-      cx = (pd == d) ? T[NV + d] : cx;
-      dx = (pd == d) ? D[d] : dx;
-    });
-    colc = (c0 + c1) + cx;
+    double dx = 0.0;
+    if constexpr (IDX) {
+      // (entry idx of this lane's row, coordinate or dense column alike: one indexed read per group)
+      colc = R.template at_group_uniform<W>(idx);
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        dx = (pd == d) ? D[d] : dx;
+      });
+    } else {
+      const BcT eb = bcast_indicator<W>(pc);
+      double c0 = 0.0, c1 = 0.0, cx = 0.0;
+      static_for<0, NV>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if constexpr (j % 2 == 0) c0 = fma_bcast<W, j>(c0, eb, T[j]);
+        else c1 = fma_bcast<W, j>(c1, eb, T[j]);
+      });
+      static_for<0, MD>([&](auto Dc) {
+        constexpr int d = decltype(Dc)::value;
+        cx = (pd == d) ? T[NV + d] : cx;
+        dx = (pd == d) ? D[d] : dx;
+      });
+      colc = (c0 + c1) + cx;
+    }
     cold = dx + tr;
   };
 
@@ -412,25 +446,19 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       const bool cert_fails = group_first_lane<W>(fails || failsd) < W;
       if (!ref || status != STATUS_OPTIMAL) r = 0.0, rd = 0.0;
       // (x_F, lambda_A) += T_BB r: the coordinate role's entry, then the dense role's
-      double sdiag = 0.0, sdd = 0.0;
-#pragma unroll
-      for (int j = 0; j < NV; ++j)
-        if (j == li) sdiag = T[j];
-#pragma unroll
-      for (int d = 0; d < MD; ++d)
-        if (d == li) sdd = D[d];
+      const double sdiag = sdiag_run, sdd = sdd_run;
       const BcT rb = bcast_prepare<W>(r), rdb = bcast_prepare<W>(rd);
       double p0 = 0.0, p1 = 0.0;
       static_for<0, NV>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        if constexpr (j % 2 == 0) p0 = fma_bcast<W, j>(p0, rb, T[j]);
-        else p1 = fma_bcast<W, j>(p1, rb, T[j]);
+        if constexpr (j % 2 == 0) p0 = fma_bcast<W, j>(p0, rb, tget(Jc));
+        else p1 = fma_bcast<W, j>(p1, rb, tget(Jc));
       });
       static_for<0, MD>([&](auto Dc) {
         constexpr int d = decltype(Dc)::value;
-        p0 = fma_bcast<W, d>(p0, rdb, T[NV + d]);
+        p0 = fma_bcast<W, d>(p0, rdb, tget(std::integral_constant<int, NV + d>{}));
       });
-      double q0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * r; });
+      double q0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return tget(std::integral_constant<int, NV + decltype(Dc)::value>{}) * r; });
       static_for<0, MD>([&](auto Dc) {
         constexpr int d = decltype(Dc)::value;
         q0 = fma_bcast<W, d>(q0, rdb, D[d]);
@@ -594,13 +622,17 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       const double nt = -t, ntd = -td;
       static_for<0, NV>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        T[j] = fma_bcast<W, j>(T[j], xb, nt);
+        tset(Jc, fma_bcast<W, j>(tget(Jc), xb, nt));
       });
       static_for<0, MD>([&](auto Dc) {
         constexpr int d = decltype(Dc)::value;
-        T[NV + d] = fma_bcast<W, d>(T[NV + d], xbd, nt);
+        constexpr std::integral_constant<int, NV + d> Jd{};
+        tset(Jd, fma_bcast<W, d>(tget(Jd), xbd, nt));
         D[d] = fma_bcast<W, d>(D[d], xbd, ntd);
       });
+      // (what the FMAs above just made of register li of this lane's row resp. of D[li]: the stale diagonal copies)
+      sdiag_run = fma(cp, nt, sdiag_run);
+      sdd_run = fma(cpd, ntd, sdd_run);
       tdiag = (li == pi && li < NV) ? -rp : tdiag - t * col;
       ddiag = (li == pi - NV) ? -rp : ddiag - td * cold;
     }

@@ -802,11 +802,14 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   const int n_crow = st->n_const_rows;
   if (n_crow < 0 || (n_crow > 0 && (!st->const_rows || !st->const_q0 || !st->const_b)))
     return fail(h, PINKHIP_E_INVALID, "n_const_rows must be >= 0 and come with const_rows / const_q0 / const_b");
-  if (desc->nv != md.nv || desc->n_eq != 0)
-    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, n_eq = 0)");
-  if (st->n_limit_rows < 0 || st->n_limit_rows > desc->md || (st->n_limit_rows > 0 && (!st->limit_rows || !st->limit_h)))
-    return fail(h, PINKHIP_E_INVALID, "n_limit_rows must lie in [0, md] and come with limit_rows / limit_h");
-  if (desc->md > st->n_limit_rows &&
+  const int n_eqf = st->n_constraint_frames;
+  if (n_eqf < 0 || n_eqf > pinkhip::kRolloutMaxEqFrames || (n_eqf > 0 && (!st->constraint_frame || !st->constraint_gain)))
+    return fail(h, PINKHIP_E_INVALID, "n_constraint_frames must lie in [0, 2] and come with constraint_frame / constraint_gain");
+  if (desc->nv != md.nv || desc->n_eq != 6 * n_eqf)
+    return fail(h, PINKHIP_E_INVALID, "descriptor does not describe this model's task stack (nv, n_eq = 6 n_constraint_frames)");
+  if (st->n_limit_rows < 0 || 6 * n_eqf + st->n_limit_rows > desc->md || (st->n_limit_rows > 0 && (!st->limit_rows || !st->limit_h)))
+    return fail(h, PINKHIP_E_INVALID, "n_limit_rows must lie in [0, md - n_eq] and come with limit_rows / limit_h");
+  if (desc->md > 6 * n_eqf + st->n_limit_rows &&
       (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain))
     return fail(h, PINKHIP_E_INVALID, "rows of position barriers need the barrier_* tables");
   if ((st->root_box || st->n_limit_rows) && md.root_nv != 6)
@@ -843,6 +846,10 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
     ra.n_lim = st->n_limit_rows;
     ra.lim_rows = st->limit_rows;
     ra.lim_h = st->limit_h;
+    ra.n_eqf = n_eqf;
+    ra.eq_frame = st->constraint_frame;
+    ra.eq_gain = st->constraint_gain;
+    ra.bar_frame2 = st->barrier_frame2;
   } else {
     pc = pinkhip::select_rollout(md.nv, md.nj, fkd, st->n_const_rows > 0 || st->diag_error != nullptr || st->acc_limit != nullptr || m->image.has_relative);
     if (pc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation fits this model");

@@ -143,6 +143,12 @@ __device__ __forceinline__ void pin(T &x) {
 // into a select.  Emits no instruction.
 __device__ __forceinline__ void opaque(double &x) { asm volatile("" : "+v"(x)); }
 
+// ... and a wave-uniform int (kept in a scalar register)
+__device__ __forceinline__ int opaque_uniform(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+
 // Pin two groups of eight values at once: the sixteen loads that produce them are all issued
 // before this point and waited for once (hipcc otherwise issues the LDS reads of an accumulation
 // chain pairwise, right before their use, and every pair pays the full LDS latency).

@@ -160,7 +160,7 @@ class DeviceRollout:
                  fused: bool = True, safety_break: bool = True, posture_lm_damping: float = 0.0,
                  position_barriers: Sequence = (), floating_base_limit=None, const_tasks: Sequence = (),
                  diag_tasks: Sequence = (), acceleration_limit: Optional[np.ndarray] = None,
-                 velocity_limit: Optional[np.ndarray] = None):
+                 velocity_limit: Optional[np.ndarray] = None, constraint_slots: Sequence = ()):
         """``const_tasks``: dense tasks with a constant Jacobian, ``(A [k, nv], b [k], q_0 [nq], cost, gain, lm_damping)``
         each (LinearHolonomicTask / JointCouplingTask on vector-space joints); ``diag_tasks``: identity-Jacobian tasks
         with batch-constant errors, ``(col0, e [k], cost, gain, lm_damping)`` each (DampingTask, LowAccelerationTask,
@@ -168,7 +168,11 @@ class DeviceRollout:
         ``Delta_q_prev``, ``has_configuration_limit`` per tangent coordinate of an AccelerationLimit on the joints behind
         the root (``pink/limits/acceleration_limit.py:158-199``), folded into the box on chip; ``velocity_limit``: the
         vector of a VelocityLimit built with its own numbers (the device model then carries it).  The first three need the
-        whole-step kernel (``fused="kernel"``).  The tables are the same for every robot and stay what they are over
+        whole-step kernel (``fused="kernel"``).  ``position_barriers`` takes PositionBarriers and BodySphericalBarriers
+        (``pink/barriers/body_spherical_barrier.py:73-143``) in Pink's order; their frames are slots of ``frame_tasks``
+        (zero costs for a frame that carries no task).  ``constraint_slots``: equality constraints made of frame tasks,
+        ``(slot, gain)`` each (``pink/solve_ik.py:125-149``: ``A = J``, ``b = -gain e`` of the FrameTask of that slot of
+        ``frame_tasks``, whose costs are zero when it is a constraint only); at most two.  The tables are the same for every robot and stay what they are over
         :meth:`run`: state that follows the previous step of each robot (``LowAccelerationTask.set_last_integration``,
         ``AccelerationLimit.set_last_integration``) is the caller's to refresh between steps
         (:meth:`set_diag_errors`, :meth:`set_acceleration_limit`) -- :func:`pink_amd.solve_ik_batch` does so per call."""
@@ -254,34 +258,54 @@ class DeviceRollout:
             if self.fused is False and self.root_box is not None:
                 raise ValueError("a floating-base velocity limit needs fused=True or fused=\"kernel\"")
         n_lim = len(self.lim_h)
-        bf, ba, bs, bb, bg, brow, bsafe = [], [], [], [], [], [n_lim], []
-        for bar in position_barriers:
+        # equality constraints made of frame tasks: the leading dense rows (six per constraint)
+        self.cons = [(int(s_), float(g_)) for s_, g_ in constraint_slots]
+        if len(self.cons) > 2 or any(s_ < 0 or s_ >= nf for s_, _ in self.cons):
+            raise ValueError("at most two constraint slots, each a slot of frame_tasks")
+        if self.cons and self.fused != "kernel":
+            raise ValueError('equality constraints need the whole-step kernel: fused="kernel"')
+        n_eq = 6 * len(self.cons)
+        self.n_eq = n_eq
+
+        def plain_slot(name, what):
             # (the frame's world pose and Jacobian: an ordinary slot -- a relative slot carries a signed ancestor table)
-            plain = [i for i, (n, r) in enumerate(zip(self.frames, self.arrays.roots)) if n == bar.frame and r is None]
+            plain = [i for i, (n, r) in enumerate(zip(self.frames, self.arrays.roots)) if n == name and r is None]
             if not plain:
-                raise ValueError(f"position barrier on frame {bar.frame!r}: the frame must carry one of the frame tasks")
+                raise ValueError(f"{what} on frame {name!r}: the frame must be a slot of frame_tasks")
+            return plain[0]
+
+        bf, ba, bs, bb, bg, bf2, brow, bsafe = [], [], [], [], [], [], [n_eq + n_lim], []
+        for bar in position_barriers:
+            if hasattr(bar, "frames"):  # BodySphericalBarrier: one row, axis 3, bound d_min^2 (class-K function h / (1 + |h|))
+                f1, f2 = (plain_slot(n, "spherical barrier") for n in bar.frames)
+                bf.append(f1), bf2.append(f2), ba.append(3), bs.append(1.0), bb.append(float(bar.d_min) ** 2)
+                bg.append(float(np.asarray(bar.gain, dtype=float).ravel()[0]))
+                brow.append(n_eq + n_lim + len(bf))
+                bsafe.append(float(bar.safe_displacement_gain))
+                continue
             if not getattr(bar, "identity_gain_function", False):
                 raise ValueError("position barriers on the device use the identity class-K function (the default)")
-            f = plain[0]
+            f = plain_slot(bar.frame, "position barrier")
             gains = np.asarray(bar.gain, dtype=float)
             k = 0
             for sign, bound in ((1.0, bar.p_min), (-1.0, bar.p_max)):
                 if bound is None:
                     continue
                 for i, idx in enumerate(bar.indices):
-                    bf.append(f), ba.append(int(idx)), bs.append(sign), bb.append(float(np.asarray(bound)[i])), bg.append(float(gains[k]))
+                    bf.append(f), bf2.append(f), ba.append(int(idx)), bs.append(sign), bb.append(float(np.asarray(bound)[i])), bg.append(float(gains[k]))
                     k += 1
-            brow.append(n_lim + len(bf))
+            brow.append(n_eq + n_lim + len(bf))
             bsafe.append(float(bar.safe_displacement_gain))
-        self.md = n_lim + len(bf)
+        self.md = n_eq + n_lim + len(bf)
         if self.md and self.fused != "kernel":
             raise ValueError('position barriers and dense floating-base limit rows need the whole-step kernel: fused="kernel"')
         self.brow = np.ascontiguousarray(brow, dtype=np.int32)
         self.bsafe = np.ascontiguousarray(bsafe if bsafe else [0.0], dtype=np.float64)
         self._bar_host = [np.ascontiguousarray(v if v else [0], dtype=t) for v, t in
-                          ((bf, np.int32), (ba, np.int32), (bs, np.float64), (bb, np.float64), (bg, np.float64))]
+                          ((bf, np.int32), (ba, np.int32), (bs, np.float64), (bb, np.float64), (bg, np.float64), (bf2, np.int32))]
+        self._n_bar_rows = len(bf)
         d = Desc()
-        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, T, self.Kd, self.K, self.md, 0
+        d.B, d.nv, d.T, d.Kd, d.K, d.md, d.n_eq = B, nv, T, self.Kd, self.K, self.md, n_eq
         d.task_rows = self.task_rows.ctypes.data_as(c_int32_p)
         d.task_kind = self.task_kind.ctypes.data_as(c_int32_p)
         d.task_col0 = self.task_col0.ctypes.data_as(c_int32_p)
@@ -320,11 +344,17 @@ class DeviceRollout:
             if arr.nbytes:
                 a.put(ptr, arr)
             self.d_lim.append(ptr)
-        if self.md > n_lim:
+        if self._n_bar_rows:
             for arr in self._bar_host:
                 ptr = a.alloc(max(arr.nbytes, 8))
                 a.put(ptr, arr)
                 self.d_bar.append(ptr)
+        self.d_cons = []
+        if self.cons:
+            for arr in (np.ascontiguousarray([s_ for s_, _ in self.cons], dtype=np.int32), np.ascontiguousarray([g_ for _, g_ in self.cons], dtype=np.float64)):
+                ptr = a.alloc(max(arr.nbytes, 8))
+                a.put(ptr, arr)
+                self.d_cons.append(ptr)
         self.qt_batched = 1  # d_qt holds [B, nq] (one posture target per robot) or [nq] (one for all)
         self.targets_per_frame = False  # d_Tt holds [B, nf, 12], or one [B, 12] array per frame
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
@@ -554,7 +584,10 @@ class DeviceRollout:
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
         if self.d_bar:
-            st.barrier_frame, st.barrier_axis, st.barrier_sign, st.barrier_bound, st.barrier_gain = self.d_bar
+            st.barrier_frame, st.barrier_axis, st.barrier_sign, st.barrier_bound, st.barrier_gain, st.barrier_frame2 = self.d_bar
+        if self.d_cons:
+            st.n_constraint_frames = len(self.cons)
+            st.constraint_frame, st.constraint_gain = self.d_cons
         if self.d_lim:
             st.root_box, st.limit_rows, st.limit_h = self.d_lim
             st.n_limit_rows = len(self.lim_h)
@@ -705,9 +738,9 @@ class DeviceRollout:
     def free(self) -> None:
         for name in self._BUFFERS:
             self.api.release(getattr(self, name, None))
-        for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []) + getattr(self, "d_extra", []):
+        for ptr in getattr(self, "d_bar", []) + getattr(self, "d_lim", []) + getattr(self, "d_extra", []) + getattr(self, "d_cons", []):
             self.api.release(ptr)
-        self.d_bar, self.d_lim, self.d_extra = [], [], []
+        self.d_bar, self.d_lim, self.d_extra, self.d_cons = [], [], [], []
         if getattr(self, "d_acc", None) is not None:
             self.api.release(self.d_acc)
             self.d_acc = None

@@ -373,16 +373,21 @@ def _spec_of(task):
 
 
 def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints):
-    """``(model, q [B, nq], frame task specs, target poses [B, nf, 12], posture)`` when the whole batch can be evaluated
-    on the device from the configurations alone -- every task a FrameTask (one target per instance allowed) or one
-    PostureTask, the model's default limits, no barriers, no equality constraints, one model -- else ``None``.
-    ``posture`` is ``None`` or ``(cost, gain, lm_damping, q_posture [B, nq] or [nq])``; the plan ends with the tuple of
-    position barriers to form on chip."""
+    """``(model, q [B, nq], frame task specs, target poses, posture, extras, barriers, limit gain, acceleration tables,
+    velocity vector, constraints)`` when the whole batch can be evaluated on the device from the configurations alone --
+    FrameTasks / RelativeFrameTasks (one target per instance allowed), one PostureTask, the table-formed tasks of
+    :func:`_extra_task`, the model's default limits (:func:`_default_limits_gain`), PositionBarriers (default class-K
+    function) and BodySphericalBarriers, equality constraints made of FrameTasks (``pink/solve_ik.py:125-149``), one model
+    -- else ``None``.  Frames that only a barrier or a constraint needs become slots of the device model with ZERO cost
+    (``pink/tasks/task.py:148-166``: nothing enters the objective for them); ``constraints`` is a tuple of
+    ``(slot, gain)``."""
     from .barriers.barrier import Barrier
+    from .barriers.body_spherical_barrier import BodySphericalBarrier
     from .barriers.position_barrier import PositionBarrier
+    from .tasks.frame_task import FrameTask
 
     B = len(configurations)
-    if B == 0 or constraints:
+    if B == 0:
         return None
     model = configurations.model if hasattr(configurations, "model") else configurations[0].model
     lim = _default_limits_gain(model, limits)
@@ -390,19 +395,64 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         return None
     gain, acc, vmax = lim
     for bar in barriers or ():
-        # position barriers with the default class-K function and no safe displacement of their own are formed on chip
-        if (type(bar) is not PositionBarrier or not bar.identity_gain_function
-                or type(bar).compute_safe_displacement is not Barrier.compute_safe_displacement):
+        # position barriers with the default class-K function and spherical barriers, neither with a safe displacement of
+        # its own, are formed on chip
+        if type(bar).compute_safe_displacement is not Barrier.compute_safe_displacement:
+            return None
+        if type(bar) is PositionBarrier:
+            if not bar.identity_gain_function:
+                return None
+        elif type(bar) is not BodySphericalBarrier or np.ndim(bar.gain) > 1 or np.size(bar.gain) != 1:
             return None
     plan = _device_kinematics_plan_tasks(configurations, tasks)
-    if plan is not None and barriers:
-        frames = [sp[0] for sp in plan[2] if not isinstance(sp[0], tuple)]  # (ordinary slots: a barrier needs the world pose)
-        if any(bar.frame not in frames for bar in barriers):
+    if plan is None:
+        return None
+    model, q, specs, T, posture, extras = plan
+    specs = list(specs)
+    as_list = isinstance(T, (list, tuple))
+    T = list(T) if as_list else T
+
+    def add_slot(spec, target):  # target [B, 12] (or broadcastable)
+        nonlocal T
+        specs.append(spec)
+        tg = np.broadcast_to(target, (B, 12))
+        if as_list:
+            T.append(tg)
+        else:
+            T = np.concatenate([T, np.ascontiguousarray(tg)[:, None, :]], axis=1)
+        return len(specs) - 1
+
+    cons = []
+    if constraints:
+        # the constraint tasks go through the same reading as the objective's tasks: FrameTasks with targets, shared or
+        # per instance; their slots carry zero cost
+        per_instance = len(constraints) == B and isinstance(constraints[0], (list, tuple))
+        flat = [t for c in constraints for t in c] if per_instance else list(constraints)
+        if not flat or any(type(t) is not FrameTask for t in flat):
             return None
-        plan = plan + (tuple(barriers), gain, acc, vmax)
-    elif plan is not None:
-        plan = plan + ((), gain, acc, vmax)
-    return plan
+        cplan = _device_kinematics_plan_tasks_raw(configurations, constraints)
+        if cplan is None or cplan[4] is not None or cplan[5]:
+            return None
+        _, _, cspecs, cT, _, _ = cplan
+        if len(cspecs) > 2:
+            return None  # (csrc/dispatch.h: kRolloutMaxEqFrames)
+        for k, sp in enumerate(cspecs):
+            tg = cT[k] if isinstance(cT, (list, tuple)) else cT[:, k]
+            slot = add_slot((sp[0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 0.0), tg)
+            cons.append((slot, float(sp[3])))
+    if barriers:
+        ident = np.array([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0, 0, 0, 0])
+        have = {sp[0] for sp in specs if not isinstance(sp[0], tuple)}  # (ordinary slots: a barrier needs the world pose)
+        for bar in barriers:
+            for f in ((bar.frame,) if type(bar) is PositionBarrier else tuple(bar.frames)):
+                if f not in have:
+                    if not any(fr.name == f for fr in getattr(model, "frames", ())):
+                        return None
+                    add_slot((f, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 0.0), ident)
+                    have.add(f)
+    if len(specs) > 32 or any(isinstance(sp[0], tuple) and i >= 16 for i, sp in enumerate(specs)):
+        return None
+    return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons)
 
 
 def _default_limits_gain(model, limits):
@@ -447,6 +497,8 @@ def _default_limits_gain(model, limits):
 
 
 def _barrier_key(bar):
+    if hasattr(bar, "frames"):  # BodySphericalBarrier
+        return ("spherical", tuple(bar.frames), float(bar.d_min), float(np.asarray(bar.gain, float).ravel()[0]), float(bar.safe_displacement_gain))
     return (bar.frame, tuple(bar.indices), None if bar.p_min is None else tuple(np.asarray(bar.p_min, float)),
             None if bar.p_max is None else tuple(np.asarray(bar.p_max, float)), tuple(np.asarray(bar.gain, float)),
             float(bar.safe_displacement_gain))
@@ -686,7 +738,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
     fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
@@ -694,7 +746,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
            int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras),
            None if acc is None else (acc[0].tobytes(), acc[2].tobytes()),  # (the previous displacement moves per call)
-           None if vmax is None else vmax.tobytes())
+           None if vmax is None else vmax.tobytes(), cons)
     cache = _rollout_cache(api)
     ro = cache.pop(key, None)
     fresh = False
@@ -704,6 +756,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
             kw = dict(posture_cost=posture[0], posture_gain=posture[1], posture_lm_damping=posture[2], q_posture=posture[3])
         ro = DeviceRollout(api, model, q, specs, dt, damping=damping, config_limit_gain=limit_gain,
                            max_iter=max_iter, fused="kernel", safety_break=safety_break, position_barriers=bars, floating_base_limit=fb,
+                           constraint_slots=cons,
                            const_tasks=[x[1:] for x in extras if x[0] == "const"], diag_tasks=[x[1:] for x in extras if x[0] == "diag"],
                            acceleration_limit=acc, velocity_limit=vmax, **kw)
         ro._cache_owner = model  # keeps id(model) of the key alive and unique
@@ -738,11 +791,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc, vmax
+    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc, vmax, cons
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,

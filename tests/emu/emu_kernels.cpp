@@ -295,6 +295,11 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   a.Kd = d->Kd;
   a.K = d->K;
   a.md = d->md;
+  a.n_eq = d->n_eq;
+  if (d->n_eq != 6 * st->n_constraint_frames || st->n_constraint_frames < 0 || st->n_constraint_frames > pinkhip::kRolloutMaxEqFrames) {
+    g_err = "n_eq = 6 n_constraint_frames, at most 2 constraint frames";
+    return PINKHIP_E_INVALID;
+  }
   a.n_barriers = d->n_barriers;
   a.n_dtasks = static_cast<int>(t.dtask_k.size());
   a.cost_batched = d->cost_is_batched;
@@ -358,6 +363,10 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
     ra.n_lim = st->n_limit_rows;
     ra.lim_rows = st->limit_rows;
     ra.lim_h = st->limit_h;
+    ra.n_eqf = st->n_constraint_frames;
+    ra.eq_frame = st->constraint_frame;
+    ra.eq_gain = st->constraint_gain;
+    ra.bar_frame2 = st->barrier_frame2;
     switch (dc.NV * 100 + dc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \

@@ -111,6 +111,7 @@ inline void pin8(const double (&)[4], const double (&)[4]) {}
 template <typename T>
 inline void pin(T &) {}
 inline void opaque(double &) {}
+inline int opaque_uniform(int x) { return x; }
 template <class Args>
 inline const Args *kernarg_reload(const Args &a) {
   return &a;

@@ -483,13 +483,15 @@ def test_solve_ik_batch_device_kinematics_equals_host_path(backend):
     bar = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
     V_bar = solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=True)
     assert np.abs(V_bar - solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[bar], device_kinematics=False, gpu_frame_tasks=False)).max() < 1e-8
-    # ... not eligible: a barrier with its own class-K function, or on a frame that carries no task
+    # ... so does one on a frame that carries no task (round 5: a zero-cost slot of the device model) ...
+    other = PositionBarrier("joint_2", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
+    V_other = solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[other], device_kinematics=True)
+    assert np.abs(V_other - solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[other], device_kinematics=False, gpu_frame_tasks=False)).max() < 1e-8
+    # ... not eligible: a barrier with its own class-K function
     odd = PositionBarrier("tool0", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
     odd.gain_function, odd.identity_gain_function = (lambda h: 2.0 * h), False
-    other = PositionBarrier("joint_2", indices=[1], p_max=np.array([10.0]), gain=np.array([100.0]))
-    for b_ in (odd, other):
-        with pytest.raises(pink_amd.PinkError):
-            solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[b_], device_kinematics=True)
+    with pytest.raises(pink_amd.PinkError):
+        solve_ik_batch(cfgs, per_instance, 5e-3, barriers=[odd], device_kinematics=True)
 
 
 def test_solve_ik_batch_on_arrays_equals_the_list_of_configurations(backend):

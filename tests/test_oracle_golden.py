@@ -485,8 +485,9 @@ def test_arm_stack_with_previous_step_state_against_the_references_build_ik(gold
 @pytest.mark.parametrize("where", ["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def test_equality_constraints_against_the_references_build_ik(golden4, where, request):
     """pink.build_ik(..., constraints=[FrameTask]) of the reference (solve_ik.py:125-149) on the 7-joint arm: A, b of
-    pink_amd.build_ik row for row; the hybrid route (frame rows and the constraint's rows formed on the device) returns the
-    minimiser of that equality-constrained QP."""
+    pink_amd.build_ik row for row; the hybrid route (frame rows and the constraint's rows formed on the device) and the
+    device route (the whole-step kernel: the constraint's rows are its leading equality rows) return the minimiser of that
+    equality-constrained QP."""
     import pink_amd
     from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
     from pink_amd.lie import SE3
@@ -513,9 +514,14 @@ def test_equality_constraints_against_the_references_build_ik(golden4, where, re
         assert np.abs(pr.A - A).max() < 1e-13 and np.abs(pr.b - b).max() < 1e-13
         x_ref, st, _, _ = c_oracle.gi_solve(P, c, np.vstack([A, G]), np.hstack([b, h]), meq=A.shape[0])
         assert st == 0
-        B = 70  # (the hybrid route is the automatic choice from 64 configurations on)
-        V = solve_ik_batch(ConfigurationBatch(m, np.tile(cfg.q, (B, 1))), [ft, posture], dt, limits=limits, constraints=[hold])
+        B = 70  # (from 64 configurations on the device routes are the automatic choice)
+        cb = ConfigurationBatch(m, np.tile(cfg.q, (B, 1)))
+        V = solve_ik_batch(cb, [ft, posture], dt, limits=limits, constraints=[hold], device_kinematics="frame_rows")
         assert pink_amd.last_solve_stats()["route"] == "hybrid"
+        assert np.abs(V[0] * dt - x_ref).max() < 1e-10 * max(1e-3, np.abs(x_ref).max()) and np.abs(V - V[0]).max() == 0.0
+        # round 5: the whole-step kernel forms the constraint's rows on chip as its leading equality rows
+        V = solve_ik_batch(cb, [ft, posture], dt, limits=limits, constraints=[hold])
+        assert pink_amd.last_solve_stats()["route"] == "device"
         assert np.abs(V[0] * dt - x_ref).max() < 1e-10 * max(1e-3, np.abs(x_ref).max()) and np.abs(V - V[0]).max() == 0.0
     finally:
         pink_amd.clear_device_cache()

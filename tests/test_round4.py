@@ -459,10 +459,13 @@ def test_relative_frame_tasks_are_formed_on_the_device(backend, free_flyer):
     for b in range(B):
         v = solve_ik(cfgs[b], per[b], dt)
         assert np.abs(V[b] - v).max() < 1e-8 * max(1.0, np.abs(v).max()), b
-    # a position barrier needs the world pose of its frame: an ordinary slot has to carry it
+    # a position barrier needs the world pose of its frame: round 5 gives a frame that only a relative slot carries an
+    # ordinary slot of its own, with zero cost (round 4 refused the device route here)
     bar = PositionBarrier("joint_8", indices=[2], p_max=np.array([10.0]), gain=np.array([50.0]), safe_displacement_gain=1.0)
-    with pytest.raises(pink_amd.PinkError):
-        solve_ik_batch(cb, [ft, r1, po], dt, barriers=[bar], device_kinematics=True)
+    V_bar = solve_ik_batch(cb, [ft, r1, po], dt, barriers=[bar], device_kinematics=True)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    V_bar_host = solve_ik_batch(cb, [ft, r1, po], dt, barriers=[bar], device_kinematics=False, gpu_frame_tasks=False)
+    assert np.abs(V_bar - V_bar_host).max() < 1e-8 * max(1.0, np.abs(V_bar_host).max())
 
 
 @pytest.mark.parametrize("free_flyer", [False, True])
@@ -550,8 +553,12 @@ def test_equality_constraints_made_of_frame_tasks_on_the_hybrid_route(backend, f
             per.append([hb, rb])
         stacks.append(("frame + relative", per))
     for name, cons in stacks:
-        V = solve_ik_batch(cb, [ft, po], dt, constraints=cons)
+        V = solve_ik_batch(cb, [ft, po], dt, constraints=cons, device_kinematics="frame_rows")
         assert pink_amd.last_solve_stats()["route"] == "hybrid", name
+        # (round 5: constraints made of FrameTasks alone are the leading equality rows of the whole-step kernel)
+        V_auto = solve_ik_batch(cb, [ft, po], dt, constraints=cons)
+        assert pink_amd.last_solve_stats()["route"] == ("device" if name == "one" else "hybrid"), name
+        assert np.abs(V_auto - V).max() < 1e-8 * max(1.0, np.abs(V).max()), name
         V_host = solve_ik_batch(cb, [ft, po], dt, constraints=cons, device_kinematics=False, gpu_frame_tasks=False)
         assert pink_amd.last_solve_stats()["route"] == "host-evaluated", name
         scale = max(1.0, np.abs(V_host).max())
