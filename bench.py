@@ -337,6 +337,10 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
         # (pink_amd/hybrid.py: the route of stacks the kernel does not form) and with everything evaluated on the host
         out["reference_example_stack"] = api_level_arrays(Bh, extra_task="couplings")
         out["headline_shape_plus_damping_task"] = api_level_arrays(Bh, extra_task="damping")
+        # round 5: build_ik's remaining arguments on the whole-step kernel -- constraints=[FrameTask] (its leading equality
+        # rows) and a BodySphericalBarrier next to a PositionBarrier (rows formed on chip); round 4: hybrid / host routes
+        out["headline_shape_plus_equality_constraint"] = api_level_arrays(Bh, extra_task="constraint")
+        out["headline_shape_plus_spherical_and_position_barrier"] = api_level_arrays(Bh, extra_task="barriers")
         out["headline_shape_plus_damping_task_frame_rows_only"] = api_level_arrays(Bh, extra_task="damping", route="frame_rows")
         out["headline_shape_plus_damping_task_all_host"] = api_level_arrays(Bh, extra_task="damping", route=False)
         return out
@@ -442,14 +446,30 @@ def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=N
     v_out = alloc((B, m.nv)) if pinned else None
     all_host = route is False
     route_kw = {} if route is None else dict(device_kinematics=route)  # (False: every task evaluated on the host, for comparison)
+    if extra_task == "constraint":  # pink/solve_ik.py:125-149: one frame held strictly where it is (six equality rows)
+        hold = FrameTask("joint_12", 1.0, 1.0, gain=0.5)
+        Th = ref.get_transform_frame_to_world("joint_12")
+        hold.set_target(Th)
+        q[:] = q[0]  # (every robot at the reference configuration: the constraint is within reach of one step everywhere)
+        route_kw["constraints"] = [hold]
+    elif extra_task == "barriers":
+        from pink_amd.barriers import BodySphericalBarrier, PositionBarrier
+
+        p_tool = ref.get_transform_frame_to_world("tool0").translation
+        d = float(np.linalg.norm(p_tool - ref.get_transform_frame_to_world("joint_4").translation))
+        q[:] = q[0]
+        route_kw["barriers"] = [BodySphericalBarrier(("tool0", "joint_4"), d_min=0.98 * d, gain=10.0),
+                                PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[2] + 0.01]), gain=np.array([50.0]), safe_displacement_gain=1.0)]
     v = solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw)  # builds the device state
     stats = pink_amd.last_solve_stats()
     ts = _timed(lambda: solve_ik_batch(cfgs, tasks, dt, out=v_out, **route_kw), 5 if not all_host else 2)
     t_call = statistics.median(ts)
     n = min(B, 16)
-    v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False)
+    host_kw = {k: v_ for k, v_ in route_kw.items() if k != "device_kinematics"}
+    v_host = solve_ik_batch(cfgs[:n], [_slice_task(t, n) for t in tasks], dt, device_kinematics=False, gpu_frame_tasks=False, **host_kw)
     return {"workload": f"floating base + 24 joints (nv = {m.nv}), {len(frames)} FrameTasks + PostureTask" +
-                        {"": "", "damping": " + DampingTask", "couplings": " + 2 JointCouplingTasks"}[extra_task] +
+                        {"": "", "damping": " + DampingTask", "couplings": " + 2 JointCouplingTasks", "constraint": " + constraints=[FrameTask]",
+                         "barriers": " + BodySphericalBarrier + PositionBarrier"}[extra_task] +
                         f", default limits, B = {B} as ConfigurationBatch, targets as arrays",
             "route": stats.get("route"), "solver_paths": stats.get("paths"),
             "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,
