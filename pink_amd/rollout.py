@@ -355,6 +355,7 @@ class DeviceRollout:
                 ptr = a.alloc(max(arr.nbytes, 8))
                 a.put(ptr, arr)
                 self.d_cons.append(ptr)
+        self._resident = {}  # frame slot -> token of the frozen target array d_Tt holds for it (FrameTask.freeze_targets)
         self.qt_batched = 1  # d_qt holds [B, nq] (one posture target per robot) or [nq] (one for all)
         self.targets_per_frame = False  # d_Tt holds [B, nf, 12], or one [B, 12] array per frame
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
@@ -435,15 +436,22 @@ class DeviceRollout:
             if len(targets) != nf:
                 raise ValueError(f"{nf} frame tasks, {len(targets)} target arrays")
             if self.fused == "kernel":
+                if not self.targets_per_frame:
+                    self._resident = {}
                 for f, t in enumerate(targets):
+                    tok = getattr(t, "frozen_token", None)  # (FrameTask.freeze_targets: uploaded once per device state)
+                    if tok is not None and self._resident.get(f) == tok:
+                        continue
                     t = np.ascontiguousarray(np.broadcast_to(t, (self.B, 12)), dtype=np.float64)
                     self.api.put(self.d_Tt + 8 * 12 * self.B * f, t)
+                    self._resident[f] = tok
                 self.targets_per_frame = True
                 return
             targets = np.stack([np.broadcast_to(t, (self.B, 12)) for t in targets], axis=1)
         t = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.B, nf, 12)
         self.api.put(self.d_Tt, t)
         self.targets_per_frame = False
+        self._resident = {}
 
     def step(self, integrate: bool = True) -> None:
         """Enqueue one IK step for every robot (asynchronous).  ``integrate=False`` only solves (dq, status and
@@ -516,7 +524,11 @@ class DeviceRollout:
         q0 = np.ascontiguousarray(q0, dtype=np.float64)
         if q0.shape != (B, nq):
             raise ValueError(f"q0 must have shape {(B, nq)}, got {q0.shape}")
-        tg = [np.ascontiguousarray(np.broadcast_to(t, (B, 12)), dtype=np.float64) for t in targets]
+        toks = [getattr(t, "frozen_token", None) for t in targets]  # (FrameTask.freeze_targets)
+        if not self.targets_per_frame:
+            self._resident = {}
+        skip = [tok is not None and self._resident.get(f) == tok for f, tok in enumerate(toks)]
+        tg = [None if skip[f] else np.ascontiguousarray(np.broadcast_to(t, (B, 12)), dtype=np.float64) for f, t in enumerate(targets)]
         if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
             raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
         if self.n_post:  # (the first kernel waits for the copy stream: wait_copies below)
@@ -541,7 +553,8 @@ class DeviceRollout:
             lo, hi = int(cuts[c]), int(cuts[c + 1])
             put(self.d_q + 8 * nq * lo, q0[lo:hi])
             for f, t in enumerate(tg):
-                put(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
+                if t is not None:
+                    put(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
             if asyn:
                 a.wait_copies()
             if not self._one_kernel_step(False, lo, hi):
@@ -556,6 +569,8 @@ class DeviceRollout:
                 a.get_async(res[2][lo:hi], self.d_iters + 4 * lo)
         self.steps_done = 1
         self._pipelined = res
+        self._resident = dict(enumerate(toks))
+        self.bytes_in_last_call = int(q0.nbytes + sum(t.nbytes for t in tg if t is not None))
         # Configuration.check_limits on the whole batch (pink/solve_ik.py:260), after the fact: the velocities of a
         # batch that violates its limits are never handed out -- the copies into a page-locked `out` are already in
         # flight at this point, so a refusal waits for them and blanks the array before it propagates
@@ -583,6 +598,12 @@ class DeviceRollout:
         self._extra(st)
         if self.targets_per_frame:
             st.sT_b, st.sT_f = 12, 12 * self.B
+        self._dense_tables(st)
+        return self.api.rollout_step(self.desc, self.dmodel, st)
+
+    def _dense_tables(self, st) -> None:
+        """The batch-constant tables behind the dense rows the kernel forms on chip: barriers, constraint slots, the
+        floating-base limit (box on the root coordinates + constant rows)."""
         if self.d_bar:
             st.barrier_frame, st.barrier_axis, st.barrier_sign, st.barrier_bound, st.barrier_gain, st.barrier_frame2 = self.d_bar
         if self.d_cons:
@@ -591,7 +612,6 @@ class DeviceRollout:
         if self.d_lim:
             st.root_box, st.limit_rows, st.limit_h = self.d_lim
             st.n_limit_rows = len(self.lim_h)
-        return self.api.rollout_step(self.desc, self.dmodel, st)
 
     def set_diag_errors(self, errors: Sequence[np.ndarray]) -> None:
         """New batch-constant errors of the extra diagonal tasks (``diag_tasks`` of the constructor, in that order): a
@@ -636,8 +656,8 @@ class DeviceRollout:
     def _one_kernel_step_range(self, integrate: bool, lo: int, hi: int) -> bool:
         """The whole-step kernel on the robots ``lo .. hi`` of the resident batch (per-frame target arrays)."""
         nf, nv, nq = len(self.frames), self.nv, self.nq
-        if not self.targets_per_frame or self.md:
-            raise ValueError("ranges of the batch are launched over per-frame target arrays, without dense rows")
+        if not self.targets_per_frame:
+            raise ValueError("ranges of the batch are launched over per-frame target arrays")
         st = RolloutStep()
         st.q, st.cost = self.d_q + 8 * nq * lo, self.d_cost
         st.T_target, st.T_frames = self.d_Tt + 8 * 12 * lo, self.d_T + 8 * 12 * max(nf, 1) * lo
@@ -649,8 +669,7 @@ class DeviceRollout:
         self._scale_out(st, integrate)
         self._extra(st)
         st.sT_b, st.sT_f = 12, 12 * self.B
-        if self.d_lim:
-            st.root_box = self.d_lim[0]
+        self._dense_tables(st)  # (round 5: ranges of a batch with dense rows too -- the tables are the same for every robot)
         self.desc.B = hi - lo
         try:
             return self.api.rollout_step(self.desc, self.dmodel, st)

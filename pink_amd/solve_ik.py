@@ -769,8 +769,7 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
             ro.set_acceleration_limit(acc)
         # large batches with one target array per frame task: uploads of one range overlap the kernel of the previous
         qp = None if posture is None else posture[3]
-        if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and not bars and ro.md == 0
-                and ro.solve_pipelined(q, T, qp, safety_break, out=out)):
+        if not (B >= _PIPELINE_MIN_B and isinstance(T, (list, tuple)) and ro.solve_pipelined(q, T, qp, safety_break, out=out)):
             if not fresh:
                 ro.reset(q, qp, safety_break)
             ro.set_targets(T)

@@ -11,6 +11,18 @@ from ..lie import SE3, Jlog6, log6
 from .task import Task
 
 
+import itertools
+
+_FREEZE_TOKENS = itertools.count(1)
+
+
+class FrozenTargets(np.ndarray):
+    """A ``[B, 12]`` target array its owner promised not to modify (:meth:`FrameTask.freeze_targets`): read-only, and
+    carrying a token by which a device state recognises what it already holds."""
+
+    frozen_token: Optional[int] = None
+
+
 class FrameTask(Task):
     """6-D pose task; cost is ``[position x3, orientation x3]`` (``frame_task.py:44-127``)."""
 
@@ -71,6 +83,21 @@ class FrameTask(Task):
         out[:, 9:] = t
         self.target_poses = out
         self.transform_target_to_world = None  # (replaces a single target set earlier)
+
+    def freeze_targets(self) -> None:
+        """Declare the per-instance targets set by :meth:`set_target_poses` unchanged until the next ``set_target*`` call:
+        the array becomes read-only and :func:`pink_amd.solve_ik_batch` uploads it to a device ONCE per cached device state
+        instead of with every call (6.3 MB per frame task at B = 65 536: three fifths of what a call at the headline
+        shape sends across PCIe are targets).  Without it every call uploads the array as it is then -- a control loop
+        may refill it in place between two calls."""
+        if self.target_poses is None:
+            raise TargetNotSet(f"no per-instance targets set for frame '{self.frame}'")
+        arr = self.target_poses
+        if getattr(arr, "frozen_token", None) is None:
+            arr.flags.writeable = False
+            arr = arr.view(FrozenTargets)
+            arr.frozen_token = next(_FREEZE_TOKENS)
+            self.target_poses = arr
 
     def compute_error(self, configuration) -> np.ndarray:
         """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``

@@ -645,6 +645,28 @@ def test_solve_ik_batch_pipelined_ranges_equal_the_single_launch(backend, monkey
             assert np.array_equal(V_pipe, V_one) and np.abs(V_one).max() > 1e-3
         assert len(calls) == 2
         calls.clear()
+    # round 5: ranges of a batch WITH dense rows (barrier rows and an equality constraint formed on chip): the tables
+    # behind them are the same for every robot
+    from pink_amd.barriers import BodySphericalBarrier
+
+    p_tool = np.array([Configuration(m, q[b]).get_transform_frame_to_world("tool0").translation for b in range(B)])
+    bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[:, 2].max() + 0.01]), gain=np.array([50.0]), safe_displacement_gain=1.0),
+            BodySphericalBarrier(("tool0", "joint_2"), d_min=0.01, gain=10.0)]
+    hold = FrameTask("joint_8", 1.0, 1.0, gain=0.5)
+    Rh, th = np.zeros((B, 3, 3)), np.zeros((B, 3))
+    for b in range(B):
+        T = Configuration(m, q[b]).get_transform_frame_to_world("joint_8")
+        Rh[b], th[b] = T.rotation, T.translation + 1e-4 * rng.normal(size=3)
+    hold.set_target_poses(Rh, th)
+    for kw in (dict(barriers=bars), dict(constraints=[hold])):
+        pink_amd.clear_device_cache()
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 1 << 30)
+        V_one = solve_ik_batch(ConfigurationBatch(m, q), tasks + [post], 5e-3, device_kinematics=True, **kw)
+        assert not calls
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 4)
+        V_pipe = solve_ik_batch(ConfigurationBatch(m, q), tasks + [post], 5e-3, device_kinematics=True, **kw)
+        assert len(calls) == 1 and np.array_equal(V_pipe, V_one) and np.abs(V_one).max() > 1e-3
+        calls.clear()
     q_bad = q.copy()
     q_bad[9, 7 + 2] = 9.0
     with pytest.raises(NotWithinConfigurationLimits):

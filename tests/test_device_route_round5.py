@@ -24,8 +24,8 @@ def backend(request):
     set_default_solver(None)
 
 
-def _stack(free_flyer, seed, B=66):
-    m = build_chain(8, free_flyer=free_flyer, seed=7, limit=2.6, velocity=4.0)
+def _stack(free_flyer, seed, B=66, joints=8):
+    m = build_chain(joints, free_flyer=free_flyer, seed=7, limit=2.6, velocity=4.0)
     rng = np.random.default_rng(seed)
     q = _draw_q(m, B, rng)
     cfgs = [Configuration(m, q[b]) for b in range(B)]
@@ -145,3 +145,39 @@ def test_inconsistent_equality_constraints_are_reported_per_instance(backend):
     with pytest.raises(NoSolutionFound) as host:
         solve_ik_batch(ConfigurationBatch(m, q), [ft, po], dt, constraints=[hold], device_kinematics=False, gpu_frame_tasks=False)
     assert list(dev.value.indices) == list(host.value.indices) == list(range(1, 64, 2))
+
+
+def test_frozen_targets_are_uploaded_once_and_new_targets_replace_them(backend):
+    """FrameTask.freeze_targets: the per-instance target array becomes read-only and the cached device state keeps its
+    copy across calls (nothing but q goes up); set_target_poses afterwards is seen by the next call; an array that was
+    NOT frozen may be refilled in place between two calls and the second call sees the new numbers."""
+    dt = 5e-3
+    m, rng, q, cfgs, ft, po, R, t = _stack(False, 11, B=64, joints=14)  # (14 joints: the whole-step kernel serves the call)
+    cb = ConfigurationBatch(m, q)
+    V0 = solve_ik_batch(cb, [ft, po], dt).copy()
+    # refilled in place, not frozen: the next call uploads what the array holds then
+    ft.target_poses[:, 9:] += 0.01
+    V1 = solve_ik_batch(cb, [ft, po], dt).copy()
+    assert np.abs(V1 - V0).max() > 1e-3
+    ft.freeze_targets()
+    assert not ft.target_poses.flags.writeable
+    with pytest.raises(ValueError):
+        ft.target_poses[0, 9] = 0.0
+    V2 = solve_ik_batch(cb, [ft, po], dt).copy()
+    assert np.array_equal(V2, V1)
+    puts = []
+    api = pink_amd.runtime.default_solver()
+    orig = type(api).put
+    try:
+        type(api).put = lambda self, ptr, arr: (puts.append(np.asarray(arr).nbytes), orig(self, ptr, arr))[1]
+        V3 = solve_ik_batch(cb, [ft, po], dt).copy()
+    finally:
+        type(api).put = orig
+    assert np.array_equal(V3, V1)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    assert 64 * 12 * 8 not in puts, puts  # (the frozen [64, 12] target array did not go up again)
+    # new targets: a fresh (writeable, unfrozen) array replaces the frozen one
+    ft.set_target_poses(R, t + 0.02)
+    V4 = solve_ik_batch(cb, [ft, po], dt)
+    ref = solve_ik(cfgs[3], [_own_frame_task(R, t + 0.02, 3), po], dt)
+    assert np.abs(V4[3] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()) and np.abs(V4 - V1).max() > 1e-3
