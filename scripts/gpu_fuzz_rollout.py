@@ -2,7 +2,8 @@
 """One-off fuzz of the device-resident path on the GPU box: random kinematic chains (fixed and floating base), random
 configurations and FrameTask targets, optionally a PositionBarrier and a FloatingBaseVelocityLimit, and (FUZZ_EXTRAS=1)
 the tasks the kernel forms from tables since round 4: RelativeFrameTasks, JointCouplingTasks, DampingTask,
-LowAccelerationTask, JointVelocityTask -- the whole-step kernel
+LowAccelerationTask, JointVelocityTask -- and (FUZZ_EXTRAS=2) round 5's rows: BodySphericalBarriers, barriers on frames without a
+task, constraints=[FrameTask] -- the whole-step kernel
 (solve_ik_batch(device_kinematics=True): kinematics, rows, limits, QP on chip) against the host-evaluated path (tasks,
 limits and barriers evaluated per configuration in NumPy as Pink does, only the QP on the device).
    python scripts/gpu_fuzz_rollout.py [first] [count]        (FUZZ_EMU=1: on the CPU wave emulator of tests/emu)"""
@@ -19,6 +20,13 @@ from pink_amd import Configuration, FrameTask, PostureTask, build_chain, solve_i
 from pink_amd.barriers import PositionBarrier  # noqa: E402
 from pink_amd.lie import SE3, exp6  # noqa: E402
 from pink_amd.limits import FloatingBaseVelocityLimit  # noqa: E402
+
+
+def _kw_of(kw, b):
+    """The keyword arguments of instance b (per-instance constraint lists)."""
+    if kw.get("constraints") is None:
+        return kw
+    return dict(kw, constraints=kw["constraints"][b])
 
 
 def one(sd):
@@ -101,7 +109,38 @@ def one(sd):
         bars.append(PositionBarrier(frames[0], indices=[2], p_max=np.array([p0[:, 2].max() + float(rng.uniform(0.0, 0.05))]),
                                     gain=np.array([float(rng.uniform(5.0, 100.0))]),
                                     safe_displacement_gain=float(rng.choice([0.0, 1.0]))))
+    cons = None
+    if os.environ.get("FUZZ_EXTRAS") == "2":
+        # round 5 (a fourth stream): BodySphericalBarriers, a PositionBarrier on a frame without a task, constraints=[FrameTask]
+        # with per-instance targets within reach of one step -- rows the whole-step kernel forms on chip
+        from pink_amd.barriers import BodySphericalBarrier
+
+        r4 = np.random.default_rng(sd + 3 * 10 ** 9)
+        names = [f"joint_{k}" for k in range(1, n + 1)] + ["tool0"]
+        if n >= 4 and r4.random() < 0.5:
+            f1, f2 = (str(v) for v in r4.choice(names, size=2, replace=False))
+            d = np.array([np.linalg.norm(c.get_transform_frame_to_world(f1).translation - c.get_transform_frame_to_world(f2).translation) for c in cfgs])
+            if d.min() > 1e-3:
+                bars.append(BodySphericalBarrier((f1, f2), d_min=float(d.min() * r4.uniform(0.5, 0.999)), gain=float(r4.uniform(1.0, 50.0)),
+                                                 safe_displacement_gain=float(r4.choice([0.0, 1.0, 3.0]))))
+        if r4.random() < 0.3:
+            f = str(r4.choice(names))
+            p0 = np.array([c.get_transform_frame_to_world(f).translation for c in cfgs])
+            ax = int(r4.integers(0, 3))
+            bars.append(PositionBarrier(f, indices=[ax], p_min=np.array([p0[:, ax].min() - float(r4.uniform(0.0, 0.05))]),
+                                        gain=np.array([float(r4.uniform(5.0, 100.0))]), safe_displacement_gain=float(r4.choice([0.0, 1.0]))))
+        if r4.random() < 0.4:
+            k = int(r4.integers(max(1, n - 2), n + 1))  # a frame far down the chain: (almost) all joints upstream
+            if k + (6 if ff else 0) >= 7:  # six equations need six coordinates upstream
+                f, g_ = f"joint_{k}", float(r4.uniform(0.3, 1.0))
+                cons = [[] for _ in range(B)]
+                for b, cfg in enumerate(cfgs):
+                    t = FrameTask(f, 1.0, 1.0, gain=g_)
+                    t.set_target(cfg.get_transform_frame_to_world(f) * exp6(1e-4 * r4.normal(size=6)))
+                    cons[b].append(t)
     kw = dict(barriers=bars or None)
+    if cons is not None:
+        kw["constraints"] = cons
     if os.environ.get("FUZZ_EXTRAS") and m.floating_base_velocity_limit is None:
         r3 = np.random.default_rng(sd + 2 * 10 ** 9)
         if r3.random() < 0.3:  # an explicit limit list with an AccelerationLimit on the joints behind the root
@@ -128,14 +167,14 @@ def one(sd):
         # precision (FrameTasks alone on more coordinates than rows, damping 1e-12: the pivot's sign is round-off; quadprog
         # raises there as well)
         try:
-            cmax = max(np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **kw).P) for b in range(B))
+            cmax = max(np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **_kw_of(kw, b)).P) for b in range(B))
         except Exception:  # noqa: BLE001
             cmax = 0.0
         if cmax > 1e15:
             return "same failure", 0.0
         return f"host {host_err} / device {dev_err} (cond(H) up to {cmax:.1e})", 0.0
     # two evaluations of the same QP agree to cond(H) eps: the tolerance follows the conditioning of each instance
-    cond = np.array([np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **kw).P) for b in range(B)])
+    cond = np.array([np.linalg.cond(pink_amd.build_ik(cfgs[b], tasks[b], dt, **_kw_of(kw, b)).P) for b in range(B)])
     rel = np.abs(V_dev - V_host).max(axis=1) / np.maximum(1.0, np.abs(V_host).max(axis=1))
     err = float((rel / np.maximum(1.0, 1e4 * cond * np.finfo(float).eps / 1e-8)).max())  # (compared with 1e-8)
     if os.environ.get("FUZZ_VERBOSE"):
@@ -145,7 +184,7 @@ def one(sd):
         np.set_printoptions(precision=4, linewidth=200)
         print("worst instance", w, "tasks", [type(t).__name__ for t in tasks[w]], "limits", [type(l).__name__ for l in (kw.get("limits") or [])])
         print("V_host", V_host[w]); print("V_dev - V_host", V_dev[w] - V_host[w])
-        pr = pink_amd.build_ik(cfgs[w], tasks[w], dt, **kw)
+        pr = pink_amd.build_ik(cfgs[w], tasks[w], dt, **_kw_of(kw, w))
         for name, V in (("host", V_host[w]), ("dev", V_dev[w])):
             dq = V * dt
             print(name, "objective", 0.5 * dq @ pr.P @ dq + pr.q @ dq, "max G dq - h", None if pr.G is None else float((pr.G @ dq - pr.h).max()),
