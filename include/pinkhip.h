@@ -424,6 +424,12 @@ int pinkhip_memcpy_h2d_overlapped(pinkhip_handle *h, void *dst, const void *src,
  *   pinkhip_sync                waits for all three streams */
 int pinkhip_memcpy_h2d_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_stream_wait_copies(pinkhip_handle *h);
+/* Which of the handle's two compute streams the entry points enqueue on from now on (0: the stream of pinkhip_create,
+ * the default; 1: a second one, created on first use).  Ranges of one batch launched alternately on the two overlap the
+ * drain of one range's kernel with the start of the next (a range of 8 192 wavefronts is 2.7 rounds of the chip's wave
+ * slots: launched back to back on ONE stream four ranges cost twice a single launch over the batch).  pinkhip_sync waits
+ * for both; a caller that selected stream 1 selects 0 again before it uses the handle for anything else. */
+int pinkhip_select_compute_stream(pinkhip_handle *h, int32_t index);
 int pinkhip_memcpy_d2h_async(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2h(pinkhip_handle *h, void *dst, const void *src, int64_t bytes);
 int pinkhip_memcpy_d2d(pinkhip_handle *h, void *dst, const void *src, int64_t bytes); /* stream-ordered, asynchronous */

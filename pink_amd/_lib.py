@@ -128,7 +128,7 @@ ABI_SYMBOLS = (
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_host_alloc", "pinkhip_host_free", "pinkhip_malloc", "pinkhip_free",
-    "pinkhip_memcpy_h2d", "pinkhip_memcpy_h2d_overlapped", "pinkhip_memcpy_h2d_async", "pinkhip_stream_wait_copies",
+    "pinkhip_memcpy_h2d", "pinkhip_memcpy_h2d_overlapped", "pinkhip_memcpy_h2d_async", "pinkhip_stream_wait_copies", "pinkhip_select_compute_stream",
     "pinkhip_memcpy_d2h_async", "pinkhip_memcpy_d2h", "pinkhip_memcpy_d2d", "pinkhip_sync", "pinkhip_timer_start",
     "pinkhip_timer_stop",
 )
@@ -190,6 +190,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_memcpy_h2d_async.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_memcpy_d2h_async.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_stream_wait_copies.argtypes = [vp]
+    lib.pinkhip_select_compute_stream.argtypes = [vp, ctypes.c_int32]
     lib.pinkhip_memcpy_d2d.argtypes = [vp, vp, vp, ctypes.c_int64]
     lib.pinkhip_sync.argtypes = [vp]
     lib.pinkhip_timer_start.argtypes = [vp]

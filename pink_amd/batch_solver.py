@@ -332,6 +332,10 @@ class BatchSolver:
         """Kernels enqueued from now on start after the uploads enqueued so far (``pinkhip_stream_wait_copies``)."""
         self._check(self._lib.pinkhip_stream_wait_copies(self._h))
 
+    def select_stream(self, index: int) -> None:
+        """Enqueue on compute stream ``index`` (0 or 1) from now on (``pinkhip_select_compute_stream``)."""
+        self._check(self._lib.pinkhip_select_compute_stream(self._h, int(index)))
+
     def get_async(self, arr: np.ndarray, ptr: int) -> None:
         """Enqueue a download ordered after the kernels enqueued so far and return (``pinkhip_memcpy_d2h_async``);
         ``arr`` is valid after :meth:`sync`."""

@@ -44,6 +44,7 @@ struct pinkhip_handle {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of the chunked *_host path (overlaps the kernels on `stream`)
   hipStream_t d2h_stream = nullptr;   // results going home while later kernels run (pinkhip_memcpy_d2h_async)
+  hipStream_t main_stream = nullptr, alt_stream = nullptr;  // `stream` is one of these two (pinkhip_select_compute_stream)
   hipEvent_t ev_copy = nullptr, ev_kernels = nullptr;  // copy stream -> compute stream, compute stream -> d2h stream
   std::vector<hipEvent_t> chunk_events;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -379,6 +380,11 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (h->ev_kernels) (void)hipEventDestroy(h->ev_kernels);
   if (h->d2h_stream) (void)hipStreamDestroy(h->d2h_stream);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->main_stream) h->stream = h->main_stream;
+  if (h->alt_stream) {
+    (void)hipStreamSynchronize(h->alt_stream);
+    (void)hipStreamDestroy(h->alt_stream);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PINKHIP_OK;
@@ -1152,7 +1158,20 @@ int pinkhip_sync(pinkhip_handle *h) {
   PH_HIP(h, hipSetDevice(h->device));
   PH_HIP(h, hipStreamSynchronize(h->copy_stream));
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->alt_stream) {  // (both compute streams, whichever is selected)
+    PH_HIP(h, hipStreamSynchronize(h->main_stream));
+    PH_HIP(h, hipStreamSynchronize(h->alt_stream));
+  }
   PH_HIP(h, hipStreamSynchronize(h->d2h_stream));
+  return PINKHIP_OK;
+}
+
+int pinkhip_select_compute_stream(pinkhip_handle *h, int32_t index) {
+  if (!h || index < 0 || index > 1) return fail(h, PINKHIP_E_INVALID, "compute stream 0 or 1");
+  PH_HIP(h, hipSetDevice(h->device));
+  if (!h->main_stream) h->main_stream = h->stream;
+  if (index == 1 && !h->alt_stream) PH_HIP(h, hipStreamCreateWithFlags(&h->alt_stream, hipStreamNonBlocking));
+  h->stream = index ? h->alt_stream : h->main_stream;
   return PINKHIP_OK;
 }
 

@@ -549,8 +549,21 @@ class DeviceRollout:
             if getattr(self, "_h_status", None) is None:  # page-locked landing buffers of the small result arrays
                 self._h_status, self._h_iters = a.pinned_empty((B,), np.int32), a.pinned_empty((B,), np.int32)
             res = (out, self._h_status, self._h_iters)
+        # ranges go to the handle's two compute streams in turn: the drain of one range's kernel overlaps the start of the
+        # next (on one stream four range kernels cost twice a single launch over the batch: profiles/prof_pipeline_r04.txt)
+        two = asyn and hasattr(a, "select_stream") and _os.environ.get("PINKHIP_ONE_COMPUTE_STREAM") != "1"
+        try:
+            return self._pipelined_ranges(a, cuts, q0, tg, toks, put, asyn, back, res, out, safety_break, two)
+        finally:
+            if two:
+                a.select_stream(0)
+
+    def _pipelined_ranges(self, a, cuts, q0, tg, toks, put, asyn, back, res, out, safety_break, two) -> bool:
+        B, nq, nv = self.B, self.nq, self.nv
         for c in range(len(cuts) - 1):
             lo, hi = int(cuts[c]), int(cuts[c + 1])
+            if two:
+                a.select_stream(c & 1)
             put(self.d_q + 8 * nq * lo, q0[lo:hi])
             for f, t in enumerate(tg):
                 if t is not None:
