@@ -538,19 +538,33 @@ def closed_loop_figures(solver, B: int) -> dict:
     return out
 
 
+def _matching_traffic_file():
+    """(`profiles/traffic_rNN.json` record, its name) of the newest committed PMC pass that was collected on exactly these
+    kernel sources (content hash), or (None, reason)."""
+    import glob
+
+    import __graft_entry__ as g
+
+    want = g._source_hash(g.HIP_DEPS)
+    newest = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        newest = newest or os.path.basename(path)
+        if t.get("source_hash") == want:
+            return t, os.path.basename(path)
+    return None, (f"profiles/{newest} is from other kernel sources: not reported" if newest else "no PMC pass committed for these sources")
+
+
 def traffic_from_profiles():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC pass -- reported only when that
     pass was collected on exactly these kernel sources (content hash), else null."""
-    import __graft_entry__ as g
-
-    path = os.path.join(ROOT, "profiles", "traffic_r04.json")
-    try:
-        t = json.load(open(path))
-        if t.get("source_hash") == g._source_hash(g.HIP_DEPS):
-            return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/traffic_r04.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
-        return None, "profiles/traffic_r04.json is from other kernel sources: not reported"
-    except (OSError, ValueError, KeyError):
-        return None, "no PMC pass committed for these sources"
+    t, name = _matching_traffic_file()
+    if t is None:
+        return None, name
+    return t.get("solve_kernel_hbm_bytes_per_launch"), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources {t['source_hash'][:12]})"
 
 
 def _valu_issue(kernel_ms: float, n_cu: int):
@@ -558,20 +572,15 @@ def _valu_issue(kernel_ms: float, n_cu: int):
     committed counter pass, same kernel sources) over the live launch duration, against the issue rate of the SIMDs --
     n_cu x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per SIMD; fp64 FMA has the full rate on
     MI355X), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)."""
-    import __graft_entry__ as g
-
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))
-        if t.get("source_hash") != g._source_hash(g.HIP_DEPS) or "solve_kernel_valu_instructions_per_launch" not in t:
-            return None
-    except (OSError, ValueError):
+    t, name = _matching_traffic_file()
+    if t is None or "solve_kernel_valu_instructions_per_launch" not in t:
         return None
     insts = t["solve_kernel_valu_instructions_per_launch"]
     peak = n_cu * 4 * 2.4e9 / 4 / 1e9
     achieved = insts / (kernel_ms * 1e-3) / 1e9
     return {"bound": "valu issue", "achieved": achieved, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": achieved / peak,
             "valu_instructions_per_launch": insts, "fma_f64_share": t.get("solve_kernel_fma_f64_instructions_per_launch", 0.0) / insts,
-            "source": "SQ_INSTS_VALU of profiles/sq_counters_r04.txt (rocprofv3 --pmc, same kernel sources) / kernel_ms measured here"}
+            "source": f"SQ_INSTS_VALU of profiles/{name.replace('traffic', 'sq_counters').replace('.json', '.txt')} (rocprofv3 --pmc, same kernel sources) / kernel_ms measured here"}
 
 
 def _with_timeout(fn, seconds: float, what: str):

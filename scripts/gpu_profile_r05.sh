@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiling visit of round 5 (a trimmed scripts/gpu_profile.sh): the bench line + detail, rocprofv3 kernel stats of the timed kernel
+# alone and of every kernel the bench runs, HBM PMC passes (separate --pmc runs, kernel-trace only), SQ counters of the headline,
+# the JVRC-shaped and the nv = 30 + 6 rows kernels, A/B of the solve kernels, stages of the pipelined array call, the array
+# API variants.  Outputs under gpurun_out/; `python scripts/collect_profiles.py r05` copies the summaries into profiles/.
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf gpurun_out/prof gpurun_out/prof_all gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc gpurun_out/pmc_jvrc gpurun_out/pmc_draco3b gpurun_out/prof_rollout
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 300 gpurun_out/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_all -o r01 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_all.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o r01 -- python scripts/stack_and_solve_once.py > /dev/null 2> gpurun_out/pmc_$c.err
+done
+bash scripts/pmc_probe.sh gpurun_out/pmc > gpurun_out/sq_counters.txt 2>&1
+bash scripts/pmc_probe.sh gpurun_out/pmc_jvrc --config jvrc > gpurun_out/sq_counters_jvrc.txt 2>&1
+bash scripts/pmc_probe.sh gpurun_out/pmc_draco3b --config draco3b > gpurun_out/sq_counters_draco3b.txt 2>&1
+python scripts/rollout_bench.py > gpurun_out/rollout_bench.txt 2>&1; tail -2 gpurun_out/rollout_bench.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rollout -o r01 -- python scripts/rollout_bench.py > /dev/null 2> gpurun_out/prof_rollout.err
+bash scripts/ab_solvers.sh > gpurun_out/ab_solvers.txt 2>&1
+python scripts/prof_pipeline.py > gpurun_out/prof_pipeline.txt 2>&1
+python scripts/ab_api_arrays.py > gpurun_out/ab_api_arrays.txt 2>&1
+python scripts/host_latency.py > gpurun_out/host_latency.txt 2>&1
+ls gpurun_out/prof gpurun_out/pmc_FETCH_SIZE | head
