@@ -76,13 +76,31 @@ __device__ __forceinline__ double transpose_reduce(F v) {
 // gfx9: register number + M0) instead of NT broadcast-FMAs against the indicator of p.  Entries with compile-time
 // indices stay what they were: sub-registers of the tuple, updated in place by the broadcast-FMAs.
 typedef double TabVec16 __attribute__((vector_size(128)));
+typedef double TabVec8 __attribute__((vector_size(64)));
+template <bool HALF>
+struct TabVecSel {
+  typedef TabVec16 type;
+};
+template <>
+struct TabVecSel<true> {
+  typedef TabVec8 type;
+};
 template <int NT>
 struct TabRegs {
   static constexpr int NVEC = (NT + 15) / 16;
   static_assert(NVEC >= 1 && NVEC <= 4, "at most 64 tableau columns");
-  TabVec16 v0, v1, v2, v3;  // (named members, whole-tuple reads and writes only: they must stay SSA values)
+  // (the last tuple is a 512-bit one when eight entries or fewer are left for it: NT = 56 = 16 + 16 + 16 + 8 keeps 16
+  // registers more than four full tuples would -- the difference between spills inside the tableau loop and none)
+  static constexpr bool kHalfLast = NT - 16 * (NVEC - 1) <= 8;
   template <int K>
-  __device__ __forceinline__ TabVec16 tuple() const {
+  using Vec = typename TabVecSel<(K == NVEC - 1) && kHalfLast>::type;
+  // named members, whole-tuple reads and writes only: they must stay SSA values
+  Vec<0> v0;
+  Vec<1> v1;
+  Vec<2> v2;
+  Vec<3> v3;
+  template <int K>
+  __device__ __forceinline__ Vec<K> tuple() const {
     if constexpr (K == 0) return v0;
     else if constexpr (K == 1) return v1;
     else if constexpr (K == 2) return v2;
@@ -91,13 +109,13 @@ struct TabRegs {
   template <int J>
   __device__ __forceinline__ double get() const {
     static_assert(J >= 0 && J < NT, "tableau column");
-    const TabVec16 t = tuple<J / 16>();
+    const Vec<J / 16> t = tuple<J / 16>();
     return t[J % 16];
   }
   template <int J>
   __device__ __forceinline__ void set(double x) {
     static_assert(J >= 0 && J < NT, "tableau column");
-    TabVec16 t = tuple<J / 16>();
+    Vec<J / 16> t = tuple<J / 16>();
     t[J % 16] = x;
     if constexpr (J / 16 == 0) v0 = t;
     else if constexpr (J / 16 == 1) v1 = t;
@@ -105,10 +123,12 @@ struct TabRegs {
     else v3 = t;
   }
   __device__ __forceinline__ void clear() {
-    const TabVec16 z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    v0 = v1 = v2 = v3 = z;
+    v0 = Vec<0>{};
+    v1 = Vec<1>{};
+    v2 = Vec<2>{};
+    v3 = Vec<3>{};
   }
-  // entry p of this lane's row, p the same in every lane of the wave (0 <= p < 16 NVEC): every tuple is read at p % 16
+  // entry p of this lane's row, p the same in every lane of the wave (0 <= p < NT): every tuple is read at p % 16
   // and a scalar condition selects (a scalar BRANCH around the reads sent the tuples to scratch memory: measured)
   __device__ __forceinline__ double at_uniform(int p) const {
     const int hi = p >> 4;
@@ -116,21 +136,22 @@ struct TabRegs {
     // extract element lo" into a scalar load at a run-time address while the tuples still sit in an alloca -- which then
     // never becomes registers: the ik_sweepx.h instantiations ended up reading their tableau from scratch memory)
     const int lo = opaque_uniform(p & 15);
-    const TabVec16 t0 = v0;
-    double r = t0[lo];
+    const int lo8 = kHalfLast ? opaque_uniform(p & 7) : lo;  // (the index into a 512-bit last tuple: opaque AFTER its mask)
+    const Vec<0> t0 = v0;
+    double r = t0[NVEC == 1 ? lo8 : lo];
     if constexpr (NVEC > 1) {
-      const TabVec16 t1 = v1;
-      const double r1 = t1[lo];
+      const Vec<1> t1 = v1;
+      const double r1 = t1[NVEC == 2 ? lo8 : lo];
       r = (hi == 1) ? r1 : r;
     }
     if constexpr (NVEC > 2) {
-      const TabVec16 t2 = v2;
-      const double r2 = t2[lo];
+      const Vec<2> t2 = v2;
+      const double r2 = t2[NVEC == 3 ? lo8 : lo];
       r = (hi == 2) ? r2 : r;
     }
     if constexpr (NVEC > 3) {
-      const TabVec16 t3 = v3;
-      const double r3 = t3[lo];
+      const Vec<3> t3 = v3;
+      const double r3 = t3[lo8];
       r = (hi == 3) ? r3 : r;
     }
     return r;

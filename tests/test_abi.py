@@ -134,6 +134,31 @@ def test_headline_kernel_has_no_register_spills(built):
     assert vspill <= 16 and vgpr <= 168, row[0]
 
 
+def test_tableau_rows_stay_in_registers(built):
+    """Round 5: the tableau rows of the 32- and 64-lane kernels live in 1024-bit VGPR tuples so that a column of a
+    run-time index is a register read (TabRegs, csrc/ik_common.h).  When the optimiser gets to rewrite "load the tuple,
+    extract element p" as a scalar load at a run-time address, the tuples never become registers and the kernel reads its
+    tableau from SCRATCH memory -- correct results, a fraction of the speed, silently (it happened to the ik_sweepx.h
+    instantiations and to a 512-bit last tuple while this was written).  A tuple in memory shows as a private segment of
+    hundreds of bytes that no spilled register accounts for."""
+    import glob
+    import subprocess
+    import sys
+
+    objs = sorted(glob.glob(os.path.join(ROOT, "pink_amd", "csrc", "build", "sweep_*.o")) + glob.glob(os.path.join(ROOT, "pink_amd", "csrc", "build", "sweepx_*.o"))
+                  + glob.glob(os.path.join(ROOT, "pink_amd", "csrc", "build", "rollout_*.o")) + glob.glob(os.path.join(ROOT, "pink_amd", "csrc", "build", "rdense_*.o")))
+    assert len(objs) >= 30
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kernel_meta.py")] + objs, capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump / llvm-readelf not available: " + out.stderr[-200:])
+    rows = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("ik_")]
+    assert len(rows) >= 30, out.stdout[-2000:]
+    # private segment beyond what the spilled registers account for (4 bytes each): an array or a tuple kept in memory
+    excess = lambda f: int(f[-2]) - 4 * int(f[-4])  # noqa: E731  (columns: ... vspill sspill scratch lds)
+    worst = max(rows, key=excess)
+    assert excess(worst) < 128, " ".join(worst)  # (one 1024-bit tuple per lane is 128 bytes)
+
+
 def test_no_device_function_is_called(built):
     """Everything that touches the dynamic LDS has to be inlined into its kernel: as a *called* function the body of
     the sweep-tableau kernel reached the LDS through the per-kernel offset table LLVM builds for that case and faulted on
