@@ -6,7 +6,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf gpurun_out/prof gpurun_out/prof_all gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc gpurun_out/pmc_jvrc gpurun_out/pmc_draco3b gpurun_out/prof_rollout
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 300 gpurun_out/bench.json; echo
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cp gpurun_out/bench_detail.json gpurun_out/bench_detail_full.json; tail -c 300 gpurun_out/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_all -o r01 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_all.err
 for c in FETCH_SIZE WRITE_SIZE; do
