@@ -181,3 +181,67 @@ def test_frozen_targets_are_uploaded_once_and_new_targets_replace_them(backend):
     V4 = solve_ik_batch(cb, [ft, po], dt)
     ref = solve_ik(cfgs[3], [_own_frame_task(R, t + 0.02, 3), po], dt)
     assert np.abs(V4[3] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()) and np.abs(V4 - V1).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_page_locked_pipelined_call_on_two_compute_streams(gpu_solver, monkeypatch):
+    """The pipelined array call as a control loop makes it -- q, targets and out= in page-locked memory, so uploads,
+    range kernels (alternating between the handle's two compute streams) and downloads are all in flight at once -- with
+    frozen targets, with dense rows (a constraint; barriers) and with one compute stream: bit for bit the single launch."""
+    import sys
+
+    sik = sys.modules["pink_amd.solve_ik"]
+    set_default_solver(gpu_solver)
+    try:
+        dt, B = 5e-3, 4099  # (ranges of unequal size)
+        m = build_chain(14, free_flyer=True, seed=3, limit=2.6, velocity=4.0)
+        rng = np.random.default_rng(7)
+        q = pink_amd.pinned_empty((B, m.nq))
+        q[:] = _draw_q(m, B, rng)
+        c0 = Configuration(m, q[0])
+        tasks = []
+        for f in ("tool0", "joint_6"):
+            ft = FrameTask(f, 1.0, 0.5, lm_damping=1e-3)
+            T0 = c0.get_transform_frame_to_world(f)
+            ft.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=pink_amd.pinned_empty((B, 12)))
+            tasks.append(ft)
+        po = PostureTask(cost=5e-2)
+        po.set_target(m.neutral())
+        tasks.append(po)
+        hold = FrameTask("joint_12", 1.0, 1.0, gain=0.5)
+        hold.set_target(c0.get_transform_frame_to_world("joint_12"))
+        q[:] = q[0]  # (the constraint is within reach everywhere)
+        p_tool = c0.get_transform_frame_to_world("tool0").translation
+        bars = [PositionBarrier("tool0", indices=[2], p_max=np.array([p_tool[2] + 0.01]), gain=np.array([50.0]), safe_displacement_gain=1.0),
+                BodySphericalBarrier(("tool0", "joint_3"), d_min=0.01, gain=10.0)]
+        cb = ConfigurationBatch(m, q)
+        for kw in (dict(), dict(constraints=[hold]), dict(barriers=bars)):
+            monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 1 << 30)
+            pink_amd.clear_device_cache()
+            V_one = solve_ik_batch(cb, tasks, dt, **kw).copy()
+            assert pink_amd.last_solve_stats()["route"] == "device" and np.abs(V_one).max() > 1e-3
+            monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 64)
+            out = pink_amd.pinned_empty((B, m.nv))
+            for env in ("0", "1"):
+                monkeypatch.setenv("PINKHIP_ONE_COMPUTE_STREAM", env)
+                pink_amd.clear_device_cache()
+                for _ in range(2):  # fresh device state, then the cached one
+                    out[:] = np.nan
+                    V = solve_ik_batch(cb, tasks, dt, out=out, **kw)
+                    assert V is out and np.array_equal(V, V_one), (kw.keys(), env)
+        # frozen targets: the second call uploads q only, same result
+        for ft in tasks[:2]:
+            ft.freeze_targets()
+        monkeypatch.setenv("PINKHIP_ONE_COMPUTE_STREAM", "0")
+        pink_amd.clear_device_cache()
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 1 << 30)
+        V_one = solve_ik_batch(cb, tasks, dt).copy()
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 64)
+        pink_amd.clear_device_cache()
+        out = pink_amd.pinned_empty((B, m.nv))
+        for _ in range(3):
+            out[:] = np.nan
+            assert np.array_equal(solve_ik_batch(cb, tasks, dt, out=out), V_one)
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
