@@ -359,11 +359,11 @@ def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
 
     Returns ``(stationarity, primal violation, lam)``: multipliers ``lam >= 0`` of the inequality
     rows that are active within ``active_tol`` (and free multipliers of the equalities) are fitted by
-    non-negative least squares, the stationarity residual is ``|Px + q + G'lam + A'nu|_inf`` and the
+    bounded least squares, the stationarity residual is ``|Px + q + G'lam + A'nu|_inf`` and the
     violation ``max(0, max(Gx - h), |Ax - b|_inf)``.  A strictly convex QP has a unique minimiser, so a
     small certificate proves ``x`` is the solution whatever solver produced it.
     """
-    from scipy.optimize import nnls
+    from scipy.optimize import lsq_linear, nnls
 
     P = np.asarray(P, float)
     q = np.asarray(q, float)
@@ -392,14 +392,34 @@ def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
         viol = max(viol, float(np.abs(A @ x - np.asarray(b, float)).max()))
         an = np.linalg.norm(A, axis=1)
         an[an == 0] = 1.0
-        cols += [(A / an[:, None]).T, -(A / an[:, None]).T]  # free multiplier = difference of two non-negative ones
+        cols.append((A / an[:, None]).T)
     r = g.copy()
     if cols:
         M = np.hstack(cols)
-        sol, _ = nnls(M, -g, maxiter=50 * max(M.shape))
-        r = g + M @ sol
-        if act.size:
-            lam[act] = sol[:act.size] / norms[act]
+        n_act = int(act.size)
+        best = None
+        # bounded least squares: multipliers of the active inequality rows >= 0, those of the equalities free.  Two
+        # methods, the smaller residual wins (scipy's nnls on "free = difference of two non-negative columns" returned a
+        # non-minimising point with exactly dependent columns: gpu_fuzz seed 704011).
+        lo = np.r_[np.zeros(n_act), np.full(M.shape[1] - n_act, -np.inf)]
+        for method in ("bvls", "trf"):
+            try:
+                sol = lsq_linear(M, -g, bounds=(lo, np.inf), method=method, tol=1e-15, max_iter=50 * max(M.shape)).x
+            except Exception:  # noqa: BLE001 - a failed fit is just not a certificate
+                continue
+            rr = g + M @ sol
+            if best is None or np.abs(rr).max() < np.abs(best[0]).max():
+                best = (rr, sol)
+            if np.abs(rr).max() <= 1e-13 * max(1.0, np.abs(g).max()):
+                break
+        if n_eq == 0 and (best is None or np.abs(best[0]).max() > 1e-13 * max(1.0, np.abs(g).max())):
+            sol, _ = nnls(M, -g, maxiter=50 * max(M.shape))
+            rr = g + M @ sol
+            if best is None or np.abs(rr).max() < np.abs(best[0]).max():
+                best = (rr, sol)
+        r, sol = best
+        if n_act:
+            lam[act] = sol[:n_act] / norms[act]
     stat = float(np.abs(r).max(initial=0.0))
     return stat, viol, lam
 

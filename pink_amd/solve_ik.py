@@ -377,7 +377,8 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     velocity vector, constraints)`` when the whole batch can be evaluated on the device from the configurations alone --
     FrameTasks / RelativeFrameTasks (one target per instance allowed), one PostureTask, the table-formed tasks of
     :func:`_extra_task`, the model's default limits (:func:`_default_limits_gain`), PositionBarriers (default class-K
-    function) and BodySphericalBarriers, equality constraints made of FrameTasks (``pink/solve_ik.py:125-149``), one model
+    function) and BodySphericalBarriers, equality constraints made of FrameTasks / RelativeFrameTasks (``pink/solve_ik.py:125-149``;
+    at most two), one model
     -- else ``None``.  Frames that only a barrier or a constraint needs become slots of the device model with ZERO cost
     (``pink/tasks/task.py:148-166``: nothing enters the objective for them); ``constraints`` is a tuple of
     ``(slot, gain)``."""
@@ -385,6 +386,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     from .barriers.body_spherical_barrier import BodySphericalBarrier
     from .barriers.position_barrier import PositionBarrier
     from .tasks.frame_task import FrameTask
+    from .tasks.relative_frame_task import RelativeFrameTask
 
     B = len(configurations)
     if B == 0:
@@ -428,9 +430,16 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         # per instance; their slots carry zero cost
         per_instance = len(constraints) == B and isinstance(constraints[0], (list, tuple))
         flat = [t for c in constraints for t in c] if per_instance else list(constraints)
-        if not flat or any(type(t) is not FrameTask for t in flat):
-            return None
-        cplan = _device_kinematics_plan_tasks_raw(configurations, constraints)
+        if not flat or any(type(t) not in (FrameTask, RelativeFrameTask) for t in flat):
+            return None  # (a RelativeFrameTask constraint is a relative slot: the same rows with a signed ancestor table)
+        cfg_like = configurations
+        if per_instance and hasattr(configurations, "q") and not isinstance(configurations, (list, tuple)):
+            # (a ConfigurationBatch next to per-instance constraint objects: the reader of per-instance task lists only wants
+            # `.model` and `.q` of each configuration -- no Configuration object, no forward kinematics)
+            import types
+
+            cfg_like = [types.SimpleNamespace(model=model, q=row) for row in configurations.q]
+        cplan = _device_kinematics_plan_tasks_raw(cfg_like, constraints)
         if cplan is None or cplan[4] is not None or cplan[5]:
             return None
         _, _, cspecs, cT, _, _ = cplan

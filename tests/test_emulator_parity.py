@@ -101,6 +101,9 @@ def test_fuzz_weakly_regularised(emu):
 
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):
     assert ps.kkt_certificate(emu, range(9000, 9060)) > 80
+    # seed 704011 (wide GPU fuzz, round 5): two equalities with negative multipliers at a vertex -- the certificate's own
+    # multiplier fit has to leave them sign-free
+    assert ps.kkt_certificate(emu, [704011]) == 3
 
 
 def test_small_stack_packing(emu):
