@@ -552,9 +552,17 @@ class DeviceRollout:
         # ranges go to the handle's two compute streams in turn: the drain of one range's kernel overlaps the start of the
         # next (on one stream four range kernels cost twice a single launch over the batch: profiles/prof_pipeline_r04.txt)
         two = asyn and hasattr(a, "select_stream") and _os.environ.get("PINKHIP_ONE_COMPUTE_STREAM") != "1"
+        # Page-locked result arrays are written by the kernel itself (mapped host memory: the device address of a
+        # hipHostMalloc block is its host address): no result stream, no copy per range, nothing left to drain when the
+        # last kernel ends -- the device-to-host direction of the link is idle otherwise.  PINKHIP_RESULT_COPIES=1 goes
+        # back to the copies (A/B: profiles/ab_api_arrays_r05.txt).
+        self._zc = None
+        if back and _os.environ.get("PINKHIP_RESULT_COPIES") != "1":
+            self._zc = tuple(int(r.ctypes.data) for r in res)
         try:
             return self._pipelined_ranges(a, cuts, q0, tg, toks, put, asyn, back, res, out, safety_break, two)
         finally:
+            self._zc = None
             if two:
                 a.select_stream(0)
 
@@ -576,7 +584,7 @@ class DeviceRollout:
                 if asyn:
                     a.sync()
                 return False
-            if back:
+            if back and self._zc is None:
                 a.get_async(res[0][lo:hi], self.d_dq + 8 * nv * lo)
                 a.get_async(res[1][lo:hi], self.d_status + 4 * lo)
                 a.get_async(res[2][lo:hi], self.d_iters + 4 * lo)
@@ -604,7 +612,8 @@ class DeviceRollout:
         st = RolloutStep()
         st.q, st.cost, st.T_target, st.T_frames = self.d_q, self.d_cost, self.d_Tt, self.d_T
         st.q_target = self.d_qt if self.n_post else None
-        st.dq, st.status, st.iters, st.first_failure = self.d_dq, self.d_status, self.d_iters, self.d_fail
+        st.dq, st.status, st.iters = getattr(self, "_zc", None) or (self.d_dq, self.d_status, self.d_iters)
+        st.first_failure = self.d_fail
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)
         self._scale_out(st, integrate)
@@ -675,7 +684,8 @@ class DeviceRollout:
         st.q, st.cost = self.d_q + 8 * nq * lo, self.d_cost
         st.T_target, st.T_frames = self.d_Tt + 8 * 12 * lo, self.d_T + 8 * 12 * max(nf, 1) * lo
         st.q_target = (self.d_qt + (8 * nq * lo if self.qt_batched else 0)) if self.n_post else None
-        st.dq, st.status, st.iters = self.d_dq + 8 * nv * lo, self.d_status + 4 * lo, self.d_iters + 4 * lo
+        dq, status, iters = getattr(self, "_zc", None) or (self.d_dq, self.d_status, self.d_iters)
+        st.dq, st.status, st.iters = dq + 8 * nv * lo, status + 4 * lo, iters + 4 * lo
         st.first_failure = self.d_fail + 4 * lo
         st.config_limit_gain = self.config_limit_gain
         st.target_batched, st.step, st.integrate = self.qt_batched, self.steps_done, int(integrate)

@@ -15,16 +15,20 @@ from pink_amd import rollout  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     rows = []
+    only = os.environ.get("AB_ONLY")  # substring of the labels to run
     for label, kw, split in (("pageable", dict(), "1,1,1,1"),
                              ("page-locked", dict(pinned=True), "1,1,1,1"),
                              ("page-locked, frozen targets, 4 ranges", dict(pinned=True, freeze=True), "1,1,1,1"),
                              ("page-locked, frozen targets, 3 ranges", dict(pinned=True, freeze=True), "1,1,1"),
                              ("page-locked, frozen targets, 2 ranges", dict(pinned=True, freeze=True), "1,1"),
+                             ("page-locked, frozen targets, 1 range", dict(pinned=True, freeze=True), "1"),
                              ("page-locked, frozen targets, 5 ranges", dict(pinned=True, freeze=True), "1,1,1,1,1"),
                              ("page-locked, frozen targets, 6 ranges", dict(pinned=True, freeze=True), "1,1,1,1,1,1"),
                              ("page-locked + constraints=[FrameTask]", dict(pinned=True, extra_task="constraint"), "1,1,1,1"),
                              ("page-locked + spherical + position barrier", dict(pinned=True, extra_task="barriers"), "1,1,1,1"),
                              ("page-locked, frozen + constraints=[FrameTask]", dict(pinned=True, freeze=True, extra_task="constraint"), "1,1,1,1")):
+        if only and only not in label:
+            continue
         rollout.PIPELINE_SPLIT = tuple(float(v) for v in split.split(","))
         pink_amd.clear_device_cache()
         r = bench.api_level_arrays(B, **kw)

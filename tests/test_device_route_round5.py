@@ -245,3 +245,52 @@ def test_page_locked_pipelined_call_on_two_compute_streams(gpu_solver, monkeypat
     finally:
         pink_amd.clear_device_cache()
         set_default_solver(None)
+
+
+@pytest.mark.gpu
+def test_page_locked_results_written_by_the_kernel(gpu_solver, monkeypatch):
+    """A page-locked ``out`` (and the small status / iteration arrays behind it) is written by the whole-step kernel itself
+    (mapped host memory) instead of being copied home range by range: same bits as the copies (PINKHIP_RESULT_COPIES=1)
+    and as the single launch, also after ``q`` and the targets are refilled in place."""
+    import sys
+
+    sik = sys.modules["pink_amd.solve_ik"]
+    set_default_solver(gpu_solver)
+    try:
+        dt, B = 5e-3, 4099
+        m = build_chain(14, free_flyer=True, seed=3, limit=2.6, velocity=4.0)
+        rng = np.random.default_rng(11)
+        q = pink_amd.pinned_empty((B, m.nq))
+        q[:] = _draw_q(m, B, rng)
+        c0 = Configuration(m, q[0])
+        block = pink_amd.pinned_empty((2, B, 12))
+        tasks = []
+        for k, f in enumerate(("tool0", "joint_6")):
+            ft = FrameTask(f, 1.0, 0.5, lm_damping=1e-3)
+            T0 = c0.get_transform_frame_to_world(f)
+            ft.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=block[k])
+            tasks.append(ft)
+        po = PostureTask(cost=5e-2)
+        po.set_target(m.neutral())
+        tasks.append(po)
+        cb = ConfigurationBatch(m, q)
+        out = pink_amd.pinned_empty((B, m.nv))
+        for step in range(2):
+            monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 1 << 30)
+            pink_amd.clear_device_cache()
+            V_one = solve_ik_batch(cb, tasks, dt).copy()
+            assert pink_amd.last_solve_stats()["route"] == "device" and np.abs(V_one).max() > 1e-3
+            monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 64)
+            for rc in ("0", "1"):
+                monkeypatch.setenv("PINKHIP_RESULT_COPIES", rc)
+                pink_amd.clear_device_cache()
+                for _ in range(2):
+                    out[:] = np.nan
+                    V = solve_ik_batch(cb, tasks, dt, out=out)
+                    assert V is out and np.array_equal(V, V_one), (step, rc)
+            # the next control step: configurations and targets refilled in place
+            q[:] = _draw_q(m, B, rng)
+            block[:, :, 9:] += 0.01 * rng.normal(size=(2, B, 3))
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
