@@ -533,6 +533,18 @@ def closed_loop_figures(solver, B: int) -> dict:
             out[label] = {"nv": model.nv, "B": B, "ms_per_step": ms, "robot_steps_per_s": B / (ms * 1e-3), "launches_per_step": 1 if ro.fused == "kernel" else 2,
                           "barrier_rows": ro.md, "qp_iters_mean": float(it.mean()), "failed": int((st != 0).sum()),
                           "handover_frac": float(n_path[1]) / B, "routed_frac": float(n_path[2]) / B}
+            # what a target change costs: every robot's targets move by a few centimetres at once (the steady state above
+            # is a converged loop: < 1 active-set step per QP); the first steps afterwards, one HIP-event bracket each
+            T[:, :, 9:12] += 0.05 * rng.normal(size=(B, len(frames), 3))
+            ro.set_targets(T)
+            solver.sync()
+            after = []
+            for _ in range(4):
+                solver.timer_start()
+                ro.step()
+                t_ms = solver.timer_stop()
+                after.append({"ms": t_ms, "qp_iters_mean": float(ro.last_step()[2].mean())})
+            out[label]["steps_after_a_target_move"] = after
         finally:
             ro.free()
     return out

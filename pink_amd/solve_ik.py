@@ -856,9 +856,9 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     if not rows_only and (device_kinematics or (device_kinematics is None and len(configurations) >= 64)):
         plan = _device_kinematics_plan(configurations, tasks, limits, barriers, constraints)
         if plan is None and device_kinematics:
-            raise PinkError("device_kinematics=True needs FrameTasks (+ one PostureTask, constant-row and identity tasks shared by the "
-                            "batch), default limits, no constraints, and no barriers other than PositionBarriers (default class-K "
-                            "function) on the task frames")
+            raise PinkError("device_kinematics=True needs FrameTasks / RelativeFrameTasks (+ one PostureTask, constant-row and identity "
+                            "tasks shared by the batch), the model's default limits (+ one AccelerationLimit), constraints made of at most "
+                            "two frame tasks, and barriers that are PositionBarriers or BodySphericalBarriers with the default class-K functions")
     if plan is not None:
         from .batch_solver import BatchResult
         from .rollout import NoWholeStepKernel
