@@ -1031,7 +1031,8 @@ def main() -> None:
                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                 "model": "Kd nv (nv+1) + 2 Kd nv + nv^3/3 + 2 nv^2 + iters (4 nv^2 + 2 md nv), SURVEY.md 8(d); useful flops, not issued lanes",
             },
-            "roofline_valu_issue": _valu_issue(kernel_ms, int(info.get("compute_units") or 256)),
+            # (the counter pass is of the default workload: its instruction count says nothing about another batch or regime)
+            "roofline_valu_issue": _valu_issue(kernel_ms, int(info.get("compute_units") or 256)) if traffic is not None else None,
             "solver_stats": dict({"failed": n_bad, "iters_mean": it_mean, "iters_max": int(res.iters.max())}, **solver_paths(res)),
             "per_rank_kernel_ms": kernel_ms_ranks,
             "per_rank_end_to_end_ms": e2e_ranks,
