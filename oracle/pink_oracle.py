@@ -354,14 +354,14 @@ def goldfarb_idnani(
 # ---------------------------------------------------------------------------
 
 
-def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
+def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None, with_nu: bool = False):
     """KKT certificate of ``x`` for ``min 1/2 x'Px + q'x  s.t. Gx <= h, Ax = b``.
 
     Returns ``(stationarity, primal violation, lam)``: multipliers ``lam >= 0`` of the inequality
     rows that are active within ``active_tol`` (and free multipliers of the equalities) are fitted by
     bounded least squares, the stationarity residual is ``|Px + q + G'lam + A'nu|_inf`` and the
     violation ``max(0, max(Gx - h), |Ax - b|_inf)``.  A strictly convex QP has a unique minimiser, so a
-    small certificate proves ``x`` is the solution whatever solver produced it.
+    small certificate proves ``x`` is the solution whatever solver produced it.  ``with_nu``: also the equality multipliers.
     """
     from scipy.optimize import lsq_linear, nnls
 
@@ -372,10 +372,11 @@ def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
     n_in = 0 if G is None else len(G)
     n_eq = 0 if A is None else len(A)
     if n_in == 0 and n_eq == 0:
-        return float(np.abs(g).max(initial=0.0)), 0.0, np.zeros(0)
+        return (float(np.abs(g).max(initial=0.0)), 0.0, np.zeros(0)) + ((np.zeros(0),) if with_nu else ())
     viol = 0.0
     cols = []
     lam = np.zeros(n_in)
+    nu = np.zeros(n_eq)
     act = np.zeros(0, dtype=int)
     if n_in:
         G = np.asarray(G, float)
@@ -420,8 +421,10 @@ def kkt_residuals(P, q, G, h, x, active_tol: float = 1e-9, A=None, b=None):
         r, sol = best
         if n_act:
             lam[act] = sol[:n_act] / norms[act]
+        if n_eq:
+            nu = sol[n_act:] / an
     stat = float(np.abs(r).max(initial=0.0))
-    return stat, viol, lam
+    return (stat, viol, lam, nu) if with_nu else (stat, viol, lam)
 
 
 # ---------------------------------------------------------------------------

@@ -290,8 +290,16 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
                                       np.concatenate([e, ep], axis=1), np.concatenate([cost, np.full(nv, dcost)]),
                                       np.ones(2), np.array([lm, 0.0]), np.array([0, k, k + nv], np.int32), 1e-12, G, h,
                                       meq=neq, want_Hc=True)
-        assert np.array_equal(out.status, ref["status"]), (sd, out.status, ref["status"])
-        ok = ref["status"] == 0
+        # An "inconsistent constraints" verdict of the oracle (quadprog's rule: the entering row depends on the active ones
+        # and none can be dropped) is REFUTED by a point that is feasible and KKT-stationary -- in the weakly regularised
+        # draws round-off alone can produce that verdict (seed 965963: the C and the NumPy restatement disagree with each
+        # other, an LP confirms the rows are consistent).  Only that direction is accepted, and only on the certificate.
+        for b in np.nonzero(out.status != ref["status"])[0]:
+            assert ill and out.status[b] == 0 and ref["status"][b] == 2, (sd, out.status, ref["status"])
+            certify_point(ref["H"][b], ref["c"][b], G[b, neq:], h[b, neq:], out.dq[b], None, A[b] if neq else None, bv[b] if neq else None,
+                          tag=(sd, int(b), "oracle said inconsistent"))
+            REFUTED.append((sd, int(b)))
+        ok = (ref["status"] == 0) & (out.status == 0)
         if ok.any():
             cond = np.linalg.cond(ref["H"][ok])
             xmax = np.abs(ref["dq"][ok]).max(axis=1)
@@ -310,20 +318,30 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
 
 
 CERTIFIED = []  # (seed, instance, |dq - dq_ref|, cond(H)) of the draws accepted on their certificate instead of on dq
+REFUTED = []  # (seed, instance) where the oracle's "inconsistent" verdict was refuted by the kernel's certified point
 
 
 def certify_point(P, q, G, h, x, x_ref, A=None, b=None, tag=None):
     """``x`` is the minimiser of  min 1/2 x'Px + q'x, Gx <= h, Ax = b  as far as fp64 can tell: primal feasible to
     1e-9 (1 + |h|), stationary with non-negative multipliers to 1e-9 (|q| + |P| |x|), and an objective not above the
     oracle's by more than 1e-12 (1 + |f|).  Independent of how far x is from x_ref."""
-    stat, viol, _ = po.kkt_residuals(P, q, G, h, x, A=A, b=b)
+    stat, viol, lam, nu = po.kkt_residuals(P, q, G, h, x, A=A, b=b, with_nu=True)
     scale = max(1.0, float(np.abs(q).max()), float(np.abs(P).max() * np.abs(x).max()))
+    hf = np.abs(h)[np.abs(h) < 1e29]  # (rows  x_i <= 1e30  stand for missing bounds)
+    hmax = float(hf.max(initial=0.0))
+    assert viol <= 1e-9 * (1.0 + hmax), ("violation", tag, viol)
+    assert stat <= 1e-9 * scale, ("stationarity", tag, stat, scale)
+    if x_ref is None:  # (no reference point: feasibility + stationarity are the whole certificate)
+        return
     f = lambda v: 0.5 * v @ P @ v + q @ v  # noqa: E731
     gap = (f(x) - f(x_ref)) / (1.0 + abs(f(x_ref)))
-    hf = np.abs(h)[np.abs(h) < 1e29]  # (rows  x_i <= 1e30  stand for missing bounds)
-    assert viol <= 1e-9 * (1.0 + float(hf.max(initial=0.0))), ("violation", tag, viol)
-    assert stat <= 1e-9 * scale, ("stationarity", tag, stat, scale)
-    assert gap <= 1e-12, ("objective above the oracle's", tag, gap)
+    # Two nearly feasible KKT points differ in objective by what the multipliers make of their feasibility round-off
+    # (f moves by lam_i per unit of slack in row i): with multipliers of 6e5 (seed 961094: an equality next to pinned
+    # coordinates) one ulp of slack is 1e-11 of objective, and the comparison allows for exactly that, no more.
+    viol_ref = max(0.0, float((G @ x_ref - h).max(initial=0.0)) if len(G) else 0.0, float(np.abs(A @ x_ref - b).max()) if A is not None else 0.0)
+    slack_noise = viol + viol_ref + 4.0 * np.finfo(float).eps * (1.0 + hmax)
+    allow = (float(np.abs(lam).sum()) + float(np.abs(nu).sum())) * slack_noise / (1.0 + abs(f(x_ref)))
+    assert gap <= 1e-12 + allow, ("objective above the oracle's", tag, gap, allow)
 
 
 def kkt_certificate(solver, seeds):

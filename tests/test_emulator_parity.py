@@ -108,3 +108,17 @@ def test_kkt_certificate_independent_of_the_oracle_solver(emu):
 
 def test_small_stack_packing(emu):
     ps.small_stack_packing(emu)
+
+
+def test_seeds_the_wide_gpu_fuzz_of_round_5_stopped_on(emu, monkeypatch):
+    """Two draws of scripts/gpu_fuzz.py 900000 120000 where the CHECKER, not the kernel, was at its limit:
+    965963 (weakly regularised, duplicated dense rows): the C oracle reports "inconsistent constraints" by quadprog's rule
+    although the rows are consistent (its NumPy twin and an LP say so) -- the kernel's point is feasible and stationary, which
+    refutes the verdict; 961094 (an equality next to pinned coordinates, multipliers of 6e5): the two points agree to
+    5e-10 and their objectives differ by what those multipliers make of 1e-13 of equality residual."""
+    for solver in ("sweep", "packed"):
+        monkeypatch.setenv("PINKHIP_SOLVER", solver)
+        del ps.REFUTED[:]
+        assert ps.fuzz(emu, [965963], ill=True) == 4
+        assert ps.REFUTED == [(965963, 3)]
+        assert ps.fuzz(emu, [961094]) == 3
