@@ -75,10 +75,23 @@ def exact_minimiser(J: np.ndarray, e: np.ndarray, cost: np.ndarray, gain: Sequen
         def key(r):  # rows with the same normal (Pink stacks a configuration and a velocity row per coordinate)
             return tuple((j, float(v)) for j, v in Gs[r])
 
+        # a coordinate (or row) pinned from both sides -- g x <= h next to -g x <= -h, Pink's lb = ub -- is ONE equality with a
+        # multiplier of either sign: the second row of such a pair leaves the problem, the first joins the equalities
+        free = set(range(meq))
+        by_key = {key(r): r for r in keep if r >= meq}
+        for r in list(keep):
+            if r < meq or r not in Gs:
+                continue
+            opp = by_key.get(tuple((j, -v) for j, v in key(r)))
+            if opp is not None and opp != r and opp not in free and r not in free and hs[opp] == -hs[r]:
+                free.add(r)
+                keep.remove(opp)
+                del Gs[opp], hs[opp]
+                by_key.pop(key(r), None)
         xg = [mp.mpf(float(v)) for v in x_guess]
-        active, seen = list(range(meq)), {}
+        active, seen = sorted(free), {}
         for r in keep:
-            if r < meq:
+            if r in free:
                 continue
             s = slack(r, xg)
             if abs(s) <= mp.mpf(1e-7) * (1 + abs(hs[r])):
@@ -111,7 +124,7 @@ def exact_minimiser(J: np.ndarray, e: np.ndarray, cost: np.ndarray, gain: Sequen
             x, lam = solve(active)
             worst, at = 0, None
             for a, l in enumerate(lam):
-                if active[a] >= meq and l < -tiny and (at is None or l < worst):
+                if active[a] not in free and l < -tiny and (at is None or l < worst):
                     worst, at = l, a
             if at is not None:
                 active.pop(at)
@@ -139,7 +152,7 @@ def exact_minimiser(J: np.ndarray, e: np.ndarray, cost: np.ndarray, gain: Sequen
                 grad[j] += lam[a] * v
         res = max([abs(g) for g in grad] + [abs(slack(r, x)) for r in active] + [mp.mpf(0)])
         assert res <= tiny * (1 + max(abs(v) for v in q)), res
-        assert all(l >= -tiny for a, l in enumerate(lam) if active[a] >= meq) and all(slack(r, x) >= -tiny for r in keep if r >= meq)
+        assert all(l >= -tiny for a, l in enumerate(lam) if active[a] not in free) and all(slack(r, x) >= -tiny for r in keep if r not in free)
         order = np.argsort(active)
         return np.array([float(v) for v in x]), {"active": [active[i] for i in order], "changes": changes, "residual": float(res),
                                                  "multipliers": [float(lam[i]) for i in order]}

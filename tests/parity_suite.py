@@ -298,6 +298,12 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
             assert ill and out.status[b] == 0 and ref["status"][b] == 2, (sd, out.status, ref["status"])
             certify_point(ref["H"][b], ref["c"][b], G[b, neq:], h[b, neq:], out.dq[b], None, A[b] if neq else None, bv[b] if neq else None,
                           tag=(sd, int(b), "oracle said inconsistent"))
+            # ... and the point is THE minimiser: the exact-arithmetic solve (oracle/exact_qp.py) started from its active set
+            from oracle.exact_qp import exact_minimiser
+
+            xe, info = exact_minimiser(np.vstack([J[b], eye]), np.concatenate([e[b], ep[b]]), np.concatenate([cost, np.full(nv, dcost)]), [1.0, 1.0],
+                                       [lm, 0.0], [0, k, k + nv], 1e-12, G[b], h[b], out.dq[b], meq=neq)
+            assert np.abs(out.dq[b] - xe).max() <= 1e-8 * max(1.0, float(np.abs(xe).max())), (sd, int(b), "refuted verdict, but not the exact minimiser")
             REFUTED.append((sd, int(b)))
         ok = (ref["status"] == 0) & (out.status == 0)
         if ok.any():
