@@ -255,8 +255,18 @@ class DeviceRollout:
         self.root_box, self.lim_rows, self.lim_h = None, np.zeros((0, 6)), np.zeros(0)
         if floating_base_limit is not None:
             self.root_box, self.lim_rows, self.lim_h = _floating_base_rows(model, floating_base_limit, self.dt)
-            if self.fused is False and self.root_box is not None:
-                raise ValueError("a floating-base velocity limit needs fused=True or fused=\"kernel\"")
+        # a velocity vector with finite entries on the free-flyer's tangent coordinates (a VelocityLimit built with its own
+        # vector, pink/limits/velocity_limit.py:46-73,118-121: rows +-e_i dq <= dt v_i like any joint) joins the same box
+        # (a joint is velocity-limited only when ALL its tangent coordinates are, velocity_limit.py:66-74)
+        v_root = self.arrays.v_max[:6] if root_nv == 6 else np.zeros(0)
+        if root_nv == 6 and bool(((v_root < 1e20) & (v_root > 1e-10)).all()):
+            box = np.hstack([-self.dt * v_root, self.dt * v_root])
+            if self.root_box is None:
+                self.root_box = np.ascontiguousarray(box)
+            else:
+                self.root_box = np.ascontiguousarray(np.hstack([np.maximum(self.root_box[:6], box[:6]), np.minimum(self.root_box[6:], box[6:])]))
+        if self.fused is False and self.root_box is not None:
+            raise ValueError("a box on the floating base's coordinates needs fused=True or fused=\"kernel\"")
         n_lim = len(self.lim_h)
         # equality constraints made of frame tasks: the leading dense rows (six per constraint)
         self.cons = [(int(s_), float(g_)) for s_, g_ in constraint_slots]

@@ -491,9 +491,8 @@ def _default_limits_gain(model, limits):
     # is the same table with other numbers: the device model of the call carries that vector instead of the model's)
     vmax = None
     if not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
+        # (entries on a free-flyer's tangent coordinates become the box of the root coordinates: DeviceRollout)
         vmax = np.ascontiguousarray(vl[0].velocity_limit, dtype=np.float64)
-        if any(j.kind == "free_flyer" and np.any((vmax[j.idx_v:j.idx_v + 6] < 1e20) & (vmax[j.idx_v:j.idx_v + 6] > 1e-10)) for j in model.joints):
-            return None  # (a bound on the floating base's twist coordinates: not a table entry of the kernels)
     acc = None
     if al:
         a = al[0]

@@ -132,3 +132,36 @@ def test_a_relative_slot_beyond_the_sixteenth_frame_leaves_the_device_route(back
     assert pink_amd.last_solve_stats()["route"] != "device"
     ref = _per_configuration(m, q, lambda b: tasks, dt, 4)
     assert np.abs(V[:4] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("partly", [False, True])
+def test_velocity_bounds_on_the_floating_base_coordinates(backend, partly):
+    """A VelocityLimit built with its own vector (``pink/limits/velocity_limit.py:46-73``) whose entries on the free-flyer's
+    six tangent coordinates are finite bounds those coordinates like any joint (rows ``+-e_i dq <= dt v_i``, ``:118-121``):
+    the device route carries them in the box of the root coordinates (next to a FloatingBaseVelocityLimit's, if any)
+    instead of declining the stack."""
+    m = build_chain(8, free_flyer=True, seed=7, limit=2.6, velocity=4.0)
+    rng = np.random.default_rng(23)
+    B, dt = 64, 5e-3
+    q = _draw_q(m, B, rng)
+    vroot = np.array([0.3, 0.5, 0.4, 0.6, 0.9, 0.7])
+    if partly:  # (one entry missing: the free-flyer is then not a velocity-limited joint at all, velocity_limit.py:66-74)
+        vroot[4] = np.inf
+    v = np.asarray(m.velocityLimit, dtype=float).copy()
+    v[:6] = vroot
+    limits = [ConfigurationLimit(m), VelocityLimit(m, v)]
+    c0 = Configuration(m, q[0])
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    ft.set_target(c0.get_transform_frame_to_world("tool0") * exp6(0.3 * rng.normal(size=6)))  # far: the root saturates
+    po = PostureTask(cost=1e-3)
+    po.set_target(m.neutral())
+    tasks = [ft, po]
+    V = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt, limits=limits)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    ref = _per_configuration(m, q, lambda b: tasks, dt, 8, limits=limits)
+    assert np.abs(V[:8] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    unbounded = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt)
+    if partly:
+        assert np.abs(unbounded - V).max() < 1e-8 * max(1.0, np.abs(V).max())
+    else:
+        assert (np.abs(np.abs(ref[:, :6]) - vroot) < 1e-9).any() and np.abs(unbounded - V).max() > 1e-3  # some root bound is active
