@@ -374,7 +374,7 @@ def _spec_of(task):
 
 def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints):
     """``(model, q [B, nq], frame task specs, target poses, posture, extras, barriers, limit gain, acceleration tables,
-    velocity vector, constraints)`` when the whole batch can be evaluated on the device from the configurations alone --
+    velocity vector, constraints, floating-base limit)`` when the whole batch can be evaluated on the device from the configurations alone --
     FrameTasks / RelativeFrameTasks (one target per instance allowed), one PostureTask, the table-formed tasks of
     :func:`_extra_task`, the model's default limits (:func:`_default_limits_gain`), PositionBarriers (default class-K
     function) and BodySphericalBarriers, equality constraints made of FrameTasks / RelativeFrameTasks (``pink/solve_ik.py:125-149``;
@@ -461,14 +461,14 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
                     have.add(f)
     if len(specs) > 32 or any(isinstance(sp[0], tuple) and i >= 16 for i, sp in enumerate(specs)):
         return None
-    return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons)
+    return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons), _explicit_floating_base_limit(model, limits)
 
 
 def _default_limits_gain(model, limits):
     """``(config_limit_gain, acceleration tables or None)`` when ``limits`` amounts to what the device kernels form from
     tables: the model's default limits (``pink/solve_ik.py:94-105``) -- ``None`` itself, or an explicit list holding
-    exactly one ConfigurationLimit and one VelocityLimit of this model with the model's velocity vector (plus the
-    model's floating-base limit if it has one) -- optionally with ONE AccelerationLimit of this model on joints behind
+    exactly one ConfigurationLimit and one VelocityLimit of this model (its own velocity vector allowed), at most one
+    FloatingBaseVelocityLimit of this model -- optionally with ONE AccelerationLimit of this model on joints behind
     the root (``pink/limits/acceleration_limit.py:158-199``: a box from ``q``, the previous displacement and three
     per-coordinate tables ``a_max / Delta_q_prev / has_configuration_limit``) -- else ``None``."""
     from .limits import AccelerationLimit, ConfigurationLimit, VelocityLimit
@@ -478,14 +478,17 @@ def _default_limits_gain(model, limits):
     model.ensure_limits()
     if limits is None:
         return float(model.configuration_limit.config_limit_gain), None, None
-    fb = getattr(model, "floating_base_velocity_limit", None)
+    from .limits import FloatingBaseVelocityLimit
+
     cl = [l for l in limits if type(l) is ConfigurationLimit]
     vl = [l for l in limits if type(l) is VelocityLimit]
     al = [l for l in limits if type(l) is AccelerationLimit]
     rest = [l for l in limits if type(l) not in (ConfigurationLimit, VelocityLimit, AccelerationLimit)]
     if len(cl) != 1 or len(vl) != 1 or cl[0].model is not model or vl[0].model is not model or len(al) > 1:
         return None
-    if rest != ([] if fb is None else [fb]):
+    # (an explicit list holds no FloatingBaseVelocityLimit, or ONE of this model -- the model's own or any other: the plan
+    # carries it to the device model, _explicit_floating_base_limit)
+    if rest and (len(rest) != 1 or type(rest[0]) is not FloatingBaseVelocityLimit or getattr(rest[0], "model", model) is not model):
         return None
     # (a VelocityLimit built with its own vector -- how joints without a model limit get one, velocity_limit.py:46-58 --
     # is the same table with other numbers: the device model of the call carries that vector instead of the model's)
@@ -502,6 +505,19 @@ def _default_limits_gain(model, limits):
             acc = np.zeros((3, model.nv))  # rows: a_max (0 = no bound on the coordinate), Delta_q_prev, has_configuration_limit
             acc[0, a.indices], acc[1, a.indices], acc[2, a.indices] = a.a_max, a.Delta_q_prev, a.has_configuration_limit
     return float(cl[0].config_limit_gain), acc, vmax
+
+
+def _explicit_floating_base_limit(model, limits):
+    """The FloatingBaseVelocityLimit the call's limits hold (``pink/solve_ik.py:94-105``: the model's own by default, or the
+    one written into an explicit list), or ``None``."""
+    from .limits import FloatingBaseVelocityLimit
+
+    if limits is None:
+        return getattr(model.ensure_limits(), "floating_base_velocity_limit", None)
+    for l in limits:
+        if type(l) is FloatingBaseVelocityLimit:
+            return l
+    return None
 
 
 def _barrier_key(bar):
@@ -746,10 +762,9 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
     kernel covers the model): the host only hands over ``q`` and the targets."""
     from .rollout import DeviceRollout
 
-    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons, fb = plan
     B = q.shape[0]
     pkey = None if posture is None else posture[:3]
-    fb = getattr(model.ensure_limits(), "floating_base_velocity_limit", None)  # part of the default limits (pink/solve_ik.py:94-105)
     fkey = None if fb is None else (fb.base_frame, tuple(float(v) for v in fb.twist_max))
     key = (id(model), _model_fingerprint(model, [sp[0] for sp in specs]), B, tuple(specs), float(dt), float(damping), pkey,
            int(max_iter), float(limit_gain), tuple(_barrier_key(b) for b in bars), fkey, _extras_key(extras),
@@ -798,11 +813,11 @@ def _solve_on_device(plan, dt, damping, safety_break, api, max_iter, out=None):
 
 
 def _slice_plan(plan, lo, hi):
-    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons = plan
+    model, q, specs, T, posture, extras, bars, limit_gain, acc, vmax, cons, fb = plan
     T = [t[lo:hi] for t in T] if isinstance(T, list) else T[lo:hi]
     if posture is not None and np.ndim(posture[3]) == 2:
         posture = posture[:3] + (posture[3][lo:hi],)
-    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc, vmax, cons
+    return model, q[lo:hi], specs, T, posture, extras, bars, limit_gain, acc, vmax, cons, fb
 
 
 def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver: str = "mi355x", damping: float = 1e-12,

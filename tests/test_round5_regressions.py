@@ -165,3 +165,38 @@ def test_velocity_bounds_on_the_floating_base_coordinates(backend, partly):
         assert np.abs(unbounded - V).max() < 1e-8 * max(1.0, np.abs(V).max())
     else:
         assert (np.abs(np.abs(ref[:, :6]) - vroot) < 1e-9).any() and np.abs(unbounded - V).max() > 1e-3  # some root bound is active
+
+
+@pytest.mark.parametrize("attached", [False, True])
+def test_a_floating_base_velocity_limit_written_into_the_limits_list(backend, attached):
+    """``limits=[ConfigurationLimit, VelocityLimit, FloatingBaseVelocityLimit]`` with a floating-base limit that is NOT the
+    model's attribute (``pink/solve_ik.py:94-105`` reads the attribute only for ``limits=None``): the plan carries the
+    limit of the call to the device model; a model that has one attached but is called with a list that omits it runs
+    without it."""
+    from pink_amd.limits import FloatingBaseVelocityLimit
+
+    m = build_chain(8, free_flyer=True, seed=7, limit=2.6, velocity=4.0)
+    rng = np.random.default_rng(29)
+    B, dt = 64, 5e-3
+    q = _draw_q(m, B, rng)
+    fbl = FloatingBaseVelocityLimit(m, None, max_linear_velocity=[0.2, 0.3, 0.25], max_angular_velocity=[0.4, np.inf, 0.5])
+    c0 = Configuration(m, q[0])
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    ft.set_target(c0.get_transform_frame_to_world("tool0") * exp6(0.3 * rng.normal(size=6)))
+    po = PostureTask(cost=1e-2)
+    po.set_target(m.neutral())
+    tasks = [ft, po]
+    if attached:
+        m.floating_base_velocity_limit = fbl
+        limits = [ConfigurationLimit(m), VelocityLimit(m)]  # (the list omits the attached limit: the call runs without it)
+    else:
+        limits = [ConfigurationLimit(m), VelocityLimit(m), fbl]
+    try:
+        V = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt, limits=limits)
+        assert pink_amd.last_solve_stats()["route"] == "device"
+        ref = _per_configuration(m, q, lambda b: tasks, dt, 8, limits=limits)
+        assert np.abs(V[:8] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+        bounded = np.abs(V[:, :3]).max() <= 0.3 + 1e-9
+        assert bounded == (not attached)
+    finally:
+        m.floating_base_velocity_limit = None
