@@ -37,6 +37,14 @@ def emu(built):
     return EmuSolver(lib)
 
 
+@pytest.fixture
+def emu_async(emu):
+    """The emulator behind the ASYNCHRONOUS half of BatchSolver's surface (page-locked arrays, copy / result streams, two
+    compute streams): everything completes immediately, so the host logic of the pipelined array call -- ranges, frozen
+    targets, results written into page-locked arrays by the kernel -- runs under ``-m "not gpu"`` too."""
+    return AsyncEmuSolver(emu.lib)
+
+
 class EmuSolver:
     """Same surface as pink_amd.batch_solver.BatchSolver.solve/stack, on the emulator."""
 
@@ -195,3 +203,35 @@ def gpu_solver(built):
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "pink_build_ik.npz"))
+
+
+class AsyncEmuSolver(EmuSolver):
+    """EmuSolver + put_async / get_async / wait_copies / select_stream / pinned_empty / is_pinned (see ``emu_async``)."""
+
+    def __init__(self, lib):
+        super().__init__(lib)
+        self._pinned, self.streams_selected, self.async_copies = [], [], 0
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        arr = np.empty(shape, dtype=dtype)
+        self._pinned.append(arr)  # (kept alive: the registry is by address)
+        return arr
+
+    def is_pinned(self, arr):
+        a = arr.ctypes.data
+        return any(p.ctypes.data <= a and a + arr.nbytes <= p.ctypes.data + p.nbytes for p in self._pinned)
+
+    def put_async(self, ptr, arr):
+        self.async_copies += 1  # (a pageable source is legal: the runtime stages it before the call returns)
+        self.put(ptr, arr)
+
+    def get_async(self, arr, ptr):
+        assert self.is_pinned(arr)
+        self.async_copies += 1
+        self.get(arr, ptr)
+
+    def wait_copies(self):
+        pass
+
+    def select_stream(self, index):
+        self.streams_selected.append(int(index))

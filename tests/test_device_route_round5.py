@@ -183,17 +183,25 @@ def test_frozen_targets_are_uploaded_once_and_new_targets_replace_them(backend):
     assert np.abs(V4[3] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()) and np.abs(V4 - V1).max() > 1e-3
 
 
-@pytest.mark.gpu
-def test_page_locked_pipelined_call_on_two_compute_streams(gpu_solver, monkeypatch):
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def async_backend(request):
+    """(solver, batch size): the emulator with the asynchronous surface (host logic of the pipelined call) / the MI355X."""
+    if request.param == "emu":
+        return request.getfixturevalue("emu_async"), 67
+    return request.getfixturevalue("gpu_solver"), 4099
+
+
+def test_page_locked_pipelined_call_on_two_compute_streams(async_backend, monkeypatch):
     """The pipelined array call as a control loop makes it -- q, targets and out= in page-locked memory, so uploads,
     range kernels (alternating between the handle's two compute streams) and downloads are all in flight at once -- with
     frozen targets, with dense rows (a constraint; barriers) and with one compute stream: bit for bit the single launch."""
     import sys
 
     sik = sys.modules["pink_amd.solve_ik"]
+    gpu_solver, B = async_backend
     set_default_solver(gpu_solver)
     try:
-        dt, B = 5e-3, 4099  # (ranges of unequal size)
+        dt = 5e-3  # (B: ranges of unequal size)
         m = build_chain(14, free_flyer=True, seed=3, limit=2.6, velocity=4.0)
         rng = np.random.default_rng(7)
         q = pink_amd.pinned_empty((B, m.nq))
@@ -247,17 +255,17 @@ def test_page_locked_pipelined_call_on_two_compute_streams(gpu_solver, monkeypat
         set_default_solver(None)
 
 
-@pytest.mark.gpu
-def test_page_locked_results_written_by_the_kernel(gpu_solver, monkeypatch):
+def test_page_locked_results_written_by_the_kernel(async_backend, monkeypatch):
     """A page-locked ``out`` (and the small status / iteration arrays behind it) is written by the whole-step kernel itself
     (mapped host memory) instead of being copied home range by range: same bits as the copies (PINKHIP_RESULT_COPIES=1)
     and as the single launch, also after ``q`` and the targets are refilled in place."""
     import sys
 
     sik = sys.modules["pink_amd.solve_ik"]
+    gpu_solver, B = async_backend
     set_default_solver(gpu_solver)
     try:
-        dt, B = 5e-3, 4099
+        dt = 5e-3
         m = build_chain(14, free_flyer=True, seed=3, limit=2.6, velocity=4.0)
         rng = np.random.default_rng(11)
         q = pink_amd.pinned_empty((B, m.nq))
