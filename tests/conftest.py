@@ -210,7 +210,7 @@ class AsyncEmuSolver(EmuSolver):
 
     def __init__(self, lib):
         super().__init__(lib)
-        self._pinned, self.streams_selected, self.async_copies = [], [], 0
+        self._pinned, self.streams_selected, self.async_copies, self.async_gets = [], [], 0, 0
 
     def pinned_empty(self, shape, dtype=np.float64):
         arr = np.empty(shape, dtype=dtype)
@@ -227,7 +227,7 @@ class AsyncEmuSolver(EmuSolver):
 
     def get_async(self, arr, ptr):
         assert self.is_pinned(arr)
-        self.async_copies += 1
+        self.async_gets += 1
         self.get(arr, ptr)
 
     def wait_copies(self):

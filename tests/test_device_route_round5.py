@@ -292,10 +292,13 @@ def test_page_locked_results_written_by_the_kernel(async_backend, monkeypatch):
             for rc in ("0", "1"):
                 monkeypatch.setenv("PINKHIP_RESULT_COPIES", rc)
                 pink_amd.clear_device_cache()
+                gets = getattr(gpu_solver, "async_gets", None)
                 for _ in range(2):
                     out[:] = np.nan
                     V = solve_ik_batch(cb, tasks, dt, out=out)
                     assert V is out and np.array_equal(V, V_one), (step, rc)
+                if gets is not None:  # (emulator: the result stream is used exactly when the copies are asked for)
+                    assert (gpu_solver.async_gets > gets) == (rc == "1") and set(gpu_solver.streams_selected) == {0, 1}
             # the next control step: configurations and targets refilled in place
             q[:] = _draw_q(m, B, rng)
             block[:, :, 9:] += 0.01 * rng.normal(size=(2, B, 3))
