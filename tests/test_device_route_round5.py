@@ -305,3 +305,45 @@ def test_page_locked_results_written_by_the_kernel(async_backend, monkeypatch):
     finally:
         pink_amd.clear_device_cache()
         set_default_solver(None)
+
+
+def test_a_batch_outside_its_limits_never_hands_out_velocities(async_backend, monkeypatch):
+    """``Configuration.check_limits`` (``pink/solve_ik.py:260``) runs on the whole batch; in the pipelined call the range
+    kernels are already writing into a page-locked ``out`` when the check fails: the exception propagates, the array is
+    blanked (NaN) and the next call with repaired configurations is served normally."""
+    import sys
+
+    from pink_amd.exceptions import NotWithinConfigurationLimits
+
+    sik = sys.modules["pink_amd.solve_ik"]
+    solver, B = async_backend
+    set_default_solver(solver)
+    try:
+        dt = 5e-3
+        m = build_chain(14, free_flyer=True, seed=3, limit=2.6, velocity=4.0)
+        rng = np.random.default_rng(13)
+        q = pink_amd.pinned_empty((B, m.nq))
+        q[:] = _draw_q(m, B, rng)
+        c0 = Configuration(m, q[0])
+        ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+        T0 = c0.get_transform_frame_to_world("tool0")
+        ft.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=pink_amd.pinned_empty((B, 12)))
+        po = PostureTask(cost=5e-2)
+        po.set_target(m.neutral())
+        tasks = [ft, po]
+        cb = ConfigurationBatch(m, q)
+        out = pink_amd.pinned_empty((B, m.nv))
+        monkeypatch.setattr(sik, "_PIPELINE_MIN_B", 64)
+        good = solve_ik_batch(cb, tasks, dt, out=out).copy()
+        bad_b, bad_i = B - 3, 7 + 4  # (a joint behind the free flyer, in the last range)
+        keep = q[bad_b, bad_i]
+        q[bad_b, bad_i] = 2.6 + 0.5
+        out[:] = 0.0
+        with pytest.raises(NotWithinConfigurationLimits):
+            solve_ik_batch(cb, tasks, dt, out=out)
+        assert np.isnan(out).all()
+        q[bad_b, bad_i] = keep
+        assert np.array_equal(solve_ik_batch(cb, tasks, dt, out=out), good)
+    finally:
+        pink_amd.clear_device_cache()
+        set_default_solver(None)
