@@ -33,7 +33,7 @@ for solver in os.environ.get("PINKHIP_FUZZ_KERNELS", "sweep,sweepx,packed").spli
             print("  seed", sd, "->", str(exc)[:200], flush=True)
     print(f"  {len(bad)} failing seeds: {bad}", flush=True)
     k = ps.kkt_certificate(s, range(first, first + count // 8))
-    print(f"  oracle verdicts \"inconsistent\" refuted by a certified point: {ps.REFUTED}; accepted on their certificate instead of on dq: {len(ps.CERTIFIED)}", flush=True)
-    del ps.REFUTED[:], ps.CERTIFIED[:]
+    print(f"  oracle verdicts \"inconsistent\" refuted by a certified point: {ps.REFUTED}; accepted on their certificate AND the exact-arithmetic anchor instead of on dq: {len(ps.CERTIFIED)} (anchor not computable: {len(ps.EXACT_UNSETTLED)})", flush=True)
+    del ps.REFUTED[:], ps.CERTIFIED[:], ps.EXACT_UNSETTLED[:]
     print(f"{solver}: {count} seeds, {n} feasible instances within tolerance, statuses equal (but for the refuted verdicts); "
           f"KKT certificates {k}; {time.time() - t0:.1f} s", flush=True)

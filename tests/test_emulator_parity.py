@@ -97,6 +97,11 @@ def test_fuzz_weakly_regularised(emu):
     the hand-over to the Goldfarb-Idnani code (80013: coordinates without bounds at 1e2 before; 80291: NaN behind
     status 0 before; 80135, 102469: false "inconsistent")."""
     assert ps.fuzz(emu, [80011, 80013, 80015, 80037, 80135, 80261, 80291, 80389, 102469, 520171, 537045], ill=True) > 20
+    # 415035 (cond(H) 1.9e9): |dq - dq_ref| = 1.3e-6 is beyond cond eps |x|, so the draw is accepted on its certificate --
+    # and on the exact-arithmetic anchor: the kernel's point is not farther from the exact minimiser than 10 x the oracle's
+    del ps.CERTIFIED[:], ps.EXACT_UNSETTLED[:]
+    assert ps.fuzz(emu, [415035], ill=True) >= 1
+    assert [c[:2] for c in ps.CERTIFIED] == [(415035, 0)] and not ps.EXACT_UNSETTLED
 
 
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):
