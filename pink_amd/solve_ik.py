@@ -484,7 +484,7 @@ def _default_limits_gain(model, limits):
     vl = [l for l in limits if type(l) is VelocityLimit]
     al = [l for l in limits if type(l) is AccelerationLimit]
     rest = [l for l in limits if type(l) not in (ConfigurationLimit, VelocityLimit, AccelerationLimit)]
-    if len(cl) != 1 or len(vl) != 1 or cl[0].model is not model or vl[0].model is not model or len(al) > 1:
+    if len(cl) != 1 or len(vl) > 1 or cl[0].model is not model or (vl and vl[0].model is not model) or len(al) > 1:
         return None
     # (an explicit list holds no FloatingBaseVelocityLimit, or ONE of this model -- the model's own or any other: the plan
     # carries it to the device model, _explicit_floating_base_limit)
@@ -493,7 +493,9 @@ def _default_limits_gain(model, limits):
     # (a VelocityLimit built with its own vector -- how joints without a model limit get one, velocity_limit.py:46-58 --
     # is the same table with other numbers: the device model of the call carries that vector instead of the model's)
     vmax = None
-    if not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
+    if not vl:  # (a list without a VelocityLimit: no velocity rows -- the table of the call bounds no coordinate)
+        vmax = np.full(model.nv, np.inf)
+    elif not np.array_equal(vl[0].velocity_limit, np.asarray(model.velocityLimit, dtype=float)):
         # (entries on a free-flyer's tangent coordinates become the box of the root coordinates: DeviceRollout)
         vmax = np.ascontiguousarray(vl[0].velocity_limit, dtype=np.float64)
     acc = None

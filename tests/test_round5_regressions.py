@@ -200,3 +200,25 @@ def test_a_floating_base_velocity_limit_written_into_the_limits_list(backend, at
         assert bounded == (not attached)
     finally:
         m.floating_base_velocity_limit = None
+
+
+def test_a_limits_list_without_a_velocity_limit(backend):
+    """``limits=[ConfigurationLimit(model)]``: Pink stacks the rows of the limits it is given and nothing else
+    (``pink/solve_ik.py:107-113``) -- the device route serves the call with a velocity table that bounds no coordinate."""
+    m = build_chain(7, seed=3, limit=2.8, velocity=0.5)
+    rng = np.random.default_rng(31)
+    B, dt = 64, 5e-3
+    q = _draw_q(m, B, rng)
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    ft.set_target(Configuration(m, q[0]).get_transform_frame_to_world("tool0") * exp6(0.3 * rng.normal(size=6)))
+    po = PostureTask(cost=1e-2)
+    po.set_target(m.neutral())
+    tasks = [ft, po]
+    limits = [ConfigurationLimit(m, 0.6)]
+    V = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt, limits=limits)
+    assert pink_amd.last_solve_stats()["route"] == "device"
+    ref = _per_configuration(m, q, lambda b: tasks, dt, 8, limits=limits)
+    assert np.abs(V[:8] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    assert np.abs(V).max() > 0.5 + 1e-3  # (faster than the model's velocity limit would allow)
+    bounded = solve_ik_batch(ConfigurationBatch(m, q), tasks, dt)
+    assert np.abs(bounded).max() <= 0.5 + 1e-9
