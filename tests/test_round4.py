@@ -120,7 +120,8 @@ def test_explicit_default_limits_take_the_device_route(backend):
     assert pink_amd.last_solve_stats()["route"] == "device"
     v_a = solve_ik_batch(batch, [ft, po], dt, limits=lim, device_kinematics=False)
     assert np.abs(v_d - v_a).max() < 1e-8 * max(1.0, np.abs(v_a).max())
-    for lim in ([ConfigurationLimit(m)],):  # (a list that is not the defaults: no VelocityLimit)
+    # (round 5: a list without a VelocityLimit is served too -- tests/test_round5_regressions.py)
+    for lim in ([VelocityLimit(m)],):  # (a list the device tables cannot hold: no ConfigurationLimit)
         v_h = solve_ik_batch(batch, [ft, po], dt, limits=lim)
         # (not the whole-step kernel: the limits are evaluated on the host, the FrameTask rows formed on the device)
         assert pink_amd.last_solve_stats()["route"] == "hybrid"
