@@ -79,6 +79,16 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #ifndef PINKHIP_SWEEP_ROUTE_COND
 #define PINKHIP_SWEEP_ROUTE_COND 1e10
 #endif
+// Box-only instantiations (MD = 0): single principal pivoting instead of the Goldfarb-Idnani trips (see "principal
+// pivoting" below).  0 restores round 5's loop (A/B: profiles/ab_ppm_r06.txt)
+#ifndef PINKHIP_SWEEP_PPM
+#define PINKHIP_SWEEP_PPM 1
+#endif
+// trips after which the principal pivoting switches from the largest-infeasibility rule to Murty's least-index rule
+// (finite for the P-matrices strictly convex box QPs give: Murty 1974; Judice & Pires 1994 with upper bounds)
+#ifndef PINKHIP_SWEEP_PPM_MURTY_AFTER
+#define PINKHIP_SWEEP_PPM_MURTY_AFTER(nv) (4 * (nv) + 20)
+#endif
 
 namespace pinkhip {
 
@@ -101,6 +111,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   constexpr int NT = NV + MD;
   static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
   constexpr bool DENSE = MD > 0;
+  constexpr bool PPM = !DENSE && PINKHIP_SWEEP_PPM;
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;
@@ -470,7 +481,60 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     // (a) entering constraint, for the groups that have none pending: the violated constraint that is farthest away
     // in the metric of the objective, violation / sqrt(n^T Z n) with Z the reduced inverse Hessian -- n^T Z n is the
     // diagonal entry -T[i][i] (free coordinate i: Z_ii; inactive row: g Z g^T).
-    if (wave_any(running && need_sel)) {
+    // ---- principal pivoting (box-only instantiations) ----------------------------------------------------------
+    // The KKT conditions of a strictly convex box QP are a linear complementarity problem with a P-matrix, and the
+    // tableau is its principal transform on the free set: x of the free coordinates, multipliers u of the fixed ones.
+    // Instead of Goldfarb-Idnani's trip -- entering constraint, ratio test over the multipliers, a second column and a
+    // second pivot when a multiplier blocks, the entering constraint kept pending -- every trip exchanges ONE index
+    // whose complementarity condition fails: a free coordinate outside its box is fixed at the bound it violates, a
+    // fixed one whose multiplier has the wrong sign is freed.  Which one: the largest |violation|^2 / |T_pp| (the
+    // change of the objective the exchange brings; for a violated bound Goldfarb-Idnani's reduced steepest edge).
+    // No ratio test, no pending constraint, one column and one pivot per trip; scripts/multi_pivot_study.py counted
+    // 26.5 trips on the headline batch against 28.5 of the dual method (whose partial steps are trips of their own),
+    // where exchanging SEVERAL indices per trip (block principal pivoting, candidate lists) needs 40 .. 80 pivots.
+    // The iterates are neither primal nor dual feasible and nothing decreases monotonically: after
+    // PINKHIP_SWEEP_PPM_MURTY_AFTER trips a group continues with Murty's least-index rule (finite for P-matrices);
+    // the closing KKT certificate and the hand-over behind it are what they were.
+    int dualbit = 0;
+    double cand = 0.0;
+    if constexpr (PPM) {
+      if (wave_any(running)) {
+        const double slo = x - lbv, sup = ubv - x;
+        const bool fr = state == 0;
+        const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
+        const bool vdu = in && !fr && u < 0.0;
+        // what would go to zero if this lane's index were exchanged: the distance to the violated bound resp. the
+        // gradient entry behind the multiplier (g = -phi u)
+        const double viol = fr ? (vlo ? slo : sup) : u;
+        cand = fr ? -viol : -phi * u;
+        if (fr && !vlo) cand = sup;  // (upper bound: ub - x <-> x - ub)
+        const float zf = fabsf(static_cast<float>(tdiag));
+        const float wz = (zf > 1e-30f) ? approx_rcpf(zf) : 1e30f;
+        const float fv = static_cast<float>(viol);
+        float key = -(fv * fv) * wz;
+        if (it > PINKHIP_SWEEP_PPM_MURTY_AFTER(nv)) key = static_cast<float>(li - 64);  // least index
+        const bool has = fr ? (vlo || vup) : vdu;
+        const int id = li | ((fr && !vlo) ? 64 : 0) | (fr ? 0 : 128);
+        const float best32 = group_min32<W>(has ? key32_packf(key, id) : 3.0e38f);
+        const bool none = !(best32 < 0.0f);
+        bool bad = false;
+        if (empty_box_somewhere) bad = group_first_lane<W>((vlo && vup) || (!fr && in && (vlo || vup))) < W;
+        if (running) {
+          if (bad) {
+            status = STATUS_INFEASIBLE;
+            running = false;
+          } else if (none) {
+            running = false;  // optimal
+          } else {
+            const int pl = key32_payload(best32);
+            src = pl & 63;
+            kind = (pl >> 6) & 1;
+            dualbit = pl >> 7;
+          }
+        }
+      }
+    }
+    if (!PPM && wave_any(running && need_sel)) {
       const bool sel = running && need_sel;
       const double slo = x - lbv, sup = ubv - x;
       const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
@@ -604,6 +668,46 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       col = column_of(act ? src : -1);
     }
     if (li == src) col = tdiag;
+    int pi = -1;
+    double pvt = 1.0, rp = 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
+    double sg = -1.0;
+    if constexpr (PPM) {
+      // (c') the exchange: lane src's quantity `cand` goes to zero along the column, nu = -cand / T[src][src]; the free
+      // coordinates move by -col nu, the multipliers of the fixed ones by -phi col nu -- whatever that does to their
+      // signs: the next selection sees it
+      const double num = group_bcast<W>(cand, src);
+      const double pv = group_bcast<W>(tdiag, src);
+      PINKHIP_TICK(4);  // column
+      const double rpv = fast_rcp(pv);
+      const double nu = act ? -num * rpv : 0.0;
+      const double d = col * nu;
+      x = fma(-xfree, d, x);
+      u = fma(-phi, d, u);
+      if (act) {
+        pi = src;
+        pvt = pv;
+        rp = rpv;
+        // freeing: nonbasic -> basic (sweep), fixing: basic -> nonbasic (reverse sweep)
+        sg = dualbit ? 1.0 : -1.0;
+        if (li == src) {
+          if (dualbit) {
+            state = 0;
+            x += nu;  // (off its bound, to where its gradient entry is zero)
+            u = 0.0;
+            phi = 0.0;
+            xfree = 1.0;
+          } else {
+            state = kind + 1;
+            x = (kind == 0) ? lbv : ubv;
+            phi = (kind == 0) ? -1.0 : 1.0;
+            xfree = 0.0;
+            u = fabs(nu);
+          }
+        }
+      }
+      PINKHIP_TICK(5);
+      PINKHIP_TICK(6);
+    } else {
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
     double cand = (kind == 0 ? lbv : ubv) - x;
@@ -691,8 +795,6 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     PINKHIP_TICK(5);  // step lengths, x / u update
     // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves; the
     // entering one stays pending and its column is extracted again from the new tableau)
-    int pi = -1;
-    double pvt = 1.0, rp = 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
     if (do_add) {
       pi = src;
       pvt = pv;
@@ -729,10 +831,11 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       }
     }
     PINKHIP_TICK(6);  // column of the leaving constraint
+    // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
+    // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
+    sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
+    }
     {
-      // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
-      // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
-      const double sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
       double t = col * rp;
       double cp = col;
       if (li == pi) {

@@ -21,8 +21,12 @@ best=None
 for h,ls in hdr.items():
     lo,hi=min(ls),max(ls)
     n=sum(1 for k in range(lo,hi) if 'v_fmac_f64_dpp' in lines[k])
-    if best is None or (hi-lo)>(best[3]-best[2]): best=(h,n,lo,hi)
-h,n,lo,hi=best
+    # (the tableau loop is the one that reads a column with the VGPR index mode; the stacking loops of the hand-over code
+    # can span more lines)
+    idx=sum(1 for k in range(lo,hi) if 's_set_gpr_idx_on' in lines[k])
+    score=(idx>0,hi-lo)
+    if best is None or score>best[4]: best=(h,n,lo,hi,score)
+h,n,lo,hi,_=best
 # extend hi to next block label after last
 while hi+1<ke and not re.match(r'^(\.LBB\d+_\d+):|^; %bb\.(\d+):',lines[hi+1]): hi+=1
 print("loop header",h,"lines",lo+1,hi+1,"dpp fmacs",n)
