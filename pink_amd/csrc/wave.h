@@ -310,6 +310,14 @@ __device__ __forceinline__ float approx_rcpf(float x) { return __builtin_amdgcn_
 
 // ---- sub-wave groups: W lanes per QP, 64/W QPs per wavefront (W = 8, 16, 32) ----
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0; }
+// `if (lanes_on(p)) { body }` for a predicate that is uniform over each group of lanes that exchange data in `body`:
+// the lanes of the other groups are switched off (EXEC) for the body instead of carrying selects through it.  The body
+// must ALSO be written so that a lane with p false changes nothing when it runs it (selects on p): that is what the
+// CPU wave emulator executes -- its cross-lane primitives are rendezvous of all 64 lanes -- and here the compiler
+// folds those selects away inside the branch.
+__device__ __forceinline__ bool lanes_on(bool p) { return p; }
+// bit l = the predicate of lane l (a scalar)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // A value every lane of the wave agrees on, as a scalar the compiler keeps in an SGPR and branches on with s_cbranch_scc.
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -208,6 +208,18 @@ inline bool wave_any(bool p) {
   emu_rendezvous(15);
   return r;
 }
+// (wave.h: on the device the other lanes are switched off; here every lane runs the body, which masks itself)
+inline bool lanes_on(bool) { return true; }
+inline unsigned long long wave_ballot(bool p) {
+  Emu &e = emu();
+  e.slot_i[e.cur] = p ? 1 : 0;
+  emu_rendezvous(42);
+  unsigned long long r = 0;
+  for (int l = 0; l < kWave; ++l)
+    if (e.slot_i[l]) r |= 1ull << l;
+  emu_rendezvous(43);
+  return r;
+}
 template <int W>
 inline int group_first_lane(bool p) {
   Emu &e = emu();
