@@ -365,6 +365,49 @@ def _pack_configurations_per_instance(configurations, tasks, dt, damping, limits
                       dense_rows=dense_rows, barriers=barrier_terms, batch_size=B, equality_rows=equality_rows)
 
 
+_DECLINED = {"reason": None}
+_ROUTE_WARNED = set()
+
+
+def _declined(reason: str):
+    """``return _declined("...")``: the device route is not taken, and why (the first term that declined it; read by the
+    one-shot warning of :func:`solve_ik_batch`).  Returns ``None`` like every plan function does when it declines."""
+    if _DECLINED["reason"] is None:
+        _DECLINED["reason"] = reason
+    return None
+
+
+def _stack_signature(tasks, limits, barriers, constraints) -> tuple:
+    def names(objs):
+        if objs is None:
+            return None
+        objs = list(objs)
+        if objs and isinstance(objs[0], (list, tuple)):  # per-instance lists: the first instance stands for the batch
+            objs = list(objs[0])
+        return tuple(type(o).__name__ for o in objs)
+
+    return names(tasks), names(limits), names(barriers), names(constraints)
+
+
+def _report_route(route: str, B: int, tasks, limits, barriers, constraints, strict_route, warn: bool = True) -> None:
+    """A batch of 64 and more that leaves the device route says so ONCE per (stack signature, route) -- the reference's
+    own one-shot warning style (``pink/configuration.py:188-201``) -- and raises when the caller asked for
+    ``strict_route="device"``: the routes differ by 70 .. 2000 x in cost."""
+    reason = _DECLINED["reason"] or "a term the device tables do not hold"
+    if strict_route is not None and strict_route != route:
+        raise PinkError(f"strict_route={strict_route!r}: this call would take the {route!r} route ({reason})")
+    if B < 64 or route == "device" or not warn:
+        return
+    key = (_stack_signature(tasks, limits, barriers, constraints), route)
+    if key not in _ROUTE_WARNED:
+        _ROUTE_WARNED.add(key)
+        import logging
+
+        logging.getLogger("pink_amd").warning(
+            "solve_ik_batch: B = %d leaves the device route for the %r route (%s); pass device_kinematics=True or "
+            "strict_route='device' to make this an error", B, route, reason)
+
+
 def _spec_of(task):
     """``(frame, position cost, orientation cost, gain, lm_damping)`` of a FrameTask, hashable; a RelativeFrameTask has
     ``(frame, root)`` in the first place (a relative slot of the device model, ``pink_amd/rollout.py``)."""
@@ -394,21 +437,21 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
     model = configurations.model if hasattr(configurations, "model") else configurations[0].model
     lim = _default_limits_gain(model, limits)
     if lim is None:
-        return None
+        return _declined("limits other than one ConfigurationLimit + at most one VelocityLimit / AccelerationLimit / FloatingBaseVelocityLimit of this model")
     gain, acc, vmax = lim
     for bar in barriers or ():
         # position barriers with the default class-K function and spherical barriers, neither with a safe displacement of
         # its own, are formed on chip
         if type(bar).compute_safe_displacement is not Barrier.compute_safe_displacement:
-            return None
+            return _declined(f"{type(bar).__name__} with a safe displacement of its own")
         if type(bar) is PositionBarrier:
             if not bar.identity_gain_function:
-                return None
+                return _declined("PositionBarrier with a class-K function of its own")
         elif type(bar) is not BodySphericalBarrier or np.ndim(bar.gain) > 1 or np.size(bar.gain) != 1:
-            return None
+            return _declined(f"barrier {type(bar).__name__}: only PositionBarrier and BodySphericalBarrier rows are formed on chip")
     plan = _device_kinematics_plan_tasks(configurations, tasks)
     if plan is None:
-        return None
+        return _declined("a task the whole-step kernel does not form (FrameTask / RelativeFrameTask, one PostureTask, table-formed tasks shared by the batch)")
     model, q, specs, T, posture, extras = plan
     specs = list(specs)
     as_list = isinstance(T, (list, tuple))
@@ -431,7 +474,7 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
         per_instance = len(constraints) == B and isinstance(constraints[0], (list, tuple))
         flat = [t for c in constraints for t in c] if per_instance else list(constraints)
         if not flat or any(type(t) not in (FrameTask, RelativeFrameTask) for t in flat):
-            return None  # (a RelativeFrameTask constraint is a relative slot: the same rows with a signed ancestor table)
+            return _declined("constraints= holds a task that is not a FrameTask / RelativeFrameTask")  # (a RelativeFrameTask constraint is a relative slot: the same rows with a signed ancestor table)
         cfg_like = configurations
         if per_instance and hasattr(configurations, "q") and not isinstance(configurations, (list, tuple)):
             # (a ConfigurationBatch next to per-instance constraint objects: the reader of per-instance task lists only wants
@@ -441,10 +484,10 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
             cfg_like = [types.SimpleNamespace(model=model, q=row) for row in configurations.q]
         cplan = _device_kinematics_plan_tasks_raw(cfg_like, constraints)
         if cplan is None or cplan[4] is not None or cplan[5]:
-            return None
+            return _declined("constraints= the device tables cannot hold")
         _, _, cspecs, cT, _, _ = cplan
         if len(cspecs) > 2:
-            return None  # (csrc/dispatch.h: kRolloutMaxEqFrames)
+            return _declined("more than two constraint frame tasks")  # (csrc/dispatch.h: kRolloutMaxEqFrames)
         for k, sp in enumerate(cspecs):
             tg = cT[k] if isinstance(cT, (list, tuple)) else cT[:, k]
             slot = add_slot((sp[0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 0.0), tg)
@@ -456,11 +499,11 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
             for f in ((bar.frame,) if type(bar) is PositionBarrier else tuple(bar.frames)):
                 if f not in have:
                     if not any(fr.name == f for fr in getattr(model, "frames", ())):
-                        return None
+                        return _declined(f"barrier frame {f!r} is not a frame of the model")
                     add_slot((f, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 0.0), ident)
                     have.add(f)
     if len(specs) > 32 or any(isinstance(sp[0], tuple) and i >= 16 for i, sp in enumerate(specs)):
-        return None
+        return _declined("more frame slots than the device model holds (32; relative slots among the first 16)")
     return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons), _explicit_floating_base_limit(model, limits)
 
 
@@ -849,6 +892,11 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     :func:`pink_amd.pinned_empty` (page-locked), together with ``q`` and the per-instance target arrays, the device
     route moves every byte of the call by DMA while the kernels of the neighbouring ranges run.
 
+    ``strict_route`` (keyword): ``"device"``, ``"hybrid"`` or ``"host-evaluated"`` -- raise :class:`PinkError` naming the
+    first term that declined it when the call would take another route (:func:`last_solve_stats` tells which one a call
+    took).  Without it a batch of 64 and more that leaves the device route logs ONE warning per stack signature and
+    route (logger ``pink_amd``): the routes differ by orders of magnitude in cost.
+
     ``device_ids``: shard the batch contiguously over these GPUs from this one process (one handle, stream and staging
     area per device, a thread each): no collective, results concatenated on the host.
     """
@@ -856,6 +904,10 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     from .runtime import default_solver
 
     max_iter = int(kwargs.get("max_iter", 0))
+    strict_route = kwargs.get("strict_route")
+    if strict_route not in (None, "device", "hybrid", "host-evaluated"):
+        raise PinkError(f"strict_route={strict_route!r}: None, 'device', 'hybrid' or 'host-evaluated'")
+    _DECLINED["reason"] = None
     if device_ids is not None:
         if solver_handle is not None:
             raise PinkError("device_ids= and solver_handle= are mutually exclusive")
@@ -879,6 +931,9 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
         from .batch_solver import BatchResult
         from .rollout import NoWholeStepKernel
 
+        if strict_route not in (None, "device"):
+            raise PinkError(f"strict_route={strict_route!r}: this call would take the 'device' route")
+
         try:
             if pool is not None:
                 from .sharding import shard_bounds
@@ -899,10 +954,11 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
             # tables of dispatch.h carry): the host-evaluated path below serves it, unless the caller insisted
             if device_kinematics:
                 raise
-            plan = None
+            plan = _declined("no instantiation of the whole-step kernel holds this model's rows")
         else:
             result = BatchResult(dq, status, iters, path)
             _record_stats(result, "device")
+            _report_route("device", len(configurations), tasks, limits, barriers, constraints, strict_route)
             if status.any():
                 raise NoSolutionFound(None, result, result.failed_indices(), status[status != 0])
             if scaled:  # the kernel wrote v = dq / dt (pink/solve_ik.py:274)
@@ -914,6 +970,8 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
                 return np.divide(dq, dt, out=out)
             return np.divide(dq, dt, out=dq)  # v = dq / dt, in place: dq is this call's own array
     B = len(configurations)
+    if strict_route == "device":  # (decided before any work is done)
+        _report_route("hybrid or host-evaluated", B, tasks, limits, barriers, constraints, strict_route)
     if B and hasattr(configurations, "check_limits"):
         configurations.check_limits(safety_break=safety_break)
     elif B:
@@ -928,12 +986,14 @@ def solve_ik_batch(configurations: Sequence, tasks: Sequence, dt: float, solver:
     api = solver_handle or default_solver()
     if (device_kinematics is None and (B >= 64 or rows_only) and pool is None and kwargs.get("gpu_frame_tasks", True)
             and hasattr(api, "fk_frame_tasks") and hasattr(api, "solve_raw")):
-        result = _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constraints, api, max_iter)
+        result = _solve_hybrid(configurations, tasks, dt, damping, limits, barriers, constraints, api, max_iter) if strict_route in (None, "hybrid") else None
         if result is not None:
             _record_stats(result, "hybrid")
+            _report_route("hybrid", B, tasks, limits, barriers, constraints, strict_route, warn=not rows_only)
             if not result.all_found:
                 raise NoSolutionFound(None, result, result.failed_indices(), result.status[result.status != 0])
             return np.divide(result.dq, dt, out=out if out is not None else result.dq)
+    _report_route("host-evaluated", B, tasks, limits, barriers, constraints, strict_route, warn=device_kinematics is None and not rows_only)
     batch = pack_configurations(configurations, tasks, dt, damping, limits, barriers, pool[0] if pool else solver_handle,
                                 gpu_frame_tasks=bool(kwargs.get("gpu_frame_tasks", True)), constraints=constraints)
     result = api.solve(batch, max_iter=max_iter)

@@ -89,15 +89,19 @@ class FrameTask(Task):
         the array becomes read-only and :func:`pink_amd.solve_ik_batch` uploads it to a device ONCE per cached device state
         instead of with every call (6.3 MB per frame task at B = 65 536: three fifths of what a call at the headline
         shape sends across PCIe are targets).  Without it every call uploads the array as it is then -- a control loop
-        may refill it in place between two calls."""
+        may refill it in place between two calls.
+
+        The task keeps a READ-ONLY VIEW of the array; the caller's own array object is left as it is (an ``out=`` buffer
+        can be handed to the next :meth:`set_target_poses`, which ends the freeze).  The promise is the caller's: a
+        write into the buffer while the freeze lasts is NOT seen by the device."""
         if self.target_poses is None:
             raise TargetNotSet(f"no per-instance targets set for frame '{self.frame}'")
         arr = self.target_poses
         if getattr(arr, "frozen_token", None) is None:
-            arr.flags.writeable = False
-            arr = arr.view(FrozenTargets)
-            arr.frozen_token = next(_FREEZE_TOKENS)
-            self.target_poses = arr
+            view = arr.view(FrozenTargets)
+            view.flags.writeable = False  # (the view's flag: the base array stays writeable)
+            view.frozen_token = next(_FREEZE_TOKENS)
+            self.target_poses = view
 
     def compute_error(self, configuration) -> np.ndarray:
         """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``

@@ -400,11 +400,21 @@ def test_failed_solves_are_not_integrated_and_stay_visible(api, mode):
         ro.run(3)
     idx, status, step = ro.failures()
     assert np.array_equal(info.value.indices, idx) and set(idx) <= {0, 1, 2} and idx.size >= 1
-    assert (status == 1).all() and (step == 0).all()  # STATUS_MAX_ITER at the very first step, still visible after 3
+    # STATUS_MAX_ITER, still visible after 3 steps, with the step it happened at (which one depends on how many exchanges
+    # the solver needs from ITS starting basis: the principal pivoting of round 6 starts from a guessed active set and
+    # may get through a first step that Goldfarb-Idnani's start at the unconstrained minimum did not)
+    assert (status == 1).all() and (step >= 0).all() and (step <= 2).all()
     q = ro.configurations()
-    assert np.array_equal(q[idx], q0[idx])  # frozen: the partial iterate was never applied
+    first = idx[step == 0]
+    assert np.array_equal(q[first], q0[first])  # frozen: the partial iterate was never applied
     ok = np.setdiff1d(np.arange(B), idx)
     assert np.isfinite(q).all() and ok.size >= 3
+    # ... and frozen for good: further steps raise again and leave the failed robots where they were
+    with pytest.raises(NoSolutionFound):
+        ro.run(2)
+    idx2, status2, step2 = ro.failures()
+    assert set(idx) <= set(idx2) and np.array_equal(ro.configurations()[idx], q[idx])
+    assert np.array_equal(step2[np.isin(idx2, idx)], step) and np.array_equal(status2[np.isin(idx2, idx)], status)
     ro.free()
     # initial configurations outside the joint limits are refused like solve_ik's check_limits does
     bad = q0.copy()

@@ -241,8 +241,12 @@ def test_solver_path_is_reported_per_instance(backend, request, monkeypatch):
     rd = s.solve(deficient)
     assert (rd.status == 0).all() and (rd.path == 3).all()
     rw = s.solve(weak)
-    assert (rw.status == 0).all() and (rw.path == 2).all() and rw.iters.max() < 200
-    assert rw.path_fractions() == {"tableau": 0.0, "handover": 0.0, "routed": 1.0, "goldfarb_idnani": 0.0}
+    # (round 6: the conditioning estimate behind `routed` is taken on the coordinates the start sweeps in -- the guessed
+    # free set -- so an instance whose ill-conditioned directions are held by bounds stays on the tableau, and the KKT
+    # certificate decides; the packed run below is the check of the numbers either way)
+    assert (rw.status == 0).all() and np.isin(rw.path, (0, 1, 2)).all() and rw.iters.max() < 200
+    fr = rw.path_fractions()
+    assert fr["goldfarb_idnani"] == 0.0 and abs(sum(fr.values()) - 1.0) < 1e-12
     monkeypatch.setenv("PINKHIP_SOLVER", "packed")
     rp = s.solve(good)
     assert (rp.path == 3).all() and np.abs(rp.dq - r.dq).max() < 1e-10
