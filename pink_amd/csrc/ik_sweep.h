@@ -90,6 +90,16 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #ifndef PINKHIP_SWEEP_PPM_CRASH
 #define PINKHIP_SWEEP_PPM_CRASH 1
 #endif
+// ... and with dense rows: principal pivoting as long as every exchange is regular, the dual method behind it
+#ifndef PINKHIP_SWEEP_PPM_DENSE
+#define PINKHIP_SWEEP_PPM_DENSE 1
+#endif
+// development: why a group asked for the hand-over, in the thousands of iters[] (read with PINKHIP_SWEEP_NO_HANDOVER)
+#ifdef PINKHIP_SWEEP_DEBUG_WHY
+#define PINKHIP_WHY(k) why = (k) + 10 * status_before
+#else
+#define PINKHIP_WHY(k)
+#endif
 #ifndef PINKHIP_SWEEP_PPM_MURTY_AFTER
 #define PINKHIP_SWEEP_PPM_MURTY_AFTER(nv) (4 * (nv) + 20)
 #endif
@@ -115,7 +125,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   constexpr int NT = NV + MD;
   static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
   constexpr bool DENSE = MD > 0;
-  constexpr bool PPM = !DENSE && PINKHIP_SWEEP_PPM;
+  constexpr bool PPM = !DENSE && PINKHIP_SWEEP_PPM;                                  // box-only: the whole iteration
+  constexpr bool PPMD = DENSE && PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE;       // dense rows: in front of the dual method
+  constexpr bool PPX = PPM || PPMD;
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;
@@ -261,6 +273,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // (the smallest pivot decides afterwards: a group that met a non-positive one sweeps on through whatever that leaves
   // -- infinities, NaN -- and never iterates on it; one v_min per column instead of a compare and three selects)
   int status = STATUS_OPTIMAL;
+  int why = 0, status_before = 0;
   double pmin = INF;
   // per lane: state 0 = free coordinate / inactive row, 1 = fixed at lb / active row, 2 = fixed at ub
   int state = 0;
@@ -268,7 +281,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
   }
-  if constexpr (PPM && PINKHIP_SWEEP_PPM_CRASH) {
+  if constexpr (PPX && PINKHIP_SWEEP_PPM_CRASH) {
     // ---------------------------------------------------------------- principal pivoting: where it starts
     // Principal pivoting needs no feasibility of any kind from its starting basis, so it does not have to be the
     // unconstrained minimum (every coordinate swept in: NV sweeps, and then one pivot for every bound that ends up
@@ -347,7 +360,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   double x = 0.0, u = 0.0;
   {
     double vstart = in ? ci : 0.0;
-    if constexpr (PPM) {
+    if constexpr (PPX) {
       if (state != 0) vstart = -((state == 1) ? lbv : ubv);
     }
     const BcT cb = bcast_prepare<W>(vstart);
@@ -361,20 +374,29 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     if (dlane) u = hv + (r0 + r1);
     // principal pivoting keeps ONE quantity per coordinate: x of a free one, -g (the negated gradient entry, whose
     // sign is the test of the multiplier) of a fixed one -- both move by -col nu in an exchange
-    if constexpr (PPM) {
+    if constexpr (PPX) {
       if (state != 0) x -= ci;
+    }
+    if constexpr (PPMD) {
+      if (dlane) x = u;  // (... and per dense row: its slack while it is inactive, its multiplier while it is active)
     }
   }
   // n^T H^-1 n (the unreduced curvature along a constraint normal): the reference of the linear-dependence test.
   // Box-only problems never need it: a free coordinate always has curvature left.
-  const double zd0 = -tdiag;
+  // (started from a guessed active set the tableau does not hold it: a lower bound of its size stands in -- 1 / H_ii for
+  // a coordinate, |g|^2 / max H_ii for a row; the tests against it are 1e-6 and 1e-12, dependence leaves 1e-26)
+  double zd0 = -tdiag;
+  if constexpr (PPMD) {
+    const double hmax = -group_min<W>(in ? -hii : 0.0);
+    zd0 = (li < NV) ? approx_rcp(hii) : approx_rcp(ginv * ginv * hmax);
+  }
   // Conditioning estimate  max_i H_ii (H^-1)_ii <= cond(H)  (both diagonals are at hand).  Beyond the threshold the
   // explicitly updated inverse is not expected to certify its result (weakly regularised objectives: a rank-deficient
   // task stack made positive definite by `damping` alone, pink/solve_ik.py:55, examples/humanoid_jvrc.py:69-81): the
   // group skips the tableau iteration and goes to the Goldfarb-Idnani code right away instead of paying both.
   {
     const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
-    const double kest = -group_min<W>((PPM && state != 0) ? 0.0 : -(hii0 * zd0));
+    const double kest = -group_min<W>((PPX && state != 0) ? 0.0 : hii0 * tdiag);
     PINKHIP_TRACEF(li == 0, "[sweep g%d] kest %.3e\n", g, kest);
     if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;  // (NaN: routed)
   }
@@ -404,7 +426,19 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   double uplus = 0.0;
   // principal pivoting: the interval the lane's quantity has to lie in and the thresholds of the two tests
   double blo = lbv, bhi = ubv, tlo = thr_lo, thi = thr_up;
-  if constexpr (PPM) {
+  // (a dense row: slack resp. multiplier in [0, inf); the slack of an inactive row against the threshold of the dual
+  // method, u |g|^-1 < thr_d.  An equality that waits for its turn is no candidate, and its "violation" is its slack)
+  double thr_row = 0.0;
+  if constexpr (PPMD) {
+    thr_row = thr_d * fast_rcp(ginv);
+    if (li >= NV) {
+      blo = dlane ? 0.0 : -INF;
+      bhi = INF;
+      tlo = (dlane && dr >= n_eq) ? thr_row : -INF;
+      thi = 0.0;
+    }
+  }
+  if constexpr (PPX) {
     if (state != 0) {
       blo = (state == 1) ? -INF : 0.0;
       bhi = (state == 1) ? 0.0 : INF;
@@ -560,6 +594,40 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     }
   };
 
+  // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) of the tableau on pi (-1: none, with
+  // pvt = 1, rp = 0), col = column pi
+  auto pivot_on = [&](int pi, double col, double pvt, double rp, double sg) {
+    double t = col * rp;
+    double cp = col;
+    if (li == pi) {
+      // lane pi: its row becomes sg col / p -- as T[pi][j] - (1 - sg / p) col_j -- and the column the other lanes
+      // see at j = pi is p - sg, so that their entry T[m][pi] - t_m (p - sg) becomes sg t_m
+      t = 1.0 - sg * rp;
+      cp = pvt - sg;
+    }
+    const BcT xb = bcast_prepare<W>(cp);
+    const double nt = -t;
+    static_for<0, NT>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      tset(Jc, fma_bcast<W, j>(tget(Jc), xb, nt));
+    });
+    sdiag_run = fma(cp, nt, sdiag_run);  // (what the broadcast-FMA above just made of this lane's register li)
+    tdiag = (li == pi) ? -rp : tdiag - t * col;
+  };
+
+  // Which of the two iterations a group is in (group-uniform).  With dense rows the same exchange serves the rows -- an
+  // inactive row whose slack is negative is activated, an active inequality whose multiplier is negative is released; the
+  // lane of a row keeps slack resp. multiplier in the place of x resp. -g, and both move by -col nu like everything
+  // else -- but the rows bring the degenerate exchange (a normal that depends on the active ones has no curvature left
+  // and cannot be pivoted on) and the verdict "inconsistent".  Both are the dual method's: a group that meets an
+  // irregular pivot, or runs out of trips, releases every constraint whose multiplier has the wrong sign until none is
+  // left (`restoring`; the active set only shrinks: it ends) and continues with Goldfarb-Idnani's trips from that
+  // dual-feasible basis.  Equalities are activated first, in order, and never leave.
+  bool ppm_mode = PPX;
+  bool restoring = false;
+  const bool cand_lane = in || (DENSE && dlane && dr >= n_eq);
+  const bool eq_lane = DENSE && dlane && dr < n_eq;
+
   for (;;) {
     // (a) entering constraint, for the groups that have none pending: the violated constraint that is farthest away
     // in the metric of the objective, violation / sqrt(n^T Z n) with Z the reduced inverse Hessian -- n^T Z n is the
@@ -579,34 +647,68 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     // PINKHIP_SWEEP_PPM_MURTY_AFTER trips a group continues with Murty's least-index rule (finite for P-matrices);
     // the closing KKT certificate and the hand-over behind it are what they were.
     double viol = 0.0;
-    int fixed_src = 0;
-    if constexpr (PPM) {
-      if (wave_any(running)) {
+    int nb_src = 0;     // the index that is exchanged is nonbasic (enters the basis)
+    bool iseq = false;  // ... is the next equality
+    if constexpr (PPX) {
+      if (wave_any(running && ppm_mode)) {
+        const bool sel = running && ppm_mode;
         // one test for every coordinate: a free one against its box (with the usual thresholds), a fixed one through
-        // -g against (-inf, 0] at its lower bound resp. [0, inf) at its upper bound (exact sign)
+        // -g against (-inf, 0] at its lower bound resp. [0, inf) at its upper bound (exact sign); a dense row through
+        // its slack resp. multiplier against [0, inf)
         const double slo = x - blo, sup = bhi - x;
-        const bool vlo = in && slo < tlo, vup = in && sup < thi;
+        bool ok_lane = in, nonbasic = state != 0;
+        if constexpr (DENSE) {
+          nonbasic = (li < NV) ? (state != 0) : (state == 0);
+          // (on the way to the dual method only what holds a multiplier is looked at)
+          ok_lane = cand_lane && (!restoring || ((li < NV) ? (state != 0) : (state == 1)));
+        }
+        const bool vlo = ok_lane && slo < tlo, vup = ok_lane && sup < thi;
         viol = vlo ? slo : sup;
+        if constexpr (DENSE) {
+          if (eq_lane) viol = slo;  // (an equality's turn: its slack goes to zero whatever its sign)
+        }
         const float zf = fabsf(static_cast<float>(tdiag));
         const float wz = (zf > 1e-30f) ? approx_rcpf(zf) : 1e30f;
         const float fv = static_cast<float>(viol);
         float key = -(fv * fv) * wz;
-        if (it > PINKHIP_SWEEP_PPM_MURTY_AFTER(nv)) key = static_cast<float>(li - 64);  // least index
-        const float best32 = group_min32<W>((vlo || vup) ? key32_packf(key, li | (vlo ? 0 : 64) | (state ? 128 : 0)) : 3.0e38f);
-        if (running) {
-          if (!(best32 < 0.0f)) {
-            running = false;  // optimal
+        if (it > PINKHIP_SWEEP_PPM_MURTY_AFTER(nv + md)) key = static_cast<float>(li - 64);  // least index
+        const float best32 = group_min32<W>((vlo || vup) ? key32_packf(key, li | (vlo ? 0 : 64) | (nonbasic ? 128 : 0)) : 3.0e38f);
+        bool conv = false;
+        if (sel) {
+          if (DENSE && !restoring && eq_next < n_eq) {
+            src = NV + eq_next;
+            kind = 0;
+            nb_src = 1;
+            iseq = true;
+          } else if (!(best32 < 0.0f)) {
+            if (DENSE && restoring) {
+              ppm_mode = false;  // dual feasible: Goldfarb-Idnani's trips from here, this trip included
+              need_sel = true;
+            } else {
+              running = false;  // optimal
+            }
+            conv = DENSE;
           } else {
             const int pl = key32_payload(best32);
             src = pl & 63;
             kind = (pl >> 6) & 1;
-            fixed_src = pl >> 7;
+            nb_src = pl >> 7;
+          }
+        }
+        if constexpr (DENSE) {
+          if (conv) {
+            // ... into the variables of the dual method and of the closing trips: the point, the multipliers (slacks of
+            // the inactive rows), the factors of a step
+            u = (li < NV) ? ((state == 1) ? -x : ((state == 2) ? x : 0.0)) : x;
+            phi = (li < NV) ? ((state == 1) ? -1.0 : ((state == 2) ? 1.0 : 0.0)) : ((dlane && state == 1 && dr >= n_eq) ? 1.0 : 0.0);
+            xfree = ((li < NV) ? (state != 0) : (state == 1)) ? 0.0 : 1.0;
+            if (li < NV && state != 0) x = (state == 1) ? lbv : ubv;
           }
         }
       }
     }
-    if (!PPM && wave_any(running && need_sel)) {
-      const bool sel = running && need_sel;
+    if (!PPM && wave_any(running && !ppm_mode && need_sel)) {
+      const bool sel = running && !ppm_mode && need_sel;
       const double slo = x - lbv, sup = ubv - x;
       const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
       // (no curvature left along the normal -- it depends on the active ones: the weight is just large; the step
@@ -662,6 +764,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       if (++it > max_iter) {
         status = STATUS_MAX_ITER;
         running = false;
+      }
+      if constexpr (PPMD) {
+        if (ppm_mode && it > 2 * PINKHIP_SWEEP_PPM_MURTY_AFTER(nv + md)) restoring = true;  // (the dual method ends what this did not)
       }
     }
     // once no group of the wave is running any more, closing trips take the refinement steps of all of them
@@ -719,10 +824,12 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
         if (ref) {
           if (status != STATUS_OPTIMAL) {
+            status_before = status;
             // a verdict -- inconsistent, out of iterations, a non-positive pivot in the first sweeps -- reached on a
             // tableau that may have lost its accuracy is not handed out either: the Goldfarb-Idnani code (Cholesky
             // factor, orthogonal updates) confirms it or solves the instance (rare in practice: twice the work there)
             status = STATUS_BREAKDOWN;
+            PINKHIP_WHY(2);
             refined = true;
           } else if (!cert_fails && !more) {
             if (sane) x += dxv;  // (below 1e-9 |x|: the certificate holds for the corrected point as well)
@@ -734,6 +841,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
             ++nref;
           } else {
             status = STATUS_BREAKDOWN;
+            PINKHIP_WHY(3);
             refined = true;
           }
         }
@@ -749,55 +857,100 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     int pi = -1;
     double pvt = 1.0, rp = 0.0;  // (no pivot in this group: t = 0 leaves T and tdiag as they are)
     double sg = -1.0;
-    if constexpr (PPM) {
-      // (c') the exchange: lane src's quantity `cand` goes to zero along the column, nu = -cand / T[src][src]; the free
-      // coordinates move by -col nu, the multipliers of the fixed ones by -phi col nu -- whatever that does to their
-      // signs: the next selection sees it
-      // (lower side: x - lo has to rise to zero, upper side: hi - x)
-      const double vs = group_bcast<W>(viol, src);
-      const double num = kind ? vs : -vs;
-      const double pv = group_bcast<W>(tdiag, src);
-      PINKHIP_TICK(4);  // column
-      const double rpv = fast_rcp(pv);
-      // freeing: nonbasic -> basic (sweep), fixing: basic -> nonbasic (reverse sweep).  The pivot has the sign of the
-      // curvature it stands for; anything else: H is not positive definite on this set (or the tableau is no inverse
-      // any more) -- the Goldfarb-Idnani code, whose Cholesky factorisation decides that, takes the instance
-      sg = fixed_src ? 1.0 : -1.0;
-      bool act2 = act;
-      if (act && !(pv * sg > 0.0)) {
-        status = STATUS_NOT_PD;
-        running = false;
-        act2 = false;
-      }
-      const double nu = act2 ? -num * rpv : 0.0;
-      x = fma(-col, nu, x);
-      if (act2) {
-        pi = src;
-        pvt = pv;
-        rp = rpv;
-        if (li == src) {
-          if (state != 0) {
-            // off its bound, to where its gradient entry is zero
-            x = ((state == 1) ? lbv : ubv) + nu;
-            state = 0;
-            blo = lbv;
-            bhi = ubv;
-            tlo = thr_lo;
-            thi = thr_up;
-          } else {
-            // onto the bound it violates: -g = -nu (the multiplier |nu| with the sign of its side)
-            x = -nu;
-            state = kind + 1;
-            blo = kind ? 0.0 : -INF;
-            bhi = kind ? INF : 0.0;
-            tlo = 0.0;
-            thi = 0.0;
+    if constexpr (PPX) {
+      if (PPM || wave_any(act && ppm_mode)) {
+        const bool actP = act && ppm_mode;
+        // (c') the exchange: lane src's quantity goes to zero along the column, nu = -num / T[src][src]; every lane's
+        // quantity moves by -col nu -- whatever that does to the signs: the next selection sees it
+        // (lower side: x - lo has to rise to zero, upper side: hi - x)
+        const double vs = group_bcast<W>(viol, src);
+        const double num = kind ? vs : -vs;
+        const double pv = group_bcast<W>(tdiag, src);
+        PINKHIP_TICK(4);  // column
+        const double rpv = fast_rcp(pv);
+        // entering the basis (a coordinate freed, a row activated): sweep; leaving it: reverse sweep
+        const double sgp = nb_src ? 1.0 : -1.0;
+        bool act2 = actP;
+        if constexpr (!DENSE) {
+          // The pivot has the sign of the curvature it stands for; anything else: H is not positive definite on this set
+          // (or the tableau is no inverse any more) -- the Goldfarb-Idnani code, whose Cholesky factorisation decides
+          // that, takes the instance
+          if (actP && !(pv * sgp > 0.0)) {
+            status = STATUS_NOT_PD;
+            running = false;
+            act2 = false;
+          }
+        } else {
+          // A coordinate that is fixed and a row that is activated pivot on MINUS the curvature left along their normal,
+          // n^T Z n: (next to) nothing of it left = the normal depends on the active ones.  The other two exchanges, a
+          // coordinate freed and a row released, pivot on the reciprocal of such a curvature: positive, of any size.
+          const double zr = group_bcast<W>(zd0, src);
+          const bool recip = (src < NV) == (nb_src != 0);
+          if (actP && !((recip ? pv : -pv) > (recip ? 0.0 : 1e-8 * zr))) {
+            act2 = false;
+            PINKHIP_TRACEF(li == 0, "[ppm g%d it%d] irregular: src %d kind %d nonbasic %d pv %.3e zref %.3e num %.3e eq %d restoring %d\n", g, it, src,
+                           kind, nb_src, pv, zr, num, (int)iseq, (int)restoring);
+            double hs = 0.0;
+            if (wave_any(iseq)) hs = group_bcast<W>(hv, src);
+            if (iseq && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
+              ++eq_next;  // implied by the active ones and met: nothing to add
+            } else if (!restoring) {
+              restoring = true;
+            } else {
+              status = STATUS_BREAKDOWN;  // (not even a release is regular: the tableau is no inverse any more)
+              PINKHIP_WHY(1);
+              running = false;
+            }
           }
         }
+        const double nu = act2 ? -num * rpv : 0.0;
+        x = fma(-col, nu, x);
+        if (act2) {
+          pi = src;
+          pvt = pv;
+          rp = rpv;
+          sg = sgp;
+          if (li == src) {
+            if (!DENSE || li < NV) {
+              if (state != 0) {
+                // off its bound, to where its gradient entry is zero
+                x = ((state == 1) ? lbv : ubv) + nu;
+                state = 0;
+                blo = lbv;
+                bhi = ubv;
+                tlo = thr_lo;
+                thi = thr_up;
+              } else {
+                // onto the bound it violates: -g = -nu (the multiplier |nu| with the sign of its side)
+                x = -nu;
+                state = kind + 1;
+                blo = kind ? 0.0 : -INF;
+                bhi = kind ? INF : 0.0;
+                tlo = 0.0;
+                thi = 0.0;
+              }
+            } else if (state == 0) {
+              x = nu;  // the multiplier of the row
+              state = 1;
+              tlo = 0.0;
+              if (dr < n_eq) blo = -INF;  // (an equality's: of either sign)
+            } else {
+              x = -nu;  // the slack it opens
+              state = 0;
+              tlo = thr_row;
+            }
+          }
+          if constexpr (DENSE) {
+            if (iseq) ++eq_next;
+          }
+        }
+        PINKHIP_TICK(5);
+        PINKHIP_TICK(6);
       }
-      PINKHIP_TICK(5);
-      PINKHIP_TICK(6);
-    } else {
+    }
+    if constexpr (!PPM) {
+    if (!PPMD || wave_any(act && !ppm_mode)) {
+    const bool actG = act && !ppm_mode;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
     double cand = (kind == 0 ? lbv : ubv) - x;
@@ -815,7 +968,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       // leaves delta^2 instead of delta: dependence shows as < 1e-12 of n^T H^-1 n whatever the conditioning
       // (scripts/gpu_fuzz.py seed 12979: floor 6e-11, against a threshold of 1e-10 before).
       const double z0 = group_bcast<W>(zd0, src);
-      const bool little = act && !(-pv * 1e6 > z0);
+      const bool little = actG && !(-pv * 1e6 > z0);
       if (wave_any(little)) {
         const double w = (in && state == 0) ? col : 0.0;
         const double hw = krow_times(w);
@@ -823,11 +976,11 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         if (little) pv = -curv;
       }
       lin_dep = !(-pv * 1e12 > z0);
-      PINKHIP_TRACEF(li == 0 && act, "[sweep g%d it%d] enter src %d kind %d num %.3e pv %.3e z0 %.3e little %d lin_dep %d\n", g, it, src, kind,
+      PINKHIP_TRACEF(li == 0 && actG, "[sweep g%d it%d] enter src %d kind %d num %.3e pv %.3e z0 %.3e little %d lin_dep %d\n", g, it, src, kind,
                      num, pv, z0, (int)little, (int)lin_dep);
     }
     // (a group without an entering constraint computes on garbage from here on: everything it could change is
-    // masked by act / act2 below)
+    // masked by actG / act2 below)
     PINKHIP_TICK(4);  // column
     // (c) step: the driving parameter nu (multiplier of the entering constraint) moves every quantity along the
     // column: free coordinates x -= col nu, multipliers of fixed coordinates u -= phi col nu (phi = -1 at lb, +1 at
@@ -838,7 +991,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     const double sgn = (num >= 0.0) ? 1.0 : -1.0;
     const double full = lin_dep ? BIG : -fabs(num) * rpv;
     const double rate = phi * col * sgn;
-    const bool blocking = act && rate > 0.0;
+    const bool blocking = actG && rate > 0.0;
     const double ratio = blocking ? max_raw(u, 0.0) * fast_rcp1(rate) : BIG;
     const double k1 = group_min<W>(ratio);
     const int kd = group_first_lane<W>(blocking && ratio == k1) & (W - 1);
@@ -847,9 +1000,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     double hs = 0.0;
     if constexpr (DENSE) {
       // (the bound / right-hand side of the entering constraint; cross-lane: wave-uniform control flow)
-      if (wave_any(act && stuck)) hs = group_bcast<W>((li < NV) ? (kind == 0 ? lbv : ubv) : hv, src);
+      if (wave_any(actG && stuck)) hs = group_bcast<W>((li < NV) ? (kind == 0 ? lbv : ubv) : hv, src);
     }
-    if (act && stuck) {
+    if (actG && stuck) {
       const bool tiny = DENSE && fabs(num) <= 1e-9 * (1.0 + fabs(hs));
       PINKHIP_TRACEF(li == 0, "[sweep g%d it%d] stuck: src %d kind %d num %.3e hs %.3e pv %.3e lin_dep %d k1 %.3e full %.3e tiny %d\n",
                      g, it, src, kind, num, hs, pv, (int)lin_dep, k1, full, (int)tiny);
@@ -871,7 +1024,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         running = false;
       }
     }
-    const bool act2 = act && running && !stuck;
+    const bool act2 = actG && running && !stuck;
     const bool do_add = act2 && !(k1 < full);
     const bool do_drop = act2 && !do_add;
     {
@@ -923,26 +1076,10 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     PINKHIP_TICK(6);  // column of the leaving constraint
     // sweep (nonbasic -> basic: sg = +1) or reverse sweep (basic -> nonbasic: sg = -1) on pi.  Basic = free
     // coordinate / active row, so an add pivots a coordinate out and a row in, a drop the other way round.
-    sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
+    if (!ppm_mode) sg = ((!DENSE || pi < NV) == do_add) ? -1.0 : 1.0;
     }
-    {
-      double t = col * rp;
-      double cp = col;
-      if (li == pi) {
-        // lane pi: its row becomes sg col / p -- as T[pi][j] - (1 - sg / p) col_j -- and the column the other lanes
-        // see at j = pi is p - sg, so that their entry T[m][pi] - t_m (p - sg) becomes sg t_m
-        t = 1.0 - sg * rp;
-        cp = pvt - sg;
-      }
-      const BcT xb = bcast_prepare<W>(cp);
-      const double nt = -t;
-      static_for<0, NT>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        tset(Jc, fma_bcast<W, j>(tget(Jc), xb, nt));
-      });
-      sdiag_run = fma(cp, nt, sdiag_run);  // (what the broadcast-FMA above just made of this lane's register li)
-      tdiag = (li == pi) ? -rp : tdiag - t * col;
     }
+    pivot_on(pi, col, pvt, rp, sg);
     PINKHIP_TICK(7);  // pivot
   }
   PINKHIP_TICK(8);  // exit
@@ -963,7 +1100,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       if (in) late->dq[bw * (long long)nv + li] = x * late->out_scale;
       if (li == 0) {
         late->status[bw] = status;
-        if (late->iters) late->iters[bw] = it;  // (PATH_TABLEAU = 0; a group handed over is written again)
+        if (late->iters) late->iters[bw] = it + 1000 * why;  // (PATH_TABLEAU = 0; a group handed over is written again)
       }
     }
   }
