@@ -446,8 +446,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       thi = 0.0;
     }
     // an empty box is quadprog's "constraints are inconsistent" wherever the iteration would come across it
-    if (empty_box_somewhere && status == STATUS_OPTIMAL) {
-      if (group_first_lane<W>(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up)) < W) status = STATUS_INFEASIBLE;
+    if (empty_box_somewhere) {  // (wave-uniform)
+      const bool empty = group_first_lane<W>(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up)) < W;
+      if (empty && status == STATUS_OPTIMAL) status = STATUS_INFEASIBLE;
     }
   }
   bool at_point = false;
@@ -886,12 +887,14 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
           // coordinate freed and a row released, pivot on the reciprocal of such a curvature: positive, of any size.
           const double zr = group_bcast<W>(zd0, src);
           const bool recip = (src < NV) == (nb_src != 0);
-          if (actP && !((recip ? pv : -pv) > (recip ? 0.0 : 1e-8 * zr))) {
+          const bool irregular = actP && !((recip ? pv : -pv) > (recip ? 0.0 : 1e-8 * zr));
+          // (the right-hand side of a dependent equality; cross-lane: wave-uniform control flow)
+          double hs = 0.0;
+          if (wave_any(irregular && iseq)) hs = group_bcast<W>(hv, src);
+          if (irregular) {
             act2 = false;
             PINKHIP_TRACEF(li == 0, "[ppm g%d it%d] irregular: src %d kind %d nonbasic %d pv %.3e zref %.3e num %.3e eq %d restoring %d\n", g, it, src,
                            kind, nb_src, pv, zr, num, (int)iseq, (int)restoring);
-            double hs = 0.0;
-            if (wave_any(iseq)) hs = group_bcast<W>(hv, src);
             if (iseq && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
               ++eq_next;  // implied by the active ones and met: nothing to add
             } else if (!restoring) {

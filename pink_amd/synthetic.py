@@ -38,6 +38,11 @@ CONFIGS: Dict[str, dict] = {
     "jvrc": dict(config_id=4, nv=50, root_nv=6, dt=5e-3,
                  frame_costs=[(1.0, 3.0), (1.0, 0.0), (1.0, 3.0), (1.0, 3.0)], frame_lm=0.0,
                  posture_cost=1e-1, n_barriers=2),
+    # the same stack at the size the example's own model has: Draco3 with its free-flyer root (examples/humanoid_draco3.py:55-56)
+    # has 27 actuated joints, nv = 33 -- one coordinate more than a 32-lane group holds
+    "draco3_freeflyer": dict(config_id=14, nv=33, root_nv=6, dt=5e-3,
+                             frame_costs=[(1.0, 1.0), (1.0, 0.0), (1.0, 1.0), (4.0, 4.0)], frame_lm=0.0,
+                             posture_cost=1e-1, n_barriers=0),
     # the Draco3-shaped stack with two position barriers (examples/barriers/arm_ur5.py:50-57 on the humanoid): nv = 30
     # plus six dense rows -- 36 tableau rows on a 32-lane group (ik_sweepx.h: the dense rows ride without lanes)
     "draco3b": dict(config_id=13, nv=30, root_nv=6, dt=5e-3,

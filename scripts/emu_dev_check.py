@@ -1,7 +1,7 @@
 """Development check on the CPU wave emulator built for ONE instantiation (seconds to build):
 
   (cd tests/emu && g++ -O1 -std=c++17 -fPIC -shared -DPINKHIP_DEV_NV=30 -DPINKHIP_DEV_W=32 -DPINKHIP_DEV_MD=0 \
-      -o /tmp/libpinkemu_dev.so emu_kernels.cpp)
+      -o /tmp/libpinkemu_dev.so emu_kernels.cpp emu_part.cpp)
   python scripts/emu_dev_check.py /tmp/libpinkemu_dev.so draco3 [B]
 
 Solves the synthetic batches of one configuration (tight / kinematic bounds, tracking regime) on the emulator and

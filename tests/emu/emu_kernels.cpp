@@ -1,66 +1,31 @@
 // Host harness that runs the HIP kernel source on the CPU wave emulator.
 // TEST INFRASTRUCTURE ONLY (see wave_emu.h).  Exposes the same struct-based
 // signature as the host entry points of include/pinkhip.h.
-#include "wave_emu.h"
-// clang-format off
-#include "../../pink_amd/csrc/ik_common.h"
-#include "../../pink_amd/csrc/dispatch.h"
-#include "../../pink_amd/csrc/ik_kernels_packed.h"
-#include "../../pink_amd/csrc/ik_sweep.h"
-#include "../../pink_amd/csrc/ik_sweepx.h"
-#include "../../pink_amd/csrc/ik_stack_mfma.h"
-#include "../../pink_amd/csrc/ik_frame_task.h"
-#include "../../pink_amd/csrc/ik_kinematics.h"
-#include "../../pink_amd/csrc/ik_rollout.h"
-#include "../../pink_amd/csrc/model_tables.h"
-#include "../../pink_amd/csrc/host_tables.h"
-// clang-format on
+#include "emu_lanes.h"
 
+#include <map>
 #include <string>
+#include <tuple>
+
+namespace pinkemu {
+namespace {
+std::map<std::tuple<int, int, int, int>, LaneEntry> &registry() {
+  static std::map<std::tuple<int, int, int, int>, LaneEntry> r;
+  return r;
+}
+}  // namespace
+void emu_register(int kind, int nv, int md, int w, LaneEntry fn) { registry()[std::make_tuple(kind, nv, md, w)] = fn; }
+LaneEntry emu_lookup(int kind, int nv, int md, int w) {
+  auto it = registry().find(std::make_tuple(kind, nv, md, w));
+  return it == registry().end() ? nullptr : it->second;
+}
+}  // namespace pinkemu
+
+using namespace pinkemu;
 
 namespace {
 
 using pinkhip::KernelArgs;
-
-template <int NV, int W>
-void lane_main_packed(void *p) {
-  const KernelArgs *a = static_cast<const KernelArgs *>(p);
-  if (a->md == 0)
-    pinkhip::ik_packed_instance<NV, W, false>(*a, pinkhip::block_id());
-  else
-    pinkhip::ik_packed_instance<NV, W, true>(*a, pinkhip::block_id());
-}
-
-template <int NV, int MD, int W>
-void lane_main_sweep(void *p) {
-  KernelArgs k = *static_cast<const KernelArgs *>(p);
-  k.lds_pitch = pinkhip::sweep_kernel_lds_doubles<NV, MD, W>(k.md);  // as tu_sweep.hip's launcher
-  pinkhip::ik_solve_sweep_body<NV, MD, W>(k, pinkhip::block_id());
-}
-
-template <int NV, int MD, int W>
-void lane_main_sweepx(void *p) {
-  KernelArgs k = *static_cast<const KernelArgs *>(p);
-  k.lds_pitch = pinkhip::sweepx_kernel_lds_doubles<NV, MD, W>(k.md);  // as tu_sweepx.hip's launcher
-  pinkhip::ik_solve_sweepx_body<NV, MD, W>(k, pinkhip::block_id());
-}
-
-template <int TP>
-void lane_main_stack_small(void *p) {
-  pinkhip::ik_stack_small_instance<TP>(*static_cast<const KernelArgs *>(p), pinkhip::block_id());
-}
-
-template <int NT>
-void lane_main_stack_mfma(void *p) {
-  const KernelArgs *a = static_cast<const KernelArgs *>(p);
-  if constexpr (NT >= 3) {
-    if (pinkhip::stack_staged_ok(a->nv, a->Kd, a->J)) {  // same rule as pinkhip.hip
-      pinkhip::ik_stack_mfma_instance<NT, true>(*a, pinkhip::block_id());
-      return;
-    }
-  }
-  pinkhip::ik_stack_mfma_instance<NT>(*a, pinkhip::block_id());
-}
 
 std::string g_err;
 
@@ -130,7 +95,7 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
       switch (xc.NV * 100 + xc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \
-    fn = lane_main_sweepx<NV, MD, W>;          \
+    fn = emu_lookup(KIND_SWEEPX, NV, MD, W);   \
     blocks = (d->B + 64 / W - 1) / (64 / W);   \
     break;
         PINKHIP_SWEEPX_TABLE(PINKHIP_CASE)
@@ -141,7 +106,7 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
       switch (sc.NV * 100 + sc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \
-    fn = lane_main_sweep<NV, MD, W>;           \
+    fn = emu_lookup(KIND_SWEEP, NV, MD, W);    \
     blocks = (d->B + 64 / W - 1) / (64 / W);   \
     break;
         PINKHIP_SWEEP_TABLE(PINKHIP_CASE)
@@ -152,7 +117,7 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
     if (!fn) switch (pc.NV) {
 #define PINKHIP_CASE(NV, W)          \
   case NV:                           \
-    fn = lane_main_packed<NV, W>;    \
+    fn = emu_lookup(KIND_PACKED, NV, 0, W); \
     blocks = (d->B + 64 / W - 1) / (64 / W); \
     break;
       PINKHIP_PACKED_TABLE(PINKHIP_CASE)
@@ -168,35 +133,6 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
 }
 
 }  // namespace
-
-template <int W>
-void lane_main_frame(void *p) {
-  pinkhip::ik_frame_task_instance<W>(*static_cast<const pinkhip::FrameTaskArgs *>(p), pinkhip::block_id());
-}
-
-template <int W>
-void lane_main_fk(void *p) {
-  pinkhip::ik_fk_instance<W>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
-}
-
-template <int W>
-void lane_main_fk_fused(void *p) {
-  pinkhip::ik_fk_instance<W, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
-}
-
-template <int W>
-void lane_main_step(void *p) {
-  pinkhip::ik_fk_instance<W, true, true>(*static_cast<const pinkhip::FkArgs *>(p), pinkhip::block_id());
-}
-
-template <int NV, int W>
-void lane_main_rollout(void *p) {
-  pinkhip::ik_rollout_instance<NV, 0, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
-}
-template <int NV, int MD, int W>
-void lane_main_rollout_dense(void *p) {
-  pinkhip::ik_rollout_instance<NV, MD, W>(*static_cast<const pinkhip::RolloutArgs *>(p), pinkhip::block_id());
-}
 
 struct EmuModel {
   pinkhip::ModelImage image;
@@ -370,7 +306,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
     switch (dc.NV * 100 + dc.MD) {
 #define PINKHIP_CASE(NV, MD, W)                \
   case NV * 100 + MD:                          \
-    fn = lane_main_rollout_dense<NV, MD, W>;   \
+    fn = emu_lookup(KIND_ROLLOUT_DENSE, NV, MD, W); \
     blocks = (d->B + 64 / W - 1) / (64 / W);   \
     break;
       PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_CASE)
@@ -383,7 +319,7 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   if (d->md == 0) switch (pc.NV) {
 #define PINKHIP_CASE(NV, W)                  \
   case NV:                                   \
-    fn = lane_main_rollout<NV, W>;           \
+    fn = emu_lookup(KIND_ROLLOUT, NV, 0, W);  \
     blocks = (d->B + 64 / W - 1) / (64 / W); \
     break;
     PINKHIP_ROLLOUT_TABLE(PINKHIP_CASE)

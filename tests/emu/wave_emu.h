@@ -20,7 +20,7 @@
 
 #define __device__
 #define __host__
-#define __global__
+#define __global__ inline
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define PINKHIP_OCCUPANCY_ATTR(NV)
