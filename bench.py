@@ -786,7 +786,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="draco3", choices=["ur5", "draco3", "draco3b", "jvrc", "jvrc_noposture"])
+    ap.add_argument("--config", default="draco3", choices=["ur5", "draco3", "draco3_freeflyer", "draco3b", "jvrc", "jvrc_noposture"])
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-batch", type=int, default=524288, help="total instances, split over the ranks (strong scaling)")
@@ -952,6 +952,9 @@ def main() -> None:
             extra["configs"] = {
                 "ur5_B4096": measure_config(solver, "ur5", 4096 if B >= 4096 else B, 20, bounds="tight", jacobians="dense"),
                 "jvrc_B65536": measure_config(solver, "jvrc", 65536 if B >= 4096 else B, 5, bounds="tight", jacobians="dense"),
+                # the headline stack at the size Draco3's own model has (examples/humanoid_draco3.py:55-56: free-flyer root,
+                # nv = 33): one coordinate more than a 32-lane group holds -- ik_solve_sweep_kernel<34, 0, 64>, one QP per wavefront
+                "draco3_freeflyer_nv33_B65536": measure_config(solver, "draco3_freeflyer", 65536 if B >= 4096 else B, 5, bounds="tight", jacobians="dense"),
                 # the headline stack with two position barriers: 30 coordinates + 6 dense rows = 36 tableau rows on a
                 # 32-lane group (ik_sweepx.h); the Goldfarb-Idnani kernel alone beside it
                 "draco3_2barriers_B65536": measure_config(solver, "draco3b", 65536 if B >= 4096 else B, 5, ab_gi_alone=True, bounds="tight",
@@ -1023,9 +1026,11 @@ def main() -> None:
                             f"box limits, md={batch.md} barrier rows, B={B} per GPU, bounds={args.bounds}, jacobians={args.jacobians}",
                 "batch_per_gpu": B, "global_batch": global_batch, "nv": nv, "Kd": batch.Kd, "K": batch.K, "md": batch.md,
                 "parallelism": f"batch-sharded x{world}",
-                "solver": "dual active set (Goldfarb-Idnani logic) on a register-resident sweep tableau, HIP fp64, 64/W QPs per "
-                          "wavefront (W = 32 lanes per QP at nv = 30), closing trips that refine the point and certify it against the KKT "
-                          "conditions (an instance that fails is solved again by the Goldfarb-Idnani kernel of round 2 in the same launch)",
+                "solver": "active set by single principal pivoting (largest objective change, started from the active set "
+                          "x_i = -c_i / H_ii guesses; Goldfarb-Idnani's dual method behind it where dense rows make a pivot irregular) on a "
+                          "register-resident sweep tableau, HIP fp64, 64/W QPs per wavefront (W = 32 lanes per QP at nv = 30), closing trips that "
+                          "refine the point and certify it against the KKT conditions (an instance that fails is solved again by the "
+                          "Goldfarb-Idnani kernel of round 2 in the same launch)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -259,7 +259,11 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
   // a result that fails its KKT certificate is not integrated: the Goldfarb-Idnani code solves that robot's QP again
   // (ik_sweep.h, ik_solve_sweep_body).  It forms the rows from the kinematics like the tableau did, and the tableau's
   // parking area has overwritten the kinematics scratch meanwhile: the kinematics run once more (wave-uniform, rare).
+#ifdef PINKHIP_SWEEP_NO_HANDOVER  // (development: what the tableau code alone says)
+  const bool over = false;
+#else
   const bool over = st_sweep == STATUS_BREAKDOWN || st_sweep == STATUS_ROUTED;
+#endif
   if (wave_any(over)) {
     wave_sync();
     // (arguments read again, terms built again: nothing of them is kept in registers through the tableau loop)

@@ -100,6 +100,10 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #else
 #define PINKHIP_WHY(k)
 #endif
+// ... in the whole-step kernel when the guess fixes more than this many coordinates per robot of the wave
+#ifndef PINKHIP_SWEEP_PPM_CRASH_MIN
+#define PINKHIP_SWEEP_PPM_CRASH_MIN 2
+#endif
 #ifndef PINKHIP_SWEEP_PPM_MURTY_AFTER
 #define PINKHIP_SWEEP_PPM_MURTY_AFTER(nv) (4 * (nv) + 20)
 #endif
@@ -281,7 +285,15 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
   }
-  if constexpr (PPX && PINKHIP_SWEEP_PPM_CRASH) {
+  // The start is a guessed active set.  In the whole-step kernel only when the guess fixes more than a coordinate or two per
+  // robot of the wave (wave-uniform): a controller that tracks its targets has next to nothing to guess, and there the sweeps
+  // without masks are worth more than the trip the guess saves -- the masked ones cost that kernel 9 % of a converged
+  // step (register pressure: profiles/ab_ppm_r06.txt), two copies of the sweeps cost it 2 %.  The stack + solve kernels
+  // carry the masked sweeps alone: the same experiment there is within the noise, and a second copy of the sweeps is
+  // instruction-cache footprint.
+  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH;
+  bool guess = GUESS;
+  if constexpr (GUESS) {
     // ---------------------------------------------------------------- principal pivoting: where it starts
     // Principal pivoting needs no feasibility of any kind from its starting basis, so it does not have to be the
     // unconstrained minimum (every coordinate swept in: NV sweeps, and then one pivot for every bound that ends up
@@ -295,55 +307,63 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     if (group_first_lane<W>(in && !(hii > 0.0)) < W) status = STATUS_NOT_PD;
     const double xd = -ci * approx_rcp(hii);
     if (in) state = (xd < lbv) ? 1 : ((xd > ubv) ? 2 : 0);
-    const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
-    unsigned long long ufree = fm;  // union over the groups of the wave (scalar)
-    unsigned long long gfree = fm;  // this lane's group
-    if constexpr (W == 32) {
-      ufree = (fm | (fm >> 32)) & 0xFFFFFFFFull;
-      gfree = (lane >= 32) ? (fm >> 32) : (fm & 0xFFFFFFFFull);
-    } else if constexpr (W == 16) {
-      ufree = (fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xFFFFull;
-      gfree = (fm >> (lane & 48)) & 0xFFFFull;
+    if constexpr (Src::kOnTheFly) {
+      guess = __builtin_popcountll(wave_ballot(state != 0)) > PINKHIP_SWEEP_PPM_CRASH_MIN * G;  // wave-uniform
+      if (!guess) state = 0;
     }
-    static_for<0, NV>([&](auto Kc) {
+    const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
+    // this lane's group (W = 64: the wave, a scalar; below: 32 bits of a register)
+    using FreeMask = typename std::conditional<W == 64, unsigned long long, unsigned>::type;
+    FreeMask gfree = static_cast<FreeMask>(fm);
+    if constexpr (W == 32) gfree = (lane >= 32) ? static_cast<unsigned>(fm >> 32) : static_cast<unsigned>(fm);
+    else if constexpr (W == 16) gfree = static_cast<unsigned>(fm >> (lane & 48)) & 0xFFFFu;
+    if (guess) static_for<0, NV>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
-      if ((ufree >> k) & 1ull) {  // wave-uniform: some group sweeps coordinate k in
-        // (the lanes of a group that does not are switched off for the sweep -- the broadcast operands of a row come
-        // from its own group, which is on or off as a whole -- instead of carrying these selects: wave.h, lanes_on)
-        const bool want = ((gfree >> k) & 1ull) != 0;
+      {
+        // (the lanes of a group that does not sweep coordinate k in are switched off for the sweep -- the broadcast
+        // operands of a row come from its own group, which is on or off as a whole -- instead of carrying these selects:
+        // wave.h, lanes_on; no group that does: the one branch skips the sweep)
+        const bool want = ((gfree >> k) & 1) != 0;
         if (lanes_on(want)) {
-          const BcT xb = bcast_prepare<W>(T[k]);
+          BcT xb = bcast_prepare<W>(T[k]);
           const double p = value_bcast<W, k>(xb);
           pmin = min_raw(pmin, want ? p : INF);
           const double rp = fast_rcp(p);
           const double t = T[k] * rp;
           double nt = (li == k) ? rp - 1.0 : -t;
           if (!want) nt = 0.0;
+          double tk = (li == k) ? -rp : t;
+#if defined(__HIP_DEVICE_COMPILE__)
+          // (everything the sweep needs besides the row is in registers before the row is touched: the allocator otherwise
+          // rotated the whole row through its registers around each sweep of the whole-step kernel -- 30 moves per sweep)
+          asm volatile("" : "+v"(nt), "+v"(xb.r[0]), "+v"(tk));
+#endif
           static_for<0, NT>([&](auto Jc) {
             constexpr int j = decltype(Jc)::value;
             if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
           });
-          if (want) T[k] = (li == k) ? -rp : t;
+          if (want) T[k] = tk;
         }
       }
     });
-  } else {
-  static_for<0, NV>([&](auto Kc) {
-    constexpr int k = decltype(Kc)::value;
-    if (k < nv) {  // wave-uniform
-      const BcT xb = bcast_prepare<W>(T[k]);
-      const double p = value_bcast<W, k>(xb);
-      pmin = min_raw(pmin, p);
-      const double rp = fast_rcp(p);
-      const double t = T[k] * rp;
-      const double nt = (li == k) ? rp - 1.0 : -t;
-      static_for<0, NT>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
-      });
-      T[k] = (li == k) ? -rp : t;
-    }
-  });
+  }
+  if ((!GUESS || Src::kOnTheFly) && !guess) {
+    static_for<0, NV>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      if (k < nv) {  // wave-uniform
+        const BcT xb = bcast_prepare<W>(T[k]);
+        const double p = value_bcast<W, k>(xb);
+        pmin = min_raw(pmin, p);
+        const double rp = fast_rcp(p);
+        const double t = T[k] * rp;
+        const double nt = (li == k) ? rp - 1.0 : -t;
+        static_for<0, NT>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
+        });
+        T[k] = (li == k) ? -rp : t;
+      }
+    });
   }
   if (!(pmin > 0.0)) status = STATUS_NOT_PD;
   PINKHIP_TICK(1);  // initial sweeps
@@ -517,6 +537,10 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       if (state == 0) fails = !(fabs(grad) <= gtol && x - lbv >= 10.0 * thr_lo && ubv - x >= 10.0 * thr_up);
       else fails = (state == 1) ? !(grad >= -gtol) : !(grad <= gtol);
     }
+#if defined(PINKHIP_SWEEP_DEBUG_WHY) && defined(__HIP_DEVICE_COMPILE__)
+    if (fails) printf("[cert blk %lld g%d li%d it%d nref%d] state %d x %.17g lb %.17g ub %.17g grad %.3e gtol %.3e thr %.3e %.3e\n", block, g, li, it, nref, state, x,
+                      lbv, ubv, grad, gtol, thr_lo, thr_up);
+#endif
     double r = (in && state == 0) ? grad : 0.0;
     if constexpr (DENSE) {
       if (dlane) {
@@ -815,13 +839,16 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
         const bool arow_ = DENSE && dlane && state == 1;
         const double dbv = (ref && ((in && state == 0) || arow_)) ? col + (tdiag - sdiag) * rres : 0.0;
         const double dxv = in ? dbv : 0.0;
-        const bool more = group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-13) < W;
+        // (the floor is relative to the size of the point: the correction itself carries cond(H) eps |x| of round-off
+        // -- measured 2e-13 .. 1e-12 at |x| = 0.15 on the closed-loop batch of bench.py, where an absolute floor of 1e-13
+        // asked for steps that could not halve and sent a few robots per step to the hand-over.  It is applied either way.)
+        const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
+        const bool more = group_first_lane<W>(fabs(dxv) > 1e-9 * fabs(x) + 1e-11 * (1.0 + xmax)) < W;
         // ... as long as the steps contract.  Where T is no inverse any more (cond(H) ~ 1e13 and beyond: the relative
         // error of T reaches one) the "correction" is as large as x or grows from step to step: it is not applied, x
         // stays what the iteration left -- inside its box, by construction (scripts/gpu_fuzz_rollout.py seed 14:
         // cond(H) = 4e13, a correction of 6e7 radians reported as optimal).
         const double dmax = -group_min<W>(-fabs(dxv));
-        const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
         const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
         if (ref) {
           if (status != STATUS_OPTIMAL) {
@@ -843,6 +870,10 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
           } else {
             status = STATUS_BREAKDOWN;
             PINKHIP_WHY(3);
+#if defined(PINKHIP_SWEEP_DEBUG_WHY) && defined(__HIP_DEVICE_COMPILE__)
+            if (li == 0) printf("[close blk %lld g%d it%d nref%d] cert_fails %d more %d sane %d dmax %.3e xmax %.3e dprev %.3e\n", block, g, it, nref, (int)cert_fails,
+                                (int)more, (int)sane, dmax, xmax, dprev);
+#endif
             refined = true;
           }
         }

@@ -465,9 +465,9 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       });
       const double dxc = (ref && in && state == 0) ? (p0 + p1) + (tdiag - sdiag) * r : 0.0;
       const double dxd = (ref && arow) ? q0 + (ddiag - sdd) * rd : 0.0;
-      const bool more = group_first_lane<W>(fabs(dxc) > 1e-9 * fabs(x) + 1e-13) < W;
-      const double dmax = -group_min<W>(-fabs(dxc));
       const double xmax = -group_min<W>(in ? -fabs(x) : 0.0);
+      const bool more = group_first_lane<W>(fabs(dxc) > 1e-9 * fabs(x) + 1e-11 * (1.0 + xmax)) < W;  // (ik_sweep.h: relative floor)
+      const double dmax = -group_min<W>(-fabs(dxc));
       const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
       if (ref) {
         if (status != STATUS_OPTIMAL) {

@@ -315,7 +315,11 @@ __device__ __forceinline__ bool wave_any(bool p) { return __any(p ? 1 : 0) != 0;
 // must ALSO be written so that a lane with p false changes nothing when it runs it (selects on p): that is what the
 // CPU wave emulator executes -- its cross-lane primitives are rendezvous of all 64 lanes -- and here the compiler
 // folds those selects away inside the branch.
+#ifdef PINKHIP_LANES_ON_SELECT  // (development: the body masks itself, as on the emulator)
+__device__ __forceinline__ bool lanes_on(bool) { return true; }
+#else
 __device__ __forceinline__ bool lanes_on(bool p) { return p; }
+#endif
 // bit l = the predicate of lane l (a scalar)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // A value every lane of the wave agrees on, as a scalar the compiler keeps in an SGPR and branches on with s_cbranch_scc.
