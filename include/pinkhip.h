@@ -346,7 +346,9 @@ typedef struct pinkhip_rollout_step {
    * the limit rows and the barrier rows; desc.barrier_rows offsets start at desc.n_eq + n_limit_rows.  Constraint c is the
    * FrameTask of model frame constraint_frame[c] ([n] device; its target in T_target like any frame's; a frame that
    * carries no task of the objective gets zero cost: pink/tasks/task.py:148-166 then adds nothing for it) with gain
-   * constraint_gain[c] ([n] device).  At most 2. */
+   * constraint_gain[c] ([n] device).  At most 2.  The tables live in DEVICE memory and are not inspected by the call:
+   * every constraint_frame[c] must be a slot of the model, 0 <= constraint_frame[c] < n_frames (the Python layer builds them
+   * from the model's own frame list: pink_amd/rollout.py). */
   int32_t n_constraint_frames;
   const int32_t *constraint_frame;
   const double *constraint_gain;
@@ -354,7 +356,8 @@ typedef struct pinkhip_rollout_step {
    * keeps |p_f - p_f2|^2 - d_min^2 >= 0 between the origins of model frames f = barrier_frame[d] and f2 =
    * barrier_frame2[d], with barrier_bound[d] = d_min^2 and the class's class-K function h / (1 + |h|):
    * G_d = -2 (p_f - p_f2)^T (R J_lin,f - R J_lin,f2) / dt,  h_d = gain_d alpha(h)  (pink/barriers/barrier.py:246-254).
-   * [md - n_eq - n_limit_rows] device; may be NULL when no row has axis 3. */
+   * [md - n_eq - n_limit_rows] device, mandatory whenever the barrier_* tables are passed (PINKHIP_E_INVALID without it):
+   * the entry of a position-barrier row (axis 0 .. 2) is ignored, -1 by convention. */
   const int32_t *barrier_frame2;
 } pinkhip_rollout_step;
 int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, const pinkhip_model *model,

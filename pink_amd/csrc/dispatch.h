@@ -132,23 +132,24 @@ constexpr int max3(int a, int b, int c) { return (a > b ? a : b) > c ? (a > b ? 
 // ... and, for up to kRolloutMaxEqFrames equality constraints made of frame tasks, U / V of their frames and their six errors
 // (24 doubles each): the Goldfarb-Idnani code forms those rows too while the shared area is being overwritten.
 constexpr int kRolloutMaxEqFrames = 2;
-constexpr int rollout_tail_doubles(int nf) { return ((3 * nf + 1) & ~1) + 24 * kRolloutMaxEqFrames; }
+// (sized by the constraints the call has: a barrier-only stack does not pay LDS for them)
+constexpr int rollout_tail_doubles(int nf, int n_eqf) { return ((3 * nf + 1) & ~1) + 24 * n_eqf; }
 
 // Doubles of LDS per robot of the whole-control-step kernel: its kinematics scratch (fk_doubles) shares the solve's
 // LDS, whichever is larger (+ the frame positions behind it when dense rows are formed on chip).
-constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0, int nf = 0) {
+constexpr int rollout_lds_doubles(int NV, int W, int fk_doubles, int MD = 0, int nf = 0, int n_eqf = 0) {
   return max3((fk_doubles + 1) & ~1, NV + MD > W ? sweepx_lds_doubles(NV, MD, W) : sweep_lds_doubles(NV, MD, W), packed_lds_doubles(NV, MD)) +
-         (MD > 0 ? rollout_tail_doubles(nf) : 0);
+         (MD > 0 ? rollout_tail_doubles(nf, n_eqf) : 0);
 }
 
 // Instantiation of the whole-control-step kernel for a robot with nv tangent coordinates and nj joints whose
 // kinematics scratch needs fk_doubles doubles of LDS: W lanes must hold a joint / a column each, and the 64 / W
 // robots of a wavefront must fit the 64 KiB of LDS a workgroup may ask for.
 // ... with md > 0 rows of position barriers: {NV, MD, W} from PINKHIP_ROLLOUT_DENSE_TABLE
-inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md, int nf) {
+inline SweepChoice select_rollout_dense(int nv, int nj, int fk_doubles, int md, int nf, int n_eqf) {
 #define PINKHIP_PICK(NV_, MD_, W_)                                                                          \
   if (nv <= NV_ && md <= MD_ && nj <= W_) {                                                                 \
-    const int need = rollout_lds_doubles(NV_, W_, fk_doubles, MD_, nf);                                     \
+    const int need = rollout_lds_doubles(NV_, W_, fk_doubles, MD_, nf, n_eqf);                                \
     if (8 * need * (64 / W_) + 16 <= 65536) return SweepChoice{NV_, MD_, W_};                               \
   }
   PINKHIP_ROLLOUT_DENSE_TABLE(PINKHIP_PICK)

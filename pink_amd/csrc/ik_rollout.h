@@ -197,7 +197,7 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
     if constexpr (MD > 0) {
       tt.bar_frame = ra.bar_frame, tt.bar_axis = ra.bar_axis;
       tt.bar_sign = ra.bar_sign, tt.bar_bound = ra.bar_bound, tt.bar_gain = ra.bar_gain;
-      tt.pfs = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
+      tt.pfs = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf, ra.n_eqf);
       tt.inv_dt = 1.0 / ra.k.dt;
       tt.n_lim = ra.n_lim, tt.lim_rows = ra.lim_rows, tt.lim_h = ra.lim_h;
       tt.n_eqr = 6 * ra.n_eqf, tt.eq_frame = ra.eq_frame, tt.eq_gain = ra.eq_gain, tt.bar_frame2 = ra.bar_frame2;
@@ -213,7 +213,7 @@ __device__ __forceinline__ void ik_rollout_instance(const RolloutArgs &a, long l
   auto keep_frame_positions = [&](const RolloutArgs &ra) {
     if constexpr (MD > 0) {
       const ModelDev &mm = ra.fk.m;
-      double *tail = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf);
+      double *tail = sm + ra.k.lds_pitch - rollout_tail_doubles(mm.nf, ra.n_eqf);
       for (int i = li; i < 3 * mm.nf; i += W) tail[i] = sm[12 * (mm.nj + i / 3) + 9 + i % 3];
       if (ra.n_eqf > 0) {  // (kernel argument: wave-uniform)
         double *eqt = tail + ((3 * mm.nf + 1) & ~1);

@@ -47,7 +47,7 @@ struct pinkhip_handle {
   hipStream_t main_stream = nullptr, alt_stream = nullptr;  // `stream` is one of these two (pinkhip_select_compute_stream)
   hipEvent_t ev_copy = nullptr, ev_kernels = nullptr;  // copy stream -> compute stream, compute stream -> d2h stream
   std::vector<hipEvent_t> chunk_events;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;  // timer bracket; the other compute stream joining it
   hipEvent_t evk0 = nullptr, evk1 = nullptr;  // around the solve kernel(s) of the last pinkhip_solve_host call
   bool evk_valid = false;
   std::string err;
@@ -351,6 +351,7 @@ int pinkhip_create(pinkhip_handle **out, int device_id) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_kernels, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&h->evk0);
   if (e == hipSuccess) e = hipEventCreate(&h->evk1);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_tables), kTableBytes);
@@ -373,6 +374,7 @@ int pinkhip_destroy(pinkhip_handle *h) {
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->evk0) (void)hipEventDestroy(h->evk0);
   if (h->evk1) (void)hipEventDestroy(h->evk1);
   for (hipEvent_t ev : h->chunk_events) (void)hipEventDestroy(ev);
@@ -816,8 +818,8 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   if (st->n_limit_rows < 0 || 6 * n_eqf + st->n_limit_rows > desc->md || (st->n_limit_rows > 0 && (!st->limit_rows || !st->limit_h)))
     return fail(h, PINKHIP_E_INVALID, "n_limit_rows must lie in [0, md - n_eq] and come with limit_rows / limit_h");
   if (desc->md > 6 * n_eqf + st->n_limit_rows &&
-      (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain))
-    return fail(h, PINKHIP_E_INVALID, "rows of position barriers need the barrier_* tables");
+      (!st->barrier_frame || !st->barrier_axis || !st->barrier_sign || !st->barrier_bound || !st->barrier_gain || !st->barrier_frame2))
+    return fail(h, PINKHIP_E_INVALID, "barrier rows need the barrier_* tables, barrier_frame2 included (-1 for the rows of a position barrier)");
   if ((st->root_box || st->n_limit_rows) && md.root_nv != 6)
     return fail(h, PINKHIP_E_INVALID, "a floating-base velocity limit needs a free-flyer root joint");
   int post_row0 = 0, post_k = 0;
@@ -841,9 +843,9 @@ int pinkhip_rollout_step_device(pinkhip_handle *h, const pinkhip_desc *desc, con
   pinkhip::PackedChoice pc{0, 0};
   pinkhip::SweepChoice dc{0, 0, 0};
   if (desc->md > 0) {
-    dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md, md.nf);
+    dc = pinkhip::select_rollout_dense(md.nv, md.nj, fkd, desc->md, md.nf, n_eqf);
     if (dc.NV == 0 || md.nf > 32) return fail(h, PINKHIP_E_UNSUPPORTED, "no whole-step instantiation with barrier rows fits this model");
-    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD, md.nf);
+    ra.k.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD, md.nf, n_eqf);
     ra.bar_frame = st->barrier_frame;
     ra.bar_axis = st->barrier_axis;
     ra.bar_sign = st->barrier_sign;
@@ -1095,7 +1097,12 @@ int pinkhip_host_free(pinkhip_handle *h, void *hptr) {
   if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
   if (!hptr) return PINKHIP_OK;
   PH_HIP(h, hipSetDevice(h->device));
+  // (kernels of either compute stream may still be writing results straight into this block)
   PH_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->alt_stream) {
+    PH_HIP(h, hipStreamSynchronize(h->main_stream));
+    PH_HIP(h, hipStreamSynchronize(h->alt_stream));
+  }
   PH_HIP(h, hipHostFree(hptr));
   return PINKHIP_OK;
 }
@@ -1205,6 +1212,9 @@ int pinkhip_timer_start(pinkhip_handle *h) {
   if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
   PH_HIP(h, hipSetDevice(h->device));
   PH_HIP(h, hipEventRecord(h->ev0, h->stream));
+  // (a pipelined call alternates between the two compute streams: what the other one runs from here on is inside the
+  // bracket too)
+  if (h->alt_stream) PH_HIP(h, hipStreamWaitEvent(h->stream == h->main_stream ? h->alt_stream : h->main_stream, h->ev0, 0));
   return PINKHIP_OK;
 }
 
@@ -1212,6 +1222,10 @@ int pinkhip_timer_start(pinkhip_handle *h) {
 int pinkhip_timer_stop(pinkhip_handle *h, float *elapsed_ms) {
   if (!h || !elapsed_ms) return fail(h, PINKHIP_E_INVALID, "bad argument");
   PH_HIP(h, hipSetDevice(h->device));
+  if (h->alt_stream) {  // the selected stream waits for what the other one was given
+    PH_HIP(h, hipEventRecord(h->ev_join, h->stream == h->main_stream ? h->alt_stream : h->main_stream));
+    PH_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  }
   PH_HIP(h, hipEventRecord(h->ev1, h->stream));
   PH_HIP(h, hipEventSynchronize(h->ev1));
   PH_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));

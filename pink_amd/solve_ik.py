@@ -504,7 +504,12 @@ def _device_kinematics_plan(configurations, tasks, limits, barriers, constraints
                     have.add(f)
     if len(specs) > 32 or any(isinstance(sp[0], tuple) and i >= 16 for i, sp in enumerate(specs)):
         return _declined("more frame slots than the device model holds (32; relative slots among the first 16)")
-    return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons), _explicit_floating_base_limit(model, limits)
+    fb = _explicit_floating_base_limit(model, limits)
+    if fb is not None and limits is not None and not any(j.kind == "free_flyer" for j in getattr(model, "joints", ())):
+        # (written into the call's limits for a model without a free-flyer root: the device tables have no root box to
+        # put it in -- declined here, not as a constructor error of the device model)
+        return _declined("a FloatingBaseVelocityLimit on a model without a free-flyer root joint")
+    return model, q, specs, T, posture, extras, tuple(barriers or ()), gain, acc, vmax, tuple(cons), fb
 
 
 def _default_limits_gain(model, limits):
@@ -635,7 +640,10 @@ def _admissible_plan(plan):
         q00, out = const[0][3], []
         for x in extras:
             if x[0] == "const" and not np.array_equal(x[3], q00):
-                x = ("const", x[1], x[2] + x[1] @ model.difference(q00, x[3]), q00) + tuple(x[4:])
+                # (A is zero on free-flyer coordinates, where a reference configuration may hold anything -- non-finite
+                # entries included: 0 * inf must not reach b)
+                shift = np.nan_to_num(model.difference(q00, x[3]), nan=0.0, posinf=0.0, neginf=0.0)
+                x = ("const", x[1], x[2] + x[1] @ shift, q00) + tuple(x[4:])
             out.append(x)
         extras = tuple(out)
     return model, q, specs, targets, posture, extras

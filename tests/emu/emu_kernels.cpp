@@ -289,8 +289,8 @@ int pinkhip_emu_rollout_step(const pinkhip_desc *d, void *mp, const pinkhip_roll
   long long blocks = 0;
   pinkhip::PackedChoice pc{0, 0};
   if (d->md > 0) {
-    const pinkhip::SweepChoice dc = pinkhip::select_rollout_dense(m->dev.nv, m->dev.nj, fkd, d->md, m->dev.nf);
-    a.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD, m->dev.nf);
+    const pinkhip::SweepChoice dc = pinkhip::select_rollout_dense(m->dev.nv, m->dev.nj, fkd, d->md, m->dev.nf, st->n_constraint_frames);
+    a.lds_pitch = pinkhip::rollout_lds_doubles(dc.NV, dc.W, fkd, dc.MD, m->dev.nf, st->n_constraint_frames);
     ra.bar_frame = st->barrier_frame;
     ra.bar_axis = st->barrier_axis;
     ra.bar_sign = st->barrier_sign;
