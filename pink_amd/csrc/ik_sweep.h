@@ -308,8 +308,14 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     const double xd = -ci * approx_rcp(hii);
     if (in) state = (xd < lbv) ? 1 : ((xd > ubv) ? 2 : 0);
     if constexpr (Src::kOnTheFly) {
-      guess = __builtin_popcountll(wave_ballot(state != 0)) > PINKHIP_SWEEP_PPM_CRASH_MIN * G;  // wave-uniform
-      if (!guess) state = 0;
+      // (decided per robot -- a robot's result must not depend on which robot shares its wave: a sharded batch pairs
+      // them differently -- and the masked sweeps of a robot that starts with every coordinate free are the unmasked
+      // ones, operation for operation; the wave only picks the copy of the code)
+      const unsigned long long fixm = wave_ballot(state != 0);
+      const int nfix = __builtin_popcountll(W == 64 ? fixm : (fixm >> (lane & ~(W - 1))) & ((1ull << (W & 63)) - 1ull));
+      const bool gguess = nfix > PINKHIP_SWEEP_PPM_CRASH_MIN;
+      if (!gguess) state = 0;
+      guess = wave_any(gguess);
     }
     const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
     // this lane's group (W = 64: the wave, a scalar; below: 32 bits of a register)

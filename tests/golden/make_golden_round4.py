@@ -5,6 +5,7 @@ REFERENCE's own classes (run here, once; needs /root/reference):
   pink.tasks.LinearHolonomicTask / JointCouplingTask          (pink/tasks/linear_holonomic_task.py, joint_coupling_task.py)
   pink.tasks.DampingTask, LowAccelerationTask, JointVelocityTask, PostureTask (compute_error / compute_jacobian)
   pink.barriers.PositionBarrier.compute_qp_inequalities / compute_qp_objective  (position_barrier.py:95-153, barrier.py:151-254)
+  pink.barriers.SelfCollisionBarrier (self_collision_barrier.py:85-224; round 6: over a stub of Pinocchio's collision data)
 
 on vector-space models (one single-dof joint per coordinate: the stub `pinocchio` of make_golden.py supplies
 `pin.difference` / `pin.dDifference` for those), seeded inputs.  Nothing of the reference is copied: only its OUTPUTS
@@ -377,6 +378,57 @@ def main():
     problem = pink.build_ik(ref_cfg, [ft, po], dt, damping=1e-12, limits=[ConfigurationLimit(view), VelocityLimit(view)], constraints=[hold])
     out["eq/hold_target"] = np.r_[np.asarray(hold_t.rotation).ravel(), hold_t.translation]
     out["eq/P"], out["eq/c"], out["eq/G"], out["eq/h"], out["eq/A"], out["eq/b"] = problem.P, problem.q, problem.G, problem.h, problem.A, problem.b
+    # ------------------------------------------------------------------------------------------------------------------
+    # SelfCollisionBarrier (pink/barriers/self_collision_barrier.py:85-224), round 6: the reference's class on a stand-in
+    # that shows it exactly what it reads from Pinocchio's collision data -- collision_model.collisionPairs / geometryObjects
+    # (parent joints), collision_data.distanceResults (min_distance, getNearestPoint1 / 2), data.oMi, and
+    # pin.getJointJacobian(..., LOCAL_WORLD_ALIGNED) / pin.skew -- with the distance results of sphere pairs attached to the
+    # joints of this repo's stand-in robot (the smooth convex case the reference's docstring declares well defined).  Which
+    # pairs are the closest, the sign of each term of a row, d_min and the base class's rows and objective: the reference's.
+    # (its own generator: nothing above this line changes when this section does)
+    from pink.barriers import SelfCollisionBarrier
+
+    from pink_amd.barriers.self_collision_barrier import SpherePairs
+
+    rng6 = np.random.default_rng(20260930)
+    pin.skew = lambda v: np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+    pin.getJointJacobian = lambda model, data, jid, rf: np.array(data.get_joint_jacobian_world_aligned(jid))
+    for case, n, ff in (("sc_arm", 7, False), ("sc_humanoid", 9, True)):
+        m = build_chain(n, free_flyer=ff, seed=6)
+        q = m.neutral()
+        for j in m.joints:
+            if j.kind != "free_flyer":
+                q[j.idx_q] = rng6.uniform(-0.9, 0.9)
+        if ff:
+            M0 = exp6(rng6.normal(size=6) * 0.4)
+            q[0:3], q[3:7] = M0.translation, _rot_to_quat(M0.rotation)
+        cfg = Configuration(m, q)
+        nj = len(m.joints)
+        pairs = []
+        for _ in range(5):
+            j1, j2 = sorted(int(v) for v in rng6.choice(np.arange(nj), size=2, replace=False))
+            pairs.append((j1, 0.05 * rng6.normal(size=3), float(rng6.uniform(0.01, 0.04)), j2, 0.05 * rng6.normal(size=3), float(rng6.uniform(0.01, 0.04))))
+        res = SpherePairs(pairs)(cfg)
+        geoms = []
+        for pr in res:
+            geoms += [types.SimpleNamespace(parentJoint=pr.joint1), types.SimpleNamespace(parentJoint=pr.joint2)]
+        coll_model = types.SimpleNamespace(collisionPairs=[types.SimpleNamespace(first=2 * k, second=2 * k + 1) for k in range(len(res))], geometryObjects=geoms)
+        coll_data = types.SimpleNamespace(distanceResults=[
+            types.SimpleNamespace(min_distance=pr.min_distance, getNearestPoint1=(lambda pr=pr: pr.point1), getNearestPoint2=(lambda pr=pr: pr.point2)) for pr in res])
+        ref_cfg = types.SimpleNamespace(q=cfg.q, model=types.SimpleNamespace(nv=m.nv), data=cfg, collision_model=coll_model, collision_data=coll_data)
+        dt = 5e-3
+        out[f"{case}/q"], out[f"{case}/dt"], out[f"{case}/n"], out[f"{case}/ff"] = q, dt, n, int(ff)
+        out[f"{case}/pairs"] = np.array([[j1, *c1, r1, j2, *c2, r2] for j1, c1, r1, j2, c2, r2 in pairs], dtype=float)
+        for name, kw in (("all", dict(n_collision_pairs=len(pairs), gain=20.0, safe_displacement_gain=2.0, d_min=0.02)),
+                         ("closest2", dict(n_collision_pairs=2, gain=5.0, safe_displacement_gain=0.0, d_min=0.05))):
+            sb = SelfCollisionBarrier(**kw)
+            hb, Jb = sb.compute_barrier(ref_cfg), sb.compute_jacobian(ref_cfg)
+            G, h = sb.compute_qp_inequalities(ref_cfg, dt)
+            H, c = sb.compute_qp_objective(ref_cfg)
+            out[f"{case}/{name}/barrier"], out[f"{case}/{name}/J"] = hb, Jb
+            out[f"{case}/{name}/G"], out[f"{case}/{name}/h"], out[f"{case}/{name}/H"], out[f"{case}/{name}/c"] = G, h, H, c
+            for k, v in kw.items():
+                out[f"{case}/{name}/{k}"] = np.asarray(v, dtype=float)
     path = os.path.join(HERE, "pink_round4.npz")
     np.savez(path, **out)
     print("wrote", path, "with", len(out), "arrays")

@@ -247,6 +247,7 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
     duplicated), equalities, LM damping and dimensions; infeasible draws must be reported as such
     by both sides."""
     n_checked = 0
+    n_refuted0 = len(REFUTED)
     for sd in seeds:
         rng = np.random.default_rng(sd)
         nv = int(rng.integers(nv_lo, nv_hi))
@@ -323,6 +324,14 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
                 exact_anchor_check(J[b], e[b], ep[b], cost, dcost, lm, G[b], h[b], neq, out.dq[b], ref["dq"][b], tag=(sd, b))
                 CERTIFIED.append((sd, b, float(err[k]), float(cond[k])))
             n_checked += int(ok.sum())
+    # The refuted verdicts of this call: listed (the GPU log shows them under -s / -rP) and BOUNDED -- the harness accepts
+    # "the kernel returned the certified exact minimiser where the oracle's rule said inconsistent" as the rare round-off
+    # event it is (one seed in 284 000 in round 5), not as a way for a kernel to pass by disagreeing with the oracle.
+    new = REFUTED[n_refuted0:]
+    if new:
+        print(f"parity_suite.fuzz: oracle verdict 'inconsistent' refuted by a certified exact minimiser on (seed, instance) {new}")
+    n_seeds = len(seeds) if hasattr(seeds, "__len__") else n_checked
+    assert len(new) <= 1 + n_seeds // 20000, ("too many refuted oracle verdicts", new)
     return n_checked
 
 

@@ -64,30 +64,30 @@ WORKER = textwrap.dedent(
     batch_solver.BatchSolver = FakeSolver
     import __graft_entry__ as g
     g.build_hip = lambda force=False: None
-    sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "ur5", "--batch", "6"] + EXTRA
+    sys.argv = ["bench.py", "--gpus", "%(world)d", "--steps", "2", "--warmup", "1", "--config", "ur5", "--batch", "6"] + EXTRA
     import bench
-    bench._device_count = lambda: 2
+    bench._device_count = lambda: %(world)d
     bench.main()
     """
 )
 
 
-def _run(tmp_path, extra):
+def _run(tmp_path, extra, world=2):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "extra": extra})
+    script.write_text(WORKER % {"root": ROOT, "extra": extra, "world": world})
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PINK_BENCH_DETAIL=str(tmp_path / "detail.json"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
-    assert not outs[1][0].strip(), "only rank 0 prints"
+    assert not any(o[0].strip() for o in outs[1:]), "only rank 0 prints"
     head = _strict_headline(outs[0][0])
     assert "bench detail: {" in outs[0][1]  # the full record also goes to stderr
     detail = json.loads((tmp_path / "detail.json").read_text(), parse_constant=_no_constants)
@@ -148,11 +148,22 @@ def test_two_rank_strong_scaling_splits_the_global_batch(built, tmp_path):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather"]["bytes_per_rank"] == 8 * 5 * 6
 
 
+def test_eight_rank_strong_scaling_dry_run(built, tmp_path):
+    """BASELINE configuration 5's launch shape on CPU: eight ranks, `--scaling strong`, a global batch that does not divide
+    by eight (shards of 9 and 8) -- rendezvous, sharding, the barrier + max-over-ranks timing, the gather of dq and rank 0's
+    one JSON line, so that the first real 8-GPU lease does not debug control flow.  (No N > 1 RCCL run exists: the pool's
+    boxes have one GPU; the transport here is the host rendezvous.)"""
+    line, detail = _run(tmp_path, ["--scaling", "strong", "--global-batch", "67", "--headline-only", "--no-cpu-baseline"], world=8)
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["global_batch"] == 67 and line["value"] > 0
+    assert len(detail["per_rank_kernel_ms"]) == 8 and line["config"]["batch_per_gpu"] in (8, 9)
+    assert detail["gather"].get("rank0_shard_intact") in (True, None) and "failed" not in detail["gather"]
+
+
 def test_gpus_n_without_a_launcher_starts_n_ranks(built, tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment launches its two ranks itself (one JSON line,
     n_gpus = 2, per-rank kernel and end-to-end times) instead of running one rank."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "extra": ["--headline-only", "--no-cpu-baseline"]})
+    script.write_text(WORKER % {"root": ROOT, "extra": ["--headline-only", "--no-cpu-baseline"], "world": 2})
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["PINK_BENCH_DETAIL"] = str(tmp_path / "detail.json")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
@@ -163,7 +174,7 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(built, tmp_path):
 
 def test_gpus_n_refuses_when_devices_are_missing(built, tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text((WORKER % {"root": ROOT, "extra": []}).replace("bench._device_count = lambda: 2", "bench._device_count = lambda: 1"))
+    script.write_text((WORKER % {"root": ROOT, "extra": [], "world": 2}).replace("bench._device_count = lambda: 2", "bench._device_count = lambda: 1"))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode != 0 and "device(s) visible" in out.stderr

@@ -117,6 +117,43 @@ def test_two_rank_tcp_matches_single_process(emu, tmp_path):
     _check(emu, out)
 
 
+def _tcp_worker_wide(rank, world, port, out_path, B):
+    sys.path.insert(0, ROOT)
+    from pink_amd.comm import HostComm, HostRendezvous
+    from pink_amd.sharding import shard_bounds, solve_sharded
+    from tests.cases import config_case
+
+    comm = HostComm(HostRendezvous(rank, world, "127.0.0.1", port, token=11, timeout=120))
+    batch, _ = config_case("draco3", "tight", "dense", B)
+    lo, hi = shard_bounds(B, rank, world)
+    assert 0 <= lo <= hi <= B and hi - lo in (B // world, B // world + 1)
+    res = solve_sharded(batch, _emu_solver(), comm, gather_to=0)
+    if rank == 0:
+        np.savez(out_path, dq=res.dq, status=res.status, iters=res.iters)
+    else:
+        assert res is None
+    comm.barrier()
+    comm.rdzv.close()
+
+
+def test_eight_rank_tcp_uneven_shards_match_single_process(emu, tmp_path):
+    """World 8 (BASELINE configuration 5's rank count) over the host rendezvous, a batch that does not divide by eight
+    (131 = 524 288 / 4096 + 3: shards of 17 and 16): rank 0's gathered result is bit for bit the single-process one."""
+    from tests.cases import config_case
+
+    B, world = 131, 8
+    ctx = mp.get_context("spawn")
+    port, out = _free_port(), str(tmp_path / "gathered8.npz")
+    ps = [ctx.Process(target=_tcp_worker_wide, args=(r, world, port, out, B)) for r in range(world)]
+    [p.start() for p in ps]
+    [p.join(timeout=900) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    got = np.load(out)
+    batch, _ = config_case("draco3", "tight", "dense", B)
+    ref = emu.solve(batch)
+    assert np.array_equal(got["dq"], ref.dq) and np.array_equal(got["status"], ref.status) and np.array_equal(got["iters"], ref.iters)
+
+
 class GlooComm:
     """Test-only transport: the same ``gather_arrays`` contract on a gloo process group."""
 

