@@ -182,6 +182,8 @@ def kernel_ms_of(solver, dev, steps: int, stack: bool = False, repeats: int = 3)
     headline is timed once, over exactly K steps, in main())."""
     run = solver.stack_device if stack else solver.solve_device
     emulated = bool(getattr(solver, "device_info", None)) and solver.device_info().get("gcn_arch") == "cpu-emulator"
+    if stack:
+        steps = max(steps, 20)  # (round-5 review: identical stack-only launches read +-25 % from five launches behind a cold clock)
     if emulated:
         steps, repeats = 1, 1  # (the CPU dry runs of tests/test_bench_dryrun.py: control flow, not timing)
     run(dev)
@@ -700,10 +702,11 @@ def headline_of(line: dict, detail_path) -> dict:
     """The bounded stdout line: BASELINE.json's metric, the workload, the roofline of the dominant kernel, the CPU
     baseline and the whole-batch parity figures -- and a pointer to the detail file."""
     cfg = dict(_pick(line["config"], ("workload", "batch_per_gpu", "global_batch", "nv", "Kd", "K", "md", "parallelism")),
-               solver="dual active set on a register-resident sweep tableau, fp64, W lanes per QP, KKT-certified; GI kernel as fallback")
+               solver="principal pivoting from a guessed active set on a register-resident sweep tableau, fp64, KKT-certified; GI fallback")
     out = _pick(line, _HEADLINE_KEYS)
     out["config"] = cfg
-    out["roofline"] = _pick(line["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_qp"))
+    out["roofline"] = _pick(line["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_qp",
+                                               "bound_actual", "bound_actual_frac"))
     if "cpu_baseline" in line:
         out["cpu_baseline"] = _pick(line["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu_model", "sample"))
         out["cpu_baseline"]["label"] = line["cpu_baseline"].get("label", "")[:100]
@@ -1054,6 +1057,10 @@ def main() -> None:
             "comm_note": comm_note,
             "device": info.get("gcn_arch"),
         }
+        # what actually bounds the fused kernel, inside the roofline object (round-5 review): the VALU issue rate
+        vi = line.get("roofline_valu_issue")
+        line["roofline"]["bound_actual"] = "valu_issue"
+        line["roofline"]["bound_actual_frac"] = None if not vi else vi["frac"]
         line.update(extra)
         if not args.no_cpu_baseline:
             base, _, _ = cpu_baseline(terms)

@@ -14,7 +14,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -30,8 +30,10 @@ if os.path.exists(os.path.join(src, "bench.json")):
 if os.path.exists(os.path.join(src, "bench_detail_full.json")):  # (round 5: the stdout line is a bounded headline, this is the full record;
     # saved by gpu_profile_r05.sh right after the bench -- the profiling runs of bench.py that follow overwrite bench_detail.json)
     shutil.copy(os.path.join(src, "bench_detail_full.json"), os.path.join(dst, f"bench_detail_{tag}.json"))
-for name in ("sq_counters.txt", "sq_counters_jvrc.txt", "sq_counters_draco3b.txt", "host_latency.txt", "ab_solvers.txt", "prof_pipeline.txt",
-             "fuzz.txt", "fuzz_rollout.txt", "ab_api_arrays.txt"):
+if os.path.exists(os.path.join(src, "prof_stack", "r01_kernel_stats.csv")):  # (round 6: the stack-only kernel alone, warmed)
+    shutil.copy(os.path.join(src, "prof_stack", "r01_kernel_stats.csv"), os.path.join(dst, f"kernel_stats_stack_{tag}.csv"))
+for name in ("sq_counters.txt", "sq_counters_jvrc.txt", "sq_counters_draco3b.txt", "sq_counters_nv33.txt", "host_latency.txt", "ab_solvers.txt", "prof_pipeline.txt",
+             "fuzz.txt", "fuzz_rollout.txt", "ab_api_arrays.txt", "section_clock.txt", "stack_only_warm.txt"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
         shutil.copy(os.path.join(src, name), os.path.join(dst, name.replace(".txt", f"_{tag}.txt")))
 sys.path.insert(0, ROOT)
