@@ -101,6 +101,11 @@ typedef struct pinkhip_desc {
   double dt;                 /* timestep: barrier rows are -J_h/dt (barrier.py:246) */
   int32_t cost_is_batched;   /* cost is [B,K] instead of [K]                    */
   int32_t max_iter;          /* active-set iteration cap, <=0: 20*(nv+md)+50    */
+  int32_t n_free_lead;       /* the first n_free_lead tangent coordinates carry no bound in ANY instance of the call
+                                (lb = -inf, ub = +inf: the root of a free-flyer -- pink/limits/configuration_limit.py:50-71
+                                never selects it).  A hint for dispatch, 0 when unknown: with it nv = 33 / 34 box-only batches
+                                are solved two per wavefront (the leading coordinates are eliminated before the solve);
+                                an instance that bounds them after all is still solved, by the Goldfarb-Idnani kernel */
 } pinkhip_desc;
 
 /* Per-instance data.  Host or device pointers depending on the entry point.

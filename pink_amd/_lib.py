@@ -53,6 +53,7 @@ class Desc(ctypes.Structure):
         ("dt", ctypes.c_double),
         ("cost_is_batched", ctypes.c_int32),
         ("max_iter", ctypes.c_int32),
+        ("n_free_lead", ctypes.c_int32),
     ]
 
 
@@ -236,6 +237,12 @@ class PackedArgs:
         d.damping, d.dt = float(batch.damping), float(batch.dt)
         d.cost_is_batched = int(self.cost.ndim == 2)
         d.max_iter = int(max_iter)
+        # how many leading coordinates carry no bound in any instance (the root of a free-flyer): lets the library solve
+        # nv = 33 / 34 box-only batches two per wavefront (include/pinkhip.h, n_free_lead).  Only looked for where it matters.
+        d.n_free_lead = 0
+        if 32 < nv <= 34 and batch.md == 0 and B > 0:
+            free = np.isneginf(self.lb[:, :8]).all(axis=0) & np.isposinf(self.ub[:, :8]).all(axis=0)
+            d.n_free_lead = int(free.argmin()) if not free.all() else int(free.size)
         self.desc = d
 
     def host_problem(self) -> Problem:

@@ -10,14 +10,19 @@
 #ifndef PINKHIP_DEV_MD
 #define PINKHIP_DEV_MD 0
 #endif
+#if PINKHIP_DEV_NV > PINKHIP_DEV_W  // (front coordinates eliminated in the tableau kernel: the others hold all of them on 64 lanes)
+#define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, 64)
+#define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, 64)
+#else
 #define PINKHIP_PACKED_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
 #define PINKHIP_ROLLOUT_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_W)
+#endif
 #if PINKHIP_DEV_MD > 0
 #define PINKHIP_ROLLOUT_DENSE_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
 #else
 #define PINKHIP_ROLLOUT_DENSE_TABLE(X)
 #endif
-#if PINKHIP_DEV_NV + PINKHIP_DEV_MD > PINKHIP_DEV_W  // (more tableau rows than lanes: the dense rows are virtual)
+#if PINKHIP_DEV_NV + PINKHIP_DEV_MD > PINKHIP_DEV_W  // (more tableau rows than lanes: the dense rows are virtual / front coordinates eliminated)
 #define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, 0, PINKHIP_DEV_W)
 #else
 #define PINKHIP_SWEEP_TABLE(X) X(PINKHIP_DEV_NV, PINKHIP_DEV_MD, PINKHIP_DEV_W)
@@ -32,10 +37,12 @@
 // coordinates on the W lanes, up to MD dense rows riding in a second role of the first MD lanes (NV + MD may exceed W)
 #define PINKHIP_SWEEPX_TABLE(X) X(16, 8, 16) X(30, 6, 32) X(30, 8, 32) X(32, 8, 32)
 // X(NV, MD, W): the sweep-tableau kernel ik_solve_sweep_kernel<NV, MD, W> (ik_sweep.h): NV coordinates + MD dense rows
-// = NT <= W tableau rows, one per lane.  Ordered by NT within box-only / with dense rows; problems that fit none
+// = NT <= W tableau rows, one per lane -- or, box-only with NV > W: the first NV - W coordinates are eliminated before the
+// solve (coordinates without bounds in every instance, pinkhip_desc::n_free_lead: the root of a free-flyer) and the other W
+// ride on the lanes: X(34, 0, 32) = nv 33 / 34 two QPs per wavefront.  Ordered by NT within box-only / with dense rows; problems that fit none
 // (8-lane groups, more dense rows than lanes are left) run the Goldfarb-Idnani kernel of PINKHIP_PACKED_TABLE.
 #define PINKHIP_SWEEP_TABLE(X)                                                                                      \
-  X(8, 0, 16) X(12, 0, 16) X(16, 0, 16) X(24, 0, 32) X(30, 0, 32) X(32, 0, 32) X(34, 0, 64) X(40, 0, 64) X(48, 0, 64) X(50, 0, 64) \
+  X(8, 0, 16) X(12, 0, 16) X(16, 0, 16) X(24, 0, 32) X(30, 0, 32) X(32, 0, 32) X(34, 0, 32) X(34, 0, 64) X(40, 0, 64) X(48, 0, 64) X(50, 0, 64) \
   X(56, 0, 64) X(64, 0, 64)                                                                                         \
   X(12, 4, 16) X(24, 8, 32) X(30, 2, 32) X(30, 8, 64) X(34, 8, 64) X(40, 8, 64) X(50, 6, 64) X(50, 14, 64) X(56, 8, 64)
 // the whole-control-step kernel exists for the groups of whole 16-lane rows (broadcast-FMA stacking), box limits only
@@ -69,9 +76,11 @@ struct SweepChoice {
 };
 
 // Smallest sweep-tableau instantiation that holds nv coordinates and md dense rows ({0, 0, 0}: none).
-inline SweepChoice select_sweep(int nv, int md) {
+// n_free_lead: how many leading coordinates carry no bound in any instance (an instantiation that eliminates NV - W front
+// coordinates needs that many)
+inline SweepChoice select_sweep(int nv, int md, int n_free_lead = 0) {
 #define PINKHIP_PICK(NV_, MD_, W_) \
-  if (nv <= NV_ && md <= MD_ && (md > 0) == (MD_ > 0)) return SweepChoice{NV_, MD_, W_};
+  if (nv <= NV_ && md <= MD_ && (md > 0) == (MD_ > 0) && (NV_ <= W_ || n_free_lead >= NV_ - W_)) return SweepChoice{NV_, MD_, W_};
   PINKHIP_SWEEP_TABLE(PINKHIP_PICK)
 #undef PINKHIP_PICK
   return SweepChoice{0, 0, 0};
@@ -104,8 +113,8 @@ inline bool prefer_sweepx(int nv, int md) {
 //   * for nv <= 8 in large batches: its smallest group is 16 lanes, the Goldfarb-Idnani kernel packs eight QPs per
 //     wavefront (UR5: 71 against 49 us at B = 65 536, but 13.8 against 18.4 us at B = 4 096, where eight per wavefront
 //     leave half of the 1 024 SIMDs without a wave).
-inline bool prefer_sweep(int nv, int md, long long B) {
-  const SweepChoice sc = select_sweep(nv, md);
+inline bool prefer_sweep(int nv, int md, long long B, int n_free_lead = 0) {
+  const SweepChoice sc = select_sweep(nv, md, n_free_lead);
   if (!sc.NV) return false;
   const PackedChoice pc = select_packed(nv, md);
   if (!pc.NV) return true;

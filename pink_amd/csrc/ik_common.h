@@ -203,6 +203,7 @@ struct KernelArgs {
   int max_iter;
   int lds_pitch;     // doubles of LDS per QP (0: LdsP<NV>::stride(md)); the whole-step kernel may need more for its kinematics
   int rank_deficient;  // host_tables.h rank_deficient_by_construction(): the Goldfarb-Idnani code by dispatch
+  int n_free_lead;     // pinkhip_desc::n_free_lead (host side: which instantiation; the kernels check the bounds themselves)
   double damping, dt;
   double out_scale;  // dq is written times this: 1, or 1 / dt when the caller wants the velocity (pink/solve_ik.py:274)
   // per-instance streams

@@ -38,9 +38,21 @@ struct HbmTerms {
 struct NoMid {
   __device__ __forceinline__ void operator()() const {}
 };
-template <int NV, int W, int RCMAX, class Src, int DEPTH = 1, int NM, class Mid = NoMid>
+// NX > 0: the task rows have NX columns IN FRONT of the ones the lanes hold (a.J points at column NX of row 0; ik_sweep.h:
+// coordinates that are eliminated before the solve).  Their entries are group-uniform: lane kk of a chunk requests
+// J[r0 + kk][x - NX] with its weights and the rows hand them round with the broadcast that hands the weights round.
+// Collected: this lane's entries H[li][x] in m[x], and PER-LANE PARTIAL sums of the uniform entries (to be summed over
+// the group by the caller): hxx[0] = H[0][0], and for NX = 2 hxx[1] = H[0][1], hxx[2] = H[1][1]; cx[x] = c[x].
+template <int NX>
+struct StackFront {
+  double m[NX > 0 ? NX : 1] = {};
+  double hxx[NX > 0 ? NX * (NX + 1) / 2 : 1] = {};
+  double cx[NX > 0 ? NX : 1] = {};
+};
+template <int NV, int W, int RCMAX, class Src, int DEPTH = 1, int NX = 0, int NM, class Mid = NoMid>
 __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long b, Src *terms, bool in, int li,
-                                                 double (&M)[NM], double &ci, double &mu_l, Mid mid = Mid()) {
+                                                 double (&M)[NM], double &ci, double &mu_l, Mid mid = Mid(), StackFront<NX> *front = nullptr) {
+  static_assert(NX >= 0 && NX <= 2 && (NX == 0 || !Src::kOnTheFly), "at most two front columns, from HBM");
   static_assert(NM >= NV && W >= 16, "row-group kernels only");
   using BcT = Bcast<W>;
   const int nv = a.nv, Kd = a.Kd, K = a.K;
@@ -53,6 +65,7 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
   struct Chunk {
     double r[RC];
     double pw, pe, pg, pl;
+    double px[NX > 0 ? NX : 1];
   };
   Chunk buf[NB];
   auto request = [&](Chunk &dst, int r0) {
@@ -67,6 +80,10 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
       for (int kk = 0; kk < RC; ++kk) dst.r[kk] = (in && kk < rc) ? Jb[(long long)(r0 + kk) * nv + li] : 0.0;
     }
     dst.pw = dst.pe = dst.pg = dst.pl = 0.0;
+    if constexpr (NX > 0) {
+#pragma unroll
+      for (int x = 0; x < NX; ++x) dst.px[x] = (li < rc) ? Jb[(long long)(r0 + li) * nv - NX + x] : 0.0;
+    }
     if (li < rc) {
       const int k = r0 + li;
       dst.pw = costb[k];
@@ -90,6 +107,19 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
     const double gw = (li < rc) ? cur.pg * wa * cur.pe : 0.0;
     if (li < rc) mu_l += cur.pl * (cur.pg * cur.pg) * wa * cur.pe * cur.pe;
     const BcT wab = bcast_prepare<W>(wa), gwb = bcast_prepare<W>(gw);
+    BcT pxb[NX > 0 ? NX : 1];
+    if constexpr (NX > 0) {
+      // (lane kk's own row: its part of the uniform entries)
+      front->hxx[0] = fma(wa * cur.px[0], cur.px[0], front->hxx[0]);
+      front->cx[0] = fma(gw, cur.px[0], front->cx[0]);
+      if constexpr (NX == 2) {
+        front->hxx[1] = fma(wa * cur.px[0], cur.px[1], front->hxx[1]);
+        front->hxx[2] = fma(wa * cur.px[1], cur.px[1], front->hxx[2]);
+        front->cx[1] = fma(gw, cur.px[1], front->cx[1]);
+      }
+#pragma unroll
+      for (int x = 0; x < NX; ++x) pxb[x] = bcast_prepare<W>(cur.px[x]);
+    }
     static_for<0, RC>([&](auto Kc) {
       constexpr int kk = decltype(Kc)::value;
       if (kk < rc) {  // wave-uniform
@@ -100,6 +130,10 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
           constexpr int j = decltype(Jc)::value;
           M[j] = fma_bcast<W, j>(M[j], rowb, aa);
         });
+        if constexpr (NX > 0) {
+#pragma unroll
+          for (int x = 0; x < NX; ++x) front->m[x] = fma_bcast<W, kk>(front->m[x], pxb[x], aa);  // H[li][x] += (w^2 J[k][li]) J[k][x]
+        }
       }
     });
 #pragma unroll

@@ -214,6 +214,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   {
     const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
     const double kest = -group_min<W>(-(hii0 * zd0));
+    PINKHIP_TRACEF(li == 0, "[sweepx g%d] kest %.3e\n", g, kest);
     if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;
   }
   PINKHIP_TICK(2);  // x0, dense part
@@ -469,6 +470,8 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       const bool more = group_first_lane<W>(fabs(dxc) > 1e-9 * fabs(x) + 1e-11 * (1.0 + xmax)) < W;  // (ik_sweep.h: relative floor)
       const double dmax = -group_min<W>(-fabs(dxc));
       const bool sane = dmax <= ((nref == 0) ? 0.1 * xmax : 0.5 * dprev);
+      PINKHIP_TRACEF(li == 0 && ref, "[sweepx g%d it%d nref%d] closing: cert_fails %d more %d sane %d dmax %.3e xmax %.3e dprev %.3e\n", g, it, nref, (int)cert_fails,
+                     (int)more, (int)sane, dmax, xmax, dprev);
       if (ref) {
         if (status != STATUS_OPTIMAL) {
           status = STATUS_BREAKDOWN;  // a verdict reached on the tableau is confirmed by the Goldfarb-Idnani code

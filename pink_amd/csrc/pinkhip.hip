@@ -126,9 +126,9 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   // kernel (ik_sweep.h, tu_sweep.hip) serves every problem it is instantiated for; the Goldfarb-Idnani kernel
   // (ik_kernels_packed.h, tu_packed.hip) the rest: 8-lane groups (nv <= 8), more dense rows than lanes are left.
   const char *solver_env = std::getenv("PINKHIP_SOLVER");  // development / tests: "packed" / "sweep" force one kernel
-  const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
+  const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md, a.n_free_lead);
   const bool sweep = solver_env ? (std::strcmp(solver_env, "packed") != 0 && sc.NV != 0)
-                                : (pinkhip::prefer_sweep(a.nv, a.md, a.B) && !a.rank_deficient);
+                                : (pinkhip::prefer_sweep(a.nv, a.md, a.B, a.n_free_lead) && !a.rank_deficient);
   // ... with virtual dense rows where that packs more QPs into a wavefront (ik_sweepx.h, dispatch.h prefer_sweepx)
   const pinkhip::SweepChoice xc = pinkhip::select_sweepx(a.nv, a.md);
   const bool sweepx = solver_env ? (std::strcmp(solver_env, "sweepx") == 0 && xc.NV != 0)
@@ -148,9 +148,9 @@ int launch(pinkhip_handle *h, const KernelArgs &a, bool solve) {
   }
   if (sweep) {
     hipError_t es = hipErrorInvalidValue;
-    switch (sc.NV * 100 + sc.MD) {
+    switch (sc.NV * 10000 + sc.MD * 100 + sc.W) {
 #define PINKHIP_CASE(NV, MD, W)                                            \
-  case NV * 100 + MD:                                                      \
+  case NV * 10000 + MD * 100 + W:                                          \
     es = pinkhip::PINKHIP_LAUNCH_SWEEP_NAME(NV, MD, W)(h->stream, a);      \
     break;
       PINKHIP_SWEEP_TABLE(PINKHIP_CASE)
@@ -184,6 +184,7 @@ int prepare(pinkhip_handle *h, const pinkhip_desc *d, KernelArgs &a) {
   const std::string why = pinkhip::build_tables(*d, t);
   if (!why.empty()) return fail(h, PINKHIP_E_INVALID, why);
   a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
+  a.n_free_lead = (d->n_free_lead > 0 && d->n_free_lead <= d->nv) ? d->n_free_lead : 0;
   a.out_scale = 1.0;
   PH_HIP(h, hipSetDevice(h->device));
 

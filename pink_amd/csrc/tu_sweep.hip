@@ -20,6 +20,8 @@ hipError_t PINKHIP_LAUNCH_SWEEP_NAME(PINKHIP_TU_NV, PINKHIP_TU_MD, PINKHIP_TU_W)
   // LDS: the stated problem (H packed, c, columns of G) parked for the closing refinement step
   using SL = SweepLds<NV, MD, W>;
   static_assert(sweep_lds_doubles(NV, MD, W) == SL::stride, "dispatch.h restates the LDS layout");
+  // (front coordinates eliminated: their recovery data sits behind the area of the W-coordinate tableau)
+  static_assert(NV <= W || sweep_kernel_lds_doubles<NV, MD, W>(0) >= SweepLds<(NV <= W ? NV : W), 0, W>::stride + 2 * W + 8, "LDS of the elimination");
   KernelArgs k = a;
   k.lds_pitch = sweep_kernel_lds_doubles<NV, MD, W>(a.md);  // (room for the hand-over to the Goldfarb-Idnani kernel)
   const size_t lds = 8 * static_cast<size_t>(k.lds_pitch) * G + 16;

@@ -49,6 +49,13 @@
 #define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 4 : (NT) <= 34 ? 3 : 2)
 #endif
 #define PINKHIP_OCCUPANCY_SWEEP(NT) __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEP_WAVES(NT), PINKHIP_SWEEP_WAVES(NT))))
+// ... with front coordinates eliminated (NV > W: W tableau rows + what the elimination carries through the stacking)
+#ifndef PINKHIP_SWEEP_ELIM_WAVES
+#define PINKHIP_SWEEP_ELIM_WAVES 2  // (three: 60 spilled registers, 0.64 ms per 65 536 at nv = 33; two: none, 0.48 ms)
+#endif
+#define PINKHIP_OCCUPANCY_SWEEP3(NV, MD, W)                                                                             \
+  __attribute__((amdgpu_waves_per_eu(((NV) > (W) ? PINKHIP_SWEEP_ELIM_WAVES : PINKHIP_SWEEP_WAVES((NV) + (MD))),     \
+                                     ((NV) > (W) ? PINKHIP_SWEEP_ELIM_WAVES : PINKHIP_SWEEP_WAVES((NV) + (MD))))))
 // ... with virtual dense rows (ik_sweepx.h): a lane holds NV + 2 MD doubles of tableau (its row + row d of the
 // dense-dense block)
 #ifndef PINKHIP_SWEEPX_WAVES

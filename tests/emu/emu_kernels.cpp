@@ -85,10 +85,11 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
       case 4: fn = lane_main_stack_mfma<4>; break;
     }
   } else {  // the dispatch rule of the library (dispatch.h, pinkhip.hip launch())
-    const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md);
+    a.n_free_lead = (d->n_free_lead > 0 && d->n_free_lead <= d->nv) ? d->n_free_lead : 0;
+    const pinkhip::SweepChoice sc = pinkhip::select_sweep(a.nv, a.md, a.n_free_lead);
     const char *force = std::getenv("PINKHIP_SOLVER");  // "packed" / "sweep": one kernel for every problem it serves
     a.rank_deficient = pinkhip::rank_deficient_by_construction(*d) ? 1 : 0;
-    const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : (pinkhip::prefer_sweep(a.nv, a.md, d->B) && !a.rank_deficient);
+    const bool sweep = force ? (std::string(force) != "packed" && sc.NV != 0) : (pinkhip::prefer_sweep(a.nv, a.md, d->B, a.n_free_lead) && !a.rank_deficient);
     const pinkhip::SweepChoice xc = pinkhip::select_sweepx(a.nv, a.md);
     const bool sweepx = force ? (std::string(force) == "sweepx" && xc.NV != 0) : (pinkhip::prefer_sweepx(a.nv, a.md) && !a.rank_deficient);
     if (sweepx) {
@@ -103,9 +104,9 @@ int run(const pinkhip_desc *d, const pinkhip_problem *in, const pinkhip_result *
       }
     }
     if (!fn && sweep) {
-      switch (sc.NV * 100 + sc.MD) {
+      switch (sc.NV * 10000 + sc.MD * 100 + sc.W) {
 #define PINKHIP_CASE(NV, MD, W)                \
-  case NV * 100 + MD:                          \
+  case NV * 10000 + MD * 100 + W:              \
     fn = emu_lookup(KIND_SWEEP, NV, MD, W);    \
     blocks = (d->B + 64 / W - 1) / (64 / W);   \
     break;

@@ -26,6 +26,7 @@
 #define PINKHIP_OCCUPANCY_ATTR(NV)
 #define PINKHIP_OCCUPANCY_PACKED(NV, DENSE)
 #define PINKHIP_OCCUPANCY_SWEEP(NT)
+#define PINKHIP_OCCUPANCY_SWEEP3(NV, MD, W)
 #define PINKHIP_OCCUPANCY_SWEEPX(NV, MD)
 #define PINKHIP_OCCUPANCY_ROLLOUT(NV)
 #define PINKHIP_OCCUPANCY_FK
