@@ -255,20 +255,6 @@ def run(name, B, bounds, error_scale, variants):
               f"  total pivots {(flips + rest + gt).mean():.2f}  VALU/QP {cost.mean():.0f}  pair-max {pm(cost):.0f}")
 
 
-if __name__ == "__main__":
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    name = sys.argv[2] if len(sys.argv) > 2 else "draco3"
-    bounds = sys.argv[3] if len(sys.argv) > 3 else "tight"
-    es = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
-    variants = [
-        ("pdas outer<=8 patience 1", dict(max_outer=8, patience=1)),
-        ("pdas outer<=4 patience 0", dict(max_outer=4, patience=0)),
-        ("pdas outer<=20 patience 3", dict(max_outer=20, patience=3)),
-        ("pdas frac .25 outer<=12", dict(max_outer=12, patience=2, frac=0.25)),
-        ("pdas frac .5 outer<=12", dict(max_outer=12, patience=2, frac=0.5)),
-        ("pdas frac .1 outer<=12", dict(max_outer=12, patience=2, frac=0.1)),
-    ]
-    if os.environ.get("PDAS"): run(name, B, bounds, es, variants)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -368,19 +354,133 @@ def run_candidates(name, B, bounds, error_scale, variants):
               f"  VALU/QP {cost.mean():5.0f} pair-max {pm(cost):5.0f}   [today's trip costs: {pm(old):5.0f}]")
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# Single principal pivoting (what ik_sweep.h runs since round 6): every trip exchanges the ONE index whose
+# complementarity condition fails with the largest weight -- no ratio test, no pending constraint.
+def ppm(tb: Tableau, weight="objective", topk=1, max_iter=400):
+    n = trips = 0
+    while n < max_iter:
+        vlo, vup = tb.violations()
+        dv = tb.dual_violations()
+        if not (vlo.any() or vup.any() or dv.any()):
+            return n, trips
+        d = np.abs(np.diag(tb.T))
+        v = np.where(vlo, tb.x - tb.lb, np.where(vup, tb.ub - tb.x, np.where(dv, tb.u, 0.0)))
+        key = v * v / np.maximum(d, 1e-300) if weight == "objective" else v * v
+        trips += 1
+        done = 0
+        for p in np.argsort(-key)[:topk]:
+            if key[p] <= 0:
+                break
+            if done:
+                vlo2, vup2 = tb.violations()
+                dv2 = tb.dual_violations()
+                if not (vlo2[p] or vup2[p] or dv2[p]):
+                    continue
+                vlo, vup = vlo2, vup2
+            tb.pivot(p)
+            tb.state[p] = (1 if vlo[p] else 2) if tb.state[p] == 0 else 0
+            tb.recompute()
+            n += 1
+            done += 1
+    return -1, trips
+
+
+def set_basis(tb: Tableau, st):
+    """The tableau of a given partition from scratch (a guessed active set as the start)."""
+    n, H = tb.n, tb.H
+    tb.state = st.astype(int)
+    F = st == 0
+    T = np.zeros((n, n))
+    if F.any():
+        inv = np.linalg.inv(H[np.ix_(F, F)])
+        T[np.ix_(F, F)] = -inv
+        if (~F).any():
+            Hnf = H[np.ix_(~F, F)]
+            T[np.ix_(~F, F)] = Hnf @ inv
+            T[np.ix_(F, ~F)] = (Hnf @ inv).T
+            T[np.ix_(~F, ~F)] = H[np.ix_(~F, ~F)] - Hnf @ inv @ Hnf.T
+    else:
+        T[:] = H
+    tb.T = T
+    tb.recompute()
+    return int(F.sum())
+
+
+def guess(tb: Tableau, rule):
+    """Which coordinates start fixed: `diag` = the bound that -c_i / H_ii violates (ik_sweep.h); `jacobiK` / `gsK` = K
+    projected Jacobi / Gauss-Seidel iterations on top; `c` = every bounded coordinate, side by the sign of c."""
+    H, c, lb, ub = tb.H, tb.c, tb.lb, tb.ub
+    d = np.diag(H)
+    if rule == "c":
+        bounded = np.isfinite(lb) & np.isfinite(ub)
+        return np.where(bounded, np.where(c > 0, 1, 2), 0)
+    x = -c / d
+    if rule.startswith("jacobi"):
+        for _ in range(int(rule[6:])):
+            xc = np.clip(x, lb, ub)
+            x = -(c + H @ xc - d * xc) / d
+    elif rule.startswith("gs"):
+        xc = np.clip(x, lb, ub)
+        for _ in range(int(rule[2:])):
+            for i in range(len(c)):
+                x[i] = -(c[i] + H[i] @ xc - d[i] * xc[i]) / d[i]
+                xc[i] = min(max(x[i], lb[i]), ub[i])
+    return np.where(x < lb, 1, np.where(x > ub, 2, 0))
+
+
+def run_ppm(name, B, bounds, error_scale):
+    terms = synthetic.make_terms(name, B, bounds=bounds, error_scale=error_scale)
+    batch = synthetic.pack(terms)
+    ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms), want_Hc=True, nthreads=8)
+    H, c, lb, ub = ref["H"], ref["c"], batch.lb, batch.ub
+
+    def pm(a):
+        return np.maximum(a[0::2], a[1::2]).mean()
+
+    print(f"== principal pivoting: {name} bounds={bounds} error_scale={error_scale} B={B}; oracle (quadprog's rule) {ref['iters'].mean():.2f} steps")
+    for label, kw in (("largest objective change", dict()), ("largest violation", dict(weight="none")), ("two per trip", dict(topk=2)), ("three per trip", dict(topk=3))):
+        n = np.zeros(B, int)
+        t = np.zeros(B, int)
+        for b in range(B):
+            tb = Tableau(H[b], c[b], lb[b], ub[b])
+            n[b], t[b] = ppm(tb, **kw)
+            assert n[b] >= 0 and np.abs(tb.x - ref["dq"][b]).max() < 1e-8, (label, b)
+        print(f"   from the unconstrained minimum, {label:26s} pivots {n.mean():6.2f} trips {t.mean():6.2f} (pair-max {pm(t):6.2f}) max {n.max()}")
+    for rule in ("diag", "c", "jacobi1", "jacobi2", "gs1", "gs2"):
+        n = np.zeros(B, int)
+        sw = np.zeros(B, int)
+        free = []
+        for b in range(B):
+            tb = Tableau(H[b], c[b], lb[b], ub[b])
+            st = guess(tb, rule)
+            free.append(st == 0)
+            sw[b] = set_basis(tb, st)
+            n[b], _ = ppm(tb)
+            assert n[b] >= 0 and np.abs(tb.x - ref["dq"][b]).max() < 1e-8, (rule, b)
+        union = np.array([(free[2 * i] | free[2 * i + 1]).sum() for i in range(B // 2)])
+        print(f"   from the guess `{rule:7s}`: sweeps {sw.mean():5.1f} (union of a wave's two QPs {union.mean():5.1f})  pivots {n.mean():6.2f} (pair-max {pm(n):6.2f}) max {n.max()}"
+              f"   ~VALU per QP {40 * union.mean() + 165 * pm(n):.0f}")
+
+
 if __name__ == "__main__":
-    cv = [
-        ("single (today's rule)", dict(frac=1.0)),
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    name = sys.argv[2] if len(sys.argv) > 2 else "draco3"
+    bounds = sys.argv[3] if len(sys.argv) > 3 else "tight"
+    es = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+    run(name, B, bounds, es, [
+        ("pdas outer<=8 patience 1", dict(max_outer=8, patience=1)),
+        ("pdas outer<=20 patience 3", dict(max_outer=20, patience=3)),
+        ("pdas frac .25 outer<=12", dict(max_outer=12, patience=2, frac=0.25)),
+        ("pdas frac .5 outer<=12", dict(max_outer=12, patience=2, frac=0.5)),
+    ])
+    run_candidates(name, B, bounds, es, [
+        ("single (round 5's rule)", dict(frac=1.0)),
         ("frac .5 index order", dict(frac=0.5)),
-        ("frac .25 index order", dict(frac=0.25)),
-        ("frac .1 index order", dict(frac=0.1)),
-        ("all violated index order", dict(frac=0.0)),
         ("frac .25 key order", dict(frac=0.25, order="key")),
-        ("frac .1 key order", dict(frac=0.1, order="key")),
         ("all violated key order", dict(frac=0.0, order="key")),
-        ("frac .25 best-first", dict(frac=0.25, order="best-first")),
         ("top 2 key order", dict(frac=0.0, order="key", kmax=2)),
         ("top 4 key order", dict(frac=0.0, order="key", kmax=4)),
-        ("top 8 key order", dict(frac=0.0, order="key", kmax=8)),
-    ]
-    run_candidates(name, B, bounds, es, cv)
+    ])
+    run_ppm(name, B, bounds, es)

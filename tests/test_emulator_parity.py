@@ -104,6 +104,15 @@ def test_fuzz_weakly_regularised(emu):
     assert [c[:2] for c in ps.CERTIFIED] == [(415035, 0)] and not ps.EXACT_UNSETTLED
 
 
+def test_seeds_the_wide_gpu_fuzz_of_round_6_stopped_on(emu):
+    """Three weakly regularised draws of scripts/gpu_fuzz.py 3000000 100000 (28 .. 30 coordinates with three or four dense
+    rows, conditioning estimates 3e8 .. 2e9): the tableau's point passed its certificate 2e-5 .. 8e-5 from the exact minimiser,
+    the Goldfarb-Idnani oracle is within 4e-9 of it -- on round 5's kernels as well.  The certificate cannot see an error
+    along a direction in which the residual is below its own round-off; such instances go to the Goldfarb-Idnani code by
+    their conditioning estimate (PINKHIP_SWEEP_ROUTE_COND = 1e8 since)."""
+    assert ps.fuzz(emu, [3063897, 3074349, 3085897], ill=True) >= 12
+
+
 def test_kkt_certificate_independent_of_the_oracle_solver(emu):
     assert ps.kkt_certificate(emu, range(9000, 9060)) > 80
     # seed 704011 (wide GPU fuzz, round 5): two equalities with negative multipliers at a vertex -- the certificate's own
