@@ -108,6 +108,14 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #ifndef PINKHIP_SWEEP_PPM_CRASH_MIN
 #define PINKHIP_SWEEP_PPM_CRASH_MIN 2
 #endif
+// Curvature left along the normal of a coordinate that is fixed / a row that is activated, relative to (a lower bound of) the
+// unreduced one, below which principal pivoting does not pivot: the group goes on with the dual method, which forms a small
+// curvature again as a sum of squares and knows what to do about a dependent normal.  An exchange on 5.6e-8 of it (one
+// instance in 65 536 of the nv = 30 + 6 rows batch) multiplied the tableau's round-off by its reciprocal: nu = 1e10, a
+// certificate that failed by 3e-2, the hand-over.
+#ifndef PINKHIP_SWEEP_PPM_MIN_CURV
+#define PINKHIP_SWEEP_PPM_MIN_CURV 1e-5
+#endif
 #ifndef PINKHIP_SWEEP_PPM_MURTY_AFTER
 #define PINKHIP_SWEEP_PPM_MURTY_AFTER(nv) (4 * (nv) + 20)
 #endif
@@ -520,7 +528,9 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   // group skips the tableau iteration and goes to the Goldfarb-Idnani code right away instead of paying both.
   {
     const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
-    const double kest = -group_min<W>((PPX && state != 0) ? 0.0 : hii0 * tdiag);
+    // (a coordinate the guess fixed: H_ii over its Schur complement T_ii -- H_ii (H^-1)_ii on the free set plus this one:
+    // the flat directions of a weakly regularised objective show there when the guess fixes the coordinates they live on)
+    const double kest = -group_min<W>((PPX && state != 0) ? -hii0 * approx_rcp(tdiag) : hii0 * tdiag);
     PINKHIP_TRACEF(li == 0, "[sweep g%d] kest %.3e\n", g, kest);
     if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;  // (NaN: routed)
   }
@@ -1032,7 +1042,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
           // coordinate freed and a row released, pivot on the reciprocal of such a curvature: positive, of any size.
           const double zr = group_bcast<W>(zd0, src);
           const bool recip = (src < NV) == (nb_src != 0);
-          const bool irregular = actP && !((recip ? pv : -pv) > (recip ? 0.0 : 1e-8 * zr));
+          const bool irregular = actP && !((recip ? pv : -pv) > (recip ? 0.0 : PINKHIP_SWEEP_PPM_MIN_CURV * zr));
           // (the right-hand side of a dependent equality; cross-lane: wave-uniform control flow)
           double hs = 0.0;
           if (wave_any(irregular && iseq)) hs = group_bcast<W>(hv, src);

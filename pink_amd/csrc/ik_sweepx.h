@@ -25,6 +25,11 @@
 
 #include "ik_sweep.h"
 
+// 0: round 5's Goldfarb-Idnani trips from the unconstrained minimum (A/B: profiles/ab_ppm_r06.txt)
+#ifndef PINKHIP_SWEEPX_PPM
+#define PINKHIP_SWEEPX_PPM 1
+#endif
+
 namespace pinkhip {
 
 template <int NV, int MD, int W>
@@ -42,6 +47,11 @@ template <int NV, int MD, int W, class Src = HbmTerms>
 __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long block, Src *terms = nullptr) {
   constexpr int NT = NV + MD;
   static_assert((W == 16 || W == 32 || W == 64) && NV <= W && NV % 2 == 0 && MD >= 1 && MD <= 16 && MD <= W, "dense rows ride in the first MD lanes");
+  // principal pivoting from a guessed active set in front of the dual method, as in ik_sweep.h (both roles of a lane take
+  // part: `x / -g` of a coordinate and its interval, slack / multiplier of a dense row); the arg-min's 8-bit payload holds
+  // lane (5 bits), side, role and "nonbasic"
+  constexpr bool PPX = PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE && PINKHIP_SWEEPX_PPM && W <= 32;
+  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH;
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;
@@ -121,9 +131,13 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     }
   }
   diag += dadd;
+  double hii = 1.0;  // H[li][li]
 #pragma unroll
   for (int j = 0; j < NV; ++j)
-    if (j == li) T[j] += in ? diag : 1.0;  // padded coordinates: identity rows, never pivoted
+    if (j == li) {
+      T[j] += in ? diag : 1.0;  // padded coordinates: identity rows, never pivoted
+      hii = T[j];
+    }
   // the QP as stated, parked for the closing trips (ik_sweep.h): H (lower triangle, packed), c, the columns of G
   double *sm = shared_base() + (long long)g * (a.lds_pitch ? a.lds_pitch : SL::stride);
   wave_sync();
@@ -144,22 +158,60 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // -- infinities, NaN -- and never iterates on it; one v_min per column instead of a compare and three selects)
   int status = STATUS_OPTIMAL;
   double pmin = INF;
-  static_for<0, NV>([&](auto Kc) {
-    constexpr int k = decltype(Kc)::value;
-    if (k < nv) {  // wave-uniform
-      const BcT xb = bcast_prepare<W>(T[k]);
-      const double p = value_bcast<W, k>(xb);
-      pmin = min_raw(pmin, p);
-      const double rp = fast_rcp(p);
-      const double t = T[k] * rp;
-      const double nt = (li == k) ? rp - 1.0 : -t;
-      static_for<0, NV>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
-      });
-      T[k] = (li == k) ? -rp : t;
+  int state = 0;  // coordinate role: 0 = free, 1 = fixed at lb, 2 = fixed at ub
+  if constexpr (Src::kOnTheFly) {
+    lbv = in ? terms->lb : -INF;
+    ubv = in ? terms->ub : INF;
+  }
+  if constexpr (GUESS) {
+    // where it starts: the guessed active set of ik_sweep.h (coordinate i fixed at the bound -c_i / H_ii violates), only the
+    // free coordinates swept in; in the whole-step kernel per robot, when the guess fixes more than two coordinates
+    if (group_first_lane<W>(in && !(hii > 0.0)) < W) status = STATUS_NOT_PD;
+    const double xd = -ci * approx_rcp(hii);
+    if (in) state = (xd < lbv) ? 1 : ((xd > ubv) ? 2 : 0);
+    if constexpr (Src::kOnTheFly) {
+      const unsigned long long fixm = wave_ballot(state != 0);
+      const int nfix = __builtin_popcountll((fixm >> (lane & ~(W - 1))) & ((1ull << W) - 1ull));
+      if (!(nfix > PINKHIP_SWEEP_PPM_CRASH_MIN)) state = 0;
     }
-  });
+    const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
+    const unsigned gfree = static_cast<unsigned>(fm >> (lane & ~(W - 1)));  // this lane's group
+    static_for<0, NV>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      const bool want = ((gfree >> k) & 1) != 0;
+      if (lanes_on(want)) {  // (wave.h: the other groups' lanes are switched off for the sweep)
+        const BcT xb = bcast_prepare<W>(T[k]);
+        const double p = value_bcast<W, k>(xb);
+        pmin = min_raw(pmin, want ? p : INF);
+        const double rp = fast_rcp(p);
+        const double t = T[k] * rp;
+        double nt = (li == k) ? rp - 1.0 : -t;
+        if (!want) nt = 0.0;
+        static_for<0, NV>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
+        });
+        if (want) T[k] = (li == k) ? -rp : t;
+      }
+    });
+  } else {
+    static_for<0, NV>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      if (k < nv) {  // wave-uniform
+        const BcT xb = bcast_prepare<W>(T[k]);
+        const double p = value_bcast<W, k>(xb);
+        pmin = min_raw(pmin, p);
+        const double rp = fast_rcp(p);
+        const double t = T[k] * rp;
+        const double nt = (li == k) ? rp - 1.0 : -t;
+        static_for<0, NV>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (j != k) T[j] = fma_bcast<W, j>(T[j], xb, nt);
+        });
+        T[k] = (li == k) ? -rp : t;
+      }
+    });
+  }
   if (!(pmin > 0.0)) status = STATUS_NOT_PD;
   PINKHIP_TICK(1);  // initial sweeps
   double tdiag = 0.0;
@@ -167,10 +219,13 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   for (int j = 0; j < NV; ++j)
     if (j == li) tdiag = T[j];
 
-  // x0 = -H^-1 c
+  // x0 = -H^-1 c -- from a guessed active set: v = c on the free coordinates, -bound on the fixed ones; the product is x on a
+  // free coordinate and c - g on a fixed one (DESIGN_HISTORY.md C.1)
   double x = 0.0;
+  const bool fixed0 = GUESS && state != 0;
+  const double xstart_fixed = (state == 1) ? lbv : ubv;
   {
-    const BcT cb = bcast_prepare<W>(in ? ci : 0.0);
+    const BcT cb = bcast_prepare<W>(in ? (fixed0 ? -xstart_fixed : ci) : 0.0);
     double r0 = 0.0, r1 = 0.0;
     static_for<0, NV>([&](auto Jc) {
       constexpr int j = decltype(Jc)::value;
@@ -179,28 +234,32 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     });
     x = in ? r0 + r1 : 0.0;
   }
+  const double xpoint = fixed0 ? xstart_fixed : x;  // the start point itself
+  if (fixed0) x -= ci;                              // ... and the lane's quantity: -g of a fixed coordinate
   // The dense part of the tableau swept on every coordinate, in closed form:
   //   T[m][NV + d] = (H^-1 g_d)_m = -sum_j T[m][j] G[d][j],   D[d][d'] = -g_d^T H^-1 g_d' = -sum_m G[d][m] T[m][NV + d'],
   // and the slack of row d at x0: h_d - g_d x0.
+  // (swept on the free coordinates F only, DESIGN_HISTORY.md C.3: the sums run over F, a fixed coordinate keeps its entry
+  // G[d][m] in front of its sum)
   double D[MD], ud = 0.0;
   {
-    const double gx0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * x; });
+    const double gx0 = transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * xpoint; });
     if (dl) ud = hv - gx0;
     double Tn[MD];
     static_for<0, MD>([&](auto Dc) {
       constexpr int d = decltype(Dc)::value;
-      const BcT gb = bcast_prepare<W>(T[NV + d]);
+      const BcT gb = bcast_prepare<W>(fixed0 ? 0.0 : T[NV + d]);
       double s0 = 0.0, s1 = 0.0;
       static_for<0, NV>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         if constexpr (j % 2 == 0) s0 = fma_bcast<W, j>(s0, gb, T[j]);
         else s1 = fma_bcast<W, j>(s1, gb, T[j]);
       });
-      Tn[d] = (li < NV) ? -(s0 + s1) : 0.0;
+      Tn[d] = (li < NV) ? (fixed0 ? T[NV + d] : 0.0) - (s0 + s1) : 0.0;
     });
     static_for<0, MD>([&](auto Pc) {
       constexpr int dp = decltype(Pc)::value;
-      D[dp] = -transpose_reduce<W, MD, 0>([&](auto Dc) { return T[NV + decltype(Dc)::value] * Tn[dp]; });
+      D[dp] = -transpose_reduce<W, MD, 0>([&](auto Dc) { return (fixed0 ? 0.0 : T[NV + decltype(Dc)::value]) * Tn[dp]; });
     });
     static_for<0, MD>([&](auto Dc) { T[NV + decltype(Dc)::value] = Tn[decltype(Dc)::value]; });
   }
@@ -209,11 +268,18 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   for (int d = 0; d < MD; ++d)
     if (d == li) ddiag = D[d];
   // n^T H^-1 n of a constraint normal: the reference of the linear-dependence test
-  const double zd0 = -tdiag, zdd0 = -ddiag;
+  // (from a guessed active set the tableau does not hold it: lower bounds of its size stand in, as in ik_sweep.h)
+  double zd0 = -tdiag, zdd0 = -ddiag;
+  if constexpr (GUESS) {
+    const double hmax = -group_min<W>(in ? -hii : 0.0);
+    zd0 = approx_rcp(hii);
+    zdd0 = approx_rcp(ginv * ginv * hmax);
+  }
   // conditioning estimate (ik_sweep.h): beyond the threshold the group goes to the Goldfarb-Idnani code right away
   {
     const double hii0 = (li < NV && in) ? sm[SL::tri(li < NV ? li : 0) + (li < NV ? li : 0)] : 0.0;
-    const double kest = -group_min<W>(-(hii0 * zd0));
+    // (a coordinate the guess fixed: H_ii over its Schur complement T_ii -- H_ii (H^-1)_ii on the free set plus this one)
+    const double kest = -group_min<W>((GUESS && state != 0) ? -hii0 * approx_rcp(tdiag) : hii0 * tdiag);
     PINKHIP_TRACEF(li == 0, "[sweepx g%d] kest %.3e\n", g, kest);
     if (status == STATUS_OPTIMAL && !(kest <= PINKHIP_SWEEP_ROUTE_COND)) status = STATUS_ROUTED;
   }
@@ -222,17 +288,12 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // ------------------------------------------------------------------ dual active set on the tableau
   const KernelArgs *late = &a;
   if constexpr (!Src::kOnTheFly) late = kernarg_reload<KernelArgs>(a);
-  if constexpr (Src::kOnTheFly) {
-    lbv = in ? terms->lb : -INF;
-    ubv = in ? terms->ub : INF;
-  }
   const double tol = 1e-13 * (nv > 8 ? nv * 0.125 : 1.0);
   const double thr_lo = -tol * (1.0 + fabs(lbv)), thr_up = -tol * (1.0 + fabs(ubv));
   const double thr_d = -tol * (1.0 + fabs(hv) * ginv);
   const int max_iter = late->max_iter > 0 ? late->max_iter : 20 * (nv + md) + 50;
   const bool empty_box_somewhere = wave_any(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up));
-  // coordinate role: state 0 = free, 1 = fixed at lb, 2 = fixed at ub; x; u = multiplier of a fixed coordinate
-  int state = 0;
+  // coordinate role (state: above): x; u = multiplier of a fixed coordinate
   double u = 0.0, phi = 0.0, xfree = 1.0;
   // dense role: dstate 0 = inactive (ud = slack h - g x), 1 = active (ud = multiplier); dphi = 1 for an active inequality
   int dstate = 0;
@@ -240,6 +301,25 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // group-uniform.  src / kd / pi are GLOBAL indices: < NV a coordinate, NV + d dense row d
   int it = 0, eq_next = 0, src = 0, kind = 0;  // kind 0: lower bound, 1: upper bound, 2: dense row, 3: equality row
   double uplus = 0.0;
+  // principal pivoting (ik_sweep.h): the interval of the coordinate role's quantity and the thresholds of its two tests; the
+  // dense role's quantity (slack / multiplier) lives in [0, inf) -- dtlo = the slack's threshold while the row is inactive, 0
+  // while it is active; an active equality's multiplier has either sign (dlo = -inf)
+  double blo = lbv, bhi = ubv, tlo = thr_lo, thi = thr_up;
+  const double thr_row = thr_d * fast_rcp(ginv);
+  double dlo = 0.0, dtlo = (dl && li >= n_eq) ? thr_row : -INF;
+  if constexpr (PPX) {
+    if (state != 0) {
+      blo = (state == 1) ? -INF : 0.0;
+      bhi = (state == 1) ? 0.0 : INF;
+      tlo = 0.0;
+      thi = 0.0;
+    }
+    if (empty_box_somewhere) {  // (wave-uniform) an empty box: quadprog's "constraints are inconsistent"
+      const bool empty = group_first_lane<W>(in && ubv - lbv < (thr_lo > thr_up ? thr_lo : thr_up)) < W;
+      if (empty && status == STATUS_OPTIMAL) status = STATUS_INFEASIBLE;
+    }
+  }
+  bool ppm_mode = PPX, restoring = false;
   bool running = (status == STATUS_OPTIMAL);
   bool need_sel = true;
   bool refined = (status == STATUS_ROUTED);
@@ -340,9 +420,72 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   };
 
   for (;;) {
+    // (a') principal pivoting: the index whose complementarity condition fails with the largest weight, over both roles
+    double viol = 0.0, viold = 0.0;
+    int nb_src = 0;     // the exchanged index is nonbasic (enters the basis)
+    bool iseq = false;  // ... is the next equality
+    if constexpr (PPX) {
+      if (wave_any(running && ppm_mode)) {
+        const bool sel = running && ppm_mode;
+        const double slo = x - blo, sup = bhi - x;
+        const bool okc = in && (!restoring || state != 0);
+        const bool vlo = okc && slo < tlo, vup = okc && sup < thi;
+        viol = vlo ? slo : sup;
+        const float zf = fabsf(static_cast<float>(tdiag));
+        const float wz = (zf > 1e-30f) ? approx_rcpf(zf) : 1e30f;
+        const float fv = static_cast<float>(viol);
+        float key = -(fv * fv) * wz;
+        const bool murty = it > PINKHIP_SWEEP_PPM_MURTY_AFTER(nv + md);
+        if (murty) key = static_cast<float>(li - 64);  // least index
+        float k32 = (vlo || vup) ? key32_packf(key, li | (vlo ? 0 : 32) | ((state != 0) ? 128 : 0)) : 3.0e38f;
+        // dense role: slack of an inactive inequality below its threshold, multiplier of an active one negative
+        viold = ud - dlo;
+        const bool okd = dl && li >= n_eq && (!restoring || dstate == 1);
+        if (okd && viold < dtlo) {
+          const float zdf = fabsf(static_cast<float>(ddiag));
+          const float wzd = (zdf > 1e-30f) ? approx_rcpf(zdf) : 1e30f;
+          const float fu = static_cast<float>(viold);
+          float kd = -(fu * fu) * wzd;
+          if (murty) kd = static_cast<float>(li - 32);  // (behind the coordinates)
+          const float kd32 = key32_packf(kd, li | 64 | ((dstate == 0) ? 128 : 0));
+          k32 = (kd32 < k32) ? kd32 : k32;
+        }
+        const float best32 = group_min32<W>(k32);
+        bool conv = false;
+        if (sel) {
+          if (!restoring && eq_next < n_eq) {
+            src = NV + eq_next;  // equalities are activated first, in order
+            kind = 0;
+            nb_src = 1;
+            iseq = true;
+          } else if (!(best32 < 0.0f)) {
+            if (restoring) {
+              ppm_mode = false;  // dual feasible: Goldfarb-Idnani's trips from here, this trip included
+              need_sel = true;
+            } else {
+              running = false;  // optimal
+            }
+            conv = true;
+          } else {
+            const int pl = key32_payload(best32);
+            src = (pl & 64) ? NV + (pl & 31) : (pl & 31);
+            kind = (pl & 64) ? 0 : (pl >> 5) & 1;
+            nb_src = pl >> 7;
+          }
+        }
+        if (conv) {
+          // ... into the variables of the dual method and of the closing trips
+          u = (state == 1) ? -x : ((state == 2) ? x : 0.0);
+          phi = (state == 1) ? -1.0 : ((state == 2) ? 1.0 : 0.0);
+          xfree = (state != 0) ? 0.0 : 1.0;
+          if (state != 0) x = (state == 1) ? lbv : ubv;
+          dphi = (dl && dstate == 1 && li >= n_eq) ? 1.0 : 0.0;
+        }
+      }
+    }
     // (a) entering constraint: the violated one that is farthest away in the metric of the objective
-    if (wave_any(running && need_sel)) {
-      const bool sel = running && need_sel;
+    if (wave_any(running && !ppm_mode && need_sel)) {
+      const bool sel = running && !ppm_mode && need_sel;
       const double slo = x - lbv, sup = ubv - x;
       const bool vlo = in && slo < thr_lo, vup = in && sup < thr_up;
       const float zf = static_cast<float>(-tdiag);
@@ -399,6 +542,9 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
         status = STATUS_MAX_ITER;
         running = false;
       }
+      if constexpr (PPX) {
+        if (ppm_mode && it > 2 * PINKHIP_SWEEP_PPM_MURTY_AFTER(nv + md)) restoring = true;  // (the dual method ends what this did not)
+      }
     }
     const bool closing = !wave_any(running);
     const bool ref = closing && !refined;
@@ -445,6 +591,12 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
         }
       }
       const bool cert_fails = group_first_lane<W>(fails || failsd) < W;
+      // (the conditioning estimate again, on the FINAL free set: ik_sweep.h)
+      bool illc = false;
+      if constexpr (GUESS) {
+        const double kfin = -group_min<W>((in && state == 0) ? hii * tdiag : 0.0);
+        illc = !(kfin <= PINKHIP_SWEEP_ROUTE_COND);
+      }
       if (!ref || status != STATUS_OPTIMAL) r = 0.0, rd = 0.0;
       // (x_F, lambda_A) += T_BB r: the coordinate role's entry, then the dense role's
       const double sdiag = sdiag_run, sdd = sdd_run;
@@ -473,7 +625,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
       PINKHIP_TRACEF(li == 0 && ref, "[sweepx g%d it%d nref%d] closing: cert_fails %d more %d sane %d dmax %.3e xmax %.3e dprev %.3e\n", g, it, nref, (int)cert_fails,
                      (int)more, (int)sane, dmax, xmax, dprev);
       if (ref) {
-        if (status != STATUS_OPTIMAL) {
+        if (status != STATUS_OPTIMAL || illc) {
           status = STATUS_BREAKDOWN;  // a verdict reached on the tableau is confirmed by the Goldfarb-Idnani code
           refined = true;
         } else if (!cert_fails && !more) {
@@ -499,6 +651,82 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     const int sl = sdense ? src - NV : src;
     if (li == src && li < NV) col = tdiag;
     if (li == src - NV) cold = ddiag;
+    int pi = -1;
+    double pvt = 1.0, rp = 0.0, sg = -1.0;  // (no pivot in this group: t = 0 leaves the tableau as it is)
+    if constexpr (PPX) {
+      if (wave_any(act && ppm_mode)) {
+        const bool actP = act && ppm_mode;
+        // (c') the exchange (ik_sweep.h): the quantity of the exchanged role goes to zero along the column, every lane's
+        // quantities move by -col nu
+        const double vs = group_bcast<W>(sdense ? viold : viol, sl);
+        const double num = kind ? vs : -vs;
+        const double pv = group_bcast<W>(sdense ? ddiag : tdiag, sl);
+        const double zr = group_bcast<W>(sdense ? zdd0 : zd0, sl);
+        const double rpv = fast_rcp(pv);
+        const double sgp = nb_src ? 1.0 : -1.0;
+        // a coordinate that is fixed / a row that is activated pivots on MINUS the curvature left along its normal (next to
+        // nothing left: the normal depends on the active ones); a coordinate freed / a row released on a reciprocal
+        const bool recip = (!sdense) == (nb_src != 0);
+        const bool irregular = actP && !((recip ? pv : -pv) > (recip ? 0.0 : PINKHIP_SWEEP_PPM_MIN_CURV * zr));
+        double hs = 0.0;
+        if (wave_any(irregular && iseq)) hs = group_bcast<W>(hv, sl);
+        bool act2 = actP;
+        if (irregular) {
+          act2 = false;
+          if (iseq && fabs(num) <= 1e-9 * (1.0 + fabs(hs))) {
+            ++eq_next;  // implied by the active ones and met: nothing to add
+          } else if (!restoring) {
+            restoring = true;
+          } else {
+            status = STATUS_BREAKDOWN;  // (not even a release is regular: the tableau is no inverse any more)
+            running = false;
+          }
+        }
+        const double nu = act2 ? -num * rpv : 0.0;
+        PINKHIP_TRACEF(li == 0 && actP, "[sweepx-ppm g%d it%d] src %d kind %d nonbasic %d pv %.3e zref %.3e num %.3e nu %.3e irregular %d restoring %d\n", g, it, src, kind,
+                       nb_src, pv, zr, num, nu, (int)irregular, (int)restoring);
+        x = fma(-col, nu, x);
+        ud = fma(-cold, nu, ud);
+        if (act2) {
+          pi = src;
+          pvt = pv;
+          rp = rpv;
+          sg = sgp;
+          if (li == src && li < NV) {
+            if (state != 0) {
+              x = ((state == 1) ? lbv : ubv) + nu;  // off its bound, to where its gradient entry is zero
+              state = 0;
+              blo = lbv;
+              bhi = ubv;
+              tlo = thr_lo;
+              thi = thr_up;
+            } else {
+              x = -nu;  // onto the bound it violates: -g
+              state = kind + 1;
+              blo = kind ? 0.0 : -INF;
+              bhi = kind ? INF : 0.0;
+              tlo = 0.0;
+              thi = 0.0;
+            }
+          }
+          if (li == src - NV) {
+            if (dstate == 0) {
+              ud = nu;  // the multiplier of the row
+              dstate = 1;
+              dtlo = 0.0;
+              if (li < n_eq) dlo = -INF;  // (an equality's: of either sign)
+            } else {
+              ud = -nu;  // the slack it opens
+              dstate = 0;
+              dtlo = thr_row;
+            }
+          }
+          if (iseq) ++eq_next;
+        }
+      }
+    }
+    if (!PPX || wave_any(act && !ppm_mode)) {
+    const bool actG = act && !ppm_mode;
     // what has to go to zero: the distance of the entering coordinate to its bound resp. the (negative) slack of the
     // entering row; pv = T[src][src] = -n^T Z n
     const double num = group_bcast<W>(sdense ? -ud : (kind == 0 ? lbv : ubv) - x, sl);
@@ -507,7 +735,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     bool lin_dep = false;
     {
       // little curvature left along the entering normal: formed again as a sum of squares w^T H w (ik_sweep.h)
-      const bool little = act && !(-pv * 1e6 > z0);
+      const bool little = actG && !(-pv * 1e6 > z0);
       if (wave_any(little)) {
         const double w = (in && state == 0) ? col : 0.0;
         const double hw = hrow_times(w);
@@ -522,7 +750,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     const double sgn = (num >= 0.0) ? 1.0 : -1.0;
     const double full = lin_dep ? BIG : -fabs(num) * rpv;
     const double rate = phi * col * sgn, rated = dphi * cold * sgn;
-    const bool blocking = act && rate > 0.0, blockd = act && rated > 0.0;
+    const bool blocking = actG && rate > 0.0, blockd = actG && rated > 0.0;
     const double ratio = blocking ? max_raw(u, 0.0) * fast_rcp1(rate) : BIG;
     const double ratiod = blockd ? max_raw(ud, 0.0) * fast_rcp1(rated) : BIG;
     const double k1 = group_min<W>((ratiod < ratio) ? ratiod : ratio);
@@ -532,8 +760,8 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     const double tstep = (k1 < full) ? k1 : full;
     const bool stuck = !(tstep < BIG);
     double hs = 0.0;
-    if (wave_any(act && stuck)) hs = group_bcast<W>(sdense ? hv : (kind == 0 ? lbv : ubv), sl);
-    if (act && stuck) {
+    if (wave_any(actG && stuck)) hs = group_bcast<W>(sdense ? hv : (kind == 0 ? lbv : ubv), sl);
+    if (actG && stuck) {
       const bool tiny = fabs(num) <= 1e-9 * (1.0 + fabs(hs));
       if (kind == 3 && tiny) {
         ++eq_next;  // equality implied by the active ones and already satisfied: nothing to add
@@ -551,7 +779,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
         running = false;
       }
     }
-    const bool act2 = act && running && !stuck;
+    const bool act2 = actG && running && !stuck;
     const bool do_add = act2 && !(k1 < full);
     const bool do_drop = act2 && !do_add;
     {
@@ -564,8 +792,6 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
     }
     PINKHIP_TICK(5);  // step lengths, x / u update
     // (d) pivot: on src (the entering constraint becomes tight) or on kd (the blocking constraint leaves)
-    int pi = -1;
-    double pvt = 1.0, rp = 0.0;
     if (do_add) {
       pi = src;
       pvt = pv;
@@ -608,10 +834,11 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
         }
       }
     }
+    // sweep (nonbasic -> basic: sg = +1) or reverse sweep (sg = -1) on pi.  Basic = free coordinate / active row.
+    if (!ppm_mode) sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
+    }
     PINKHIP_TICK(6);  // column of the leaving constraint
     {
-      // sweep (nonbasic -> basic: sg = +1) or reverse sweep (sg = -1) on pi.  Basic = free coordinate / active row.
-      const double sg = ((pi < NV) == do_add) ? -1.0 : 1.0;
       double t = col * rp, cp = col, td = cold * rp, cpd = cold;
       if (li == pi && li < NV) {
         t = 1.0 - sg * rp;
