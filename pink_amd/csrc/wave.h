@@ -46,7 +46,10 @@
 // (the kernel is VALU-throughput bound from three waves per SIMD on -- rocprofv3: the waves of a SIMD issue VALU
 // instructions ~100 % of the time -- so the budgets are the largest occupancy without spills: NT = 30 at four waves
 // spills 81 registers and takes 0.77 ms per 65 536 against 0.70 ms at three)
-#define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 4 : (NT) <= 34 ? 3 : 2)
+#ifndef PINKHIP_SWEEP_WAVES_MID  // (16 < NT <= 34)
+#define PINKHIP_SWEEP_WAVES_MID 3
+#endif
+#define PINKHIP_SWEEP_WAVES(NT) ((NT) <= 16 ? 4 : (NT) <= 34 ? PINKHIP_SWEEP_WAVES_MID : 2)
 #endif
 #define PINKHIP_OCCUPANCY_SWEEP(NT) __attribute__((amdgpu_waves_per_eu(PINKHIP_SWEEP_WAVES(NT), PINKHIP_SWEEP_WAVES(NT))))
 // ... with front coordinates eliminated (NV > W: W tableau rows + what the elimination carries through the stacking)

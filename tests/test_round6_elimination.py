@@ -76,3 +76,72 @@ def test_undeclared_batches_take_the_wide_group(solver):
     ref = c_oracle.solve_ik_batch(**synthetic.pink_form(terms))
     out = solver.solve(batch)
     assert np.array_equal(out.status, ref["status"]) and np.abs(out.dq - ref["dq"])[ref["status"] == 0].max() < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round-5 review, item 6(a): the DEVICE route with barrier rows pinned to the reference's rows directly -- not through the
+# host classes.  The whole-step kernel (emulator / MI355X) forms PositionBarrier and BodySphericalBarrier rows on chip; its
+# velocity must be the minimiser of the QP whose barrier rows and regulariser are the ones the REFERENCE's classes produced
+# (tests/golden/pink_round4.npz, `pb_*` cases: `*/G, h, H, c` and `*/sph_*/G, h, H, c`), solved by the oracle from those
+# arrays -- pink_amd's barrier classes do not enter the expected value.
+@pytest.fixture(scope="module")
+def golden4():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pink_round4.npz"))
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def route_backend(request):
+    import pink_amd
+    from pink_amd.runtime import set_default_solver
+
+    s = request.getfixturevalue("emu" if request.param == "emu" else "gpu_solver")
+    set_default_solver(s)
+    yield request.param
+    pink_amd.clear_device_cache()
+    set_default_solver(None)
+
+
+@pytest.mark.parametrize("case", ["pb_arm", "pb_humanoid"])
+def test_device_route_barrier_rows_are_the_references(route_backend, golden4, case):
+    import pink_amd
+    from pink_amd import Configuration, ConfigurationBatch, FrameTask, PostureTask, build_chain, solve_ik_batch
+    from pink_amd.barriers import BodySphericalBarrier, PositionBarrier
+
+    g = golden4
+    n, ff, dt = int(g[f"{case}/n"]), bool(g[f"{case}/ff"]), float(g[f"{case}/dt"])
+    m = build_chain(n, free_flyer=ff, seed=4)
+    cfg = Configuration(m, g[f"{case}/q"].copy())
+    ft = FrameTask("tool0", 1.0, 0.5, lm_damping=1e-3)
+    T = cfg.get_transform_frame_to_world("tool0").copy()
+    T.translation = T.translation + np.array([0.02, -0.01, 0.05])
+    ft.set_target(T)
+    po = PostureTask(cost=1e-2)
+    po.set_target(m.neutral())
+    base = pink_amd.build_ik(cfg, [ft, po], dt)  # the stack without barriers: P, q, limit rows (pinned to the reference elsewhere)
+    cb = ConfigurationBatch(m, np.tile(cfg.q, (66, 1)))
+    variants = []
+    for name in ("max_z", "box_xy", "min_all"):
+        kw = {}
+        for k in ("indices", "p_min", "p_max", "gain", "safe_displacement_gain"):
+            if f"{case}/{name}/{k}" in g:
+                v = g[f"{case}/{name}/{k}"]
+                kw[k] = [int(i) for i in v] if k == "indices" else (float(v) if k == "safe_displacement_gain" else v.copy())
+        variants.append((name, PositionBarrier("tool0", **kw)))
+    for name in ("far", "near"):
+        variants.append((f"sph_{name}", BodySphericalBarrier(("tool0", "joint_2"), float(g[f"{case}/sph_{name}/d_min"]), gain=g[f"{case}/sph_{name}/gain"].copy(),
+                                                              safe_displacement_gain=float(g[f"{case}/sph_{name}/safe_displacement_gain"]))))
+    for name, bar in variants:
+        V = solve_ik_batch(cb, [ft, po], dt, barriers=[bar], device_kinematics=True)
+        assert pink_amd.last_solve_stats()["route"] == "device", name
+        # the reference's QP: objective + the reference barrier's regulariser, limit rows + the reference barrier's rows
+        P = base.P + g[f"{case}/{name}/H"]
+        q = base.q + g[f"{case}/{name}/c"]
+        G = np.vstack([base.G, g[f"{case}/{name}/G"]])
+        h = np.concatenate([base.h, g[f"{case}/{name}/h"]])
+        x_ref, status, _, _ = c_oracle.gi_solve(P, q, G, h)
+        assert status == 0, name
+        dq = V * dt
+        assert np.abs(dq - x_ref[None, :]).max() < 1e-9 * max(1.0, np.abs(x_ref).max()), (case, name)
+        assert np.array_equal(V, np.tile(V[0], (V.shape[0], 1)))  # (the same robot 66 times)
