@@ -417,6 +417,11 @@ def guess(tb: Tableau, rule):
         bounded = np.isfinite(lb) & np.isfinite(ub)
         return np.where(bounded, np.where(c > 0, 1, 2), 0)
     x = -c / d
+    if rule == "rowsum":  # the damped Jacobi step that cannot overshoot: -c_i / sum_j |H_ij|
+        x = -c / np.abs(H).sum(axis=1)
+    if rule.startswith("mix"):  # -c_i / (H_ii + theta sum_{j != i} |H_ij|)
+        th = float(rule[3:])
+        x = -c / (d + th * (np.abs(H).sum(axis=1) - d))
     if rule.startswith("jacobi"):
         for _ in range(int(rule[6:])):
             xc = np.clip(x, lb, ub)
@@ -448,7 +453,7 @@ def run_ppm(name, B, bounds, error_scale):
             n[b], t[b] = ppm(tb, **kw)
             assert n[b] >= 0 and np.abs(tb.x - ref["dq"][b]).max() < 1e-8, (label, b)
         print(f"   from the unconstrained minimum, {label:26s} pivots {n.mean():6.2f} trips {t.mean():6.2f} (pair-max {pm(t):6.2f}) max {n.max()}")
-    for rule in ("diag", "c", "jacobi1", "jacobi2", "gs1", "gs2"):
+    for rule in ("diag", "rowsum", "mix0.25", "mix0.5", "c", "jacobi1", "jacobi2", "gs1", "gs2"):
         n = np.zeros(B, int)
         sw = np.zeros(B, int)
         free = []
