@@ -342,6 +342,7 @@ def api_level(solver, B: int = 4096, Bh: int = 65536) -> dict:
         if hasattr(solver, "pinned_empty"):
             out["headline_shape_arrays_page_locked"] = api_level_arrays(Bh, pinned=True)
             out["headline_shape_arrays_page_locked_frozen_targets"] = api_level_arrays(Bh, pinned=True, freeze=True)
+            out["headline_shape_arrays_page_locked_quaternion_targets"] = api_level_arrays(Bh, pinned=True, quat=True)
         # the task stack of the reference's own humanoid example (examples/humanoid_draco3.py:34-71: FrameTasks, a
         # PostureTask, two JointCouplingTasks) and one with a DampingTask: formed on chip by the whole-step kernel from
         # constant tables; beside them the same calls with only the FrameTask rows formed on the device
@@ -411,7 +412,7 @@ def api_level_host_evaluated(m, B: int) -> dict:
                                           "max_abs_velocity_difference_vs_the_device_route": float(np.abs(v - v_h).max())}}
 
 
-def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=None, freeze: bool = False) -> dict:
+def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=None, freeze: bool = False, quat: bool = False) -> dict:
     """`pink_amd.solve_ik_batch(ConfigurationBatch(model, q), tasks, dt)` at the HEADLINE shape: a floating-base robot
     with nv = 30 (free flyer + 24 joints), 4 FrameTasks + PostureTask under the model's limits, B configurations as one
     array and per-instance targets as arrays -- q and targets go in, velocities come out, per call (H2D, the
@@ -438,7 +439,13 @@ def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=N
         t = FrameTask(f, 1.0, 1.0 if k == 0 else 0.0, lm_damping=1e-3)
         T0 = ref.get_transform_frame_to_world(f)
         # every robot's target: the reference robot's frame pose displaced by a few centimetres
-        t.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=alloc((B, 12)))
+        if quat:  # FrameTask.set_target_poses_quat: translation + quaternion, 7 numbers per target instead of 12
+            from scipy.spatial.transform import Rotation
+
+            t.set_target_poses_quat(T0.translation + 0.05 * rng.normal(size=(B, 3)), np.broadcast_to(Rotation.from_matrix(T0.rotation).as_quat(), (B, 4)),
+                                    out=alloc((B, 7)))
+        else:
+            t.set_target_poses(np.broadcast_to(T0.rotation, (B, 3, 3)), T0.translation + 0.05 * rng.normal(size=(B, 3)), out=alloc((B, 12)))
         if freeze:  # FrameTask.freeze_targets: the target arrays go up once per device state, not with every call
             t.freeze_targets()
         tasks.append(t)
@@ -486,8 +493,9 @@ def api_level_arrays(B: int, extra_task: str = "", pinned: bool = False, route=N
                         f", default limits, B = {B} as ConfigurationBatch, targets as arrays",
             "route": stats.get("route"), "solver_paths": stats.get("paths"),
             "ms_per_call": t_call * 1e3, "ms_per_call_best": min(ts) * 1e3, "solves_per_s": B / t_call,
-            "bytes_in_per_call": int(q.nbytes + (0 if freeze else B * len(frames) * 12 * 8)), "bytes_out_per_call": int(B * m.nv * 8 + 8 * B),
-            "targets": "frozen (FrameTask.freeze_targets: resident on the device)" if freeze else "uploaded with every call",
+            "bytes_in_per_call": int(q.nbytes + (0 if freeze else B * len(frames) * (7 if quat else 12) * 8)), "bytes_out_per_call": int(B * m.nv * 8 + 8 * B),
+            "targets": "frozen (FrameTask.freeze_targets: resident on the device)" if freeze else
+                       ("translation + quaternion (FrameTask.set_target_poses_quat), uploaded with every call" if quat else "uploaded with every call"),
             "max_abs_velocity_difference_vs_host_evaluated_tasks_on_sample": float(np.abs(v[:n] - v_host).max()), "sample": n}
 
 
@@ -498,6 +506,8 @@ def _slice_task(task, n):
     t = copy.copy(task)
     if getattr(t, "target_poses", None) is not None:
         t.target_poses = t.target_poses[:n]
+    if getattr(t, "target_pq", None) is not None:
+        t.target_pq = t.target_pq[:n]
     if getattr(t, "target_q_batch", None) is not None:
         t.target_q_batch = t.target_q_batch[:n]
     return t

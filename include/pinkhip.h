@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PINKHIP_VERSION 111 /* 110: iters[b] carries the solver path in its high bits (PINKHIP_ITERS_*) */
+#define PINKHIP_VERSION 112 /* 110: iters[b] carries the solver path in its high bits (PINKHIP_ITERS_*); 112: pinkhip_desc::n_free_lead, pinkhip_pose_targets_device */
 
 /* API-level error codes (negative). */
 #define PINKHIP_OK 0
@@ -381,6 +381,12 @@ int pinkhip_check_limits_device(pinkhip_handle *h, const pinkhip_model *model, i
 /* q [B,nq] <- q (+) dq [B,nv], in place */
 int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *model, int64_t B, double *q,
                              const double *dq);
+/* FrameTask targets as translation + unit quaternion: pq [B,7] = (tx, ty, tz, qx, qy, qz, qw), the order of
+ * pin.SE3ToXYZQUAT, written out as the T_target layout of the calls above, T [B,12] = rotation row-major, translation
+ * (the quaternion is normalised on the way).  Replaces, for B robots, the pin.XYZQUATToSE3 a caller runs in front of
+ * FrameTask.set_target (pink/tasks/frame_task.py:129-137): a moving-target control step then sends 56 B per target
+ * across PCIe instead of 96 B.  Device pointers; enqueued on the handle's current compute stream, asynchronous. */
+int pinkhip_pose_targets_device(pinkhip_handle *h, int64_t B, const double *pq, double *T);
 /* Same, but an instance whose solve failed is NOT integrated: the reference raises NoSolutionFound and never
  * applies a failed solve (pink/solve_ik.py:271-275).  status [B] is the solver's output of this step;
  * first_failure [B] (optional, zero-initialised by the caller) keeps, per instance, `status | (step << 8)` of

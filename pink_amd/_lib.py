@@ -126,6 +126,7 @@ ABI_SYMBOLS = (
     "pinkhip_frame_task_strided_device", "pinkhip_model_create", "pinkhip_model_destroy", "pinkhip_fk_device",
     "pinkhip_fk_frame_tasks_device", "pinkhip_step_device", "pinkhip_rollout_step_device",
     "pinkhip_limits_posture_device", "pinkhip_check_limits_device", "pinkhip_integrate_device", "pinkhip_integrate_checked_device",
+    "pinkhip_pose_targets_device",
     "pinkhip_comm_get_unique_id", "pinkhip_comm_init", "pinkhip_comm_gather", "pinkhip_comm_gather_bytes",
     "pinkhip_comm_allgather_bytes", "pinkhip_comm_destroy",
     "pinkhip_host_alloc", "pinkhip_host_free", "pinkhip_malloc", "pinkhip_free",
@@ -174,6 +175,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.pinkhip_limits_posture_device.argtypes = [vp, vp, i64, f64, f64, vp, vp, i32, vp, vp, vp, i32, i32]
     lib.pinkhip_check_limits_device.argtypes = [vp, vp, i64, vp, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
     lib.pinkhip_integrate_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.pinkhip_pose_targets_device.argtypes = [vp, i64, vp, vp]
     lib.pinkhip_integrate_checked_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32]
     lib.pinkhip_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.pinkhip_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]

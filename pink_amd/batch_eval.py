@@ -57,7 +57,7 @@ def _frame_targets(col: Sequence, B: int, attr: str, what: str) -> np.ndarray:
     """``[B, 12]`` target poses of a FrameTask / RelativeFrameTask slot."""
     t0 = col[0]
     if _same(col):
-        poses = getattr(t0, "target_poses", None)
+        poses = t0.poses12() if hasattr(t0, "poses12") else getattr(t0, "target_poses", None)
         if poses is not None:
             if poses.shape != (B, 12):
                 raise PinkError(f"{type(t0).__name__} {t0.frame!r}: {poses.shape[0]} target poses for {B} configurations")

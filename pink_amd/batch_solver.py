@@ -396,6 +396,11 @@ class BatchSolver:
     def integrate(self, model, B, q, dq) -> None:
         self._check(self._lib.pinkhip_integrate_device(self._h, ctypes.c_void_p(model), B, q, dq))
 
+    def pose_targets(self, B: int, pq: int, T: int) -> None:
+        """``[B, 7]`` translation + quaternion targets at device address ``pq`` -> ``[B, 12]`` poses at ``T`` (asynchronous,
+        on the current compute stream)."""
+        self._check(self._lib.pinkhip_pose_targets_device(self._h, B, ctypes.c_void_p(pq), ctypes.c_void_p(T)))
+
     def integrate_checked(self, model, B, q, dq, status, first_failure, step) -> None:
         """``integrate`` that leaves instances with ``status != 0`` untouched and records the first failure."""
         self._check(self._lib.pinkhip_integrate_checked_device(self._h, ctypes.c_void_p(model), B, q, dq, status,

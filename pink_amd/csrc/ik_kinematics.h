@@ -9,6 +9,7 @@
 //                           (configuration_limit.py:111-120, velocity_limit.py:118-120) and the
 //                           PostureTask error q (-) q* (posture_task.py:100-107)
 //   ik_integrate_kernel     q <- q (+) dq   (pink/configuration.py:273-293: pin.integrate)
+//   ik_pose_targets_kernel  [B, 7] translation + quaternion targets -> [B, 12] poses
 //
 // Models are kinematic trees of revolute / prismatic joints with an optional free-flyer root
 // (q = [p, quat xyzw], tangent = body twist), joints in topological order.  Conventions as in
@@ -745,6 +746,41 @@ __device__ inline void ik_integrate_thread(const IntegrateArgs &a, long long t) 
 #ifndef PINKHIP_NO_ELEMENTWISE_KERNELS
 __global__ void __launch_bounds__(256) ik_integrate_kernel(IntegrateArgs a) {
   ik_integrate_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// ik_pose_targets_kernel: FrameTask targets handed over as translation + unit quaternion, [B, 7] =
+// (tx, ty, tz, qx, qy, qz, qw) -- the order of pin.SE3ToXYZQUAT -- written out as the [B, 12] poses (rotation row-major,
+// translation) the kinematics kernels read: 56 B per target across PCIe instead of 96 B.  What the caller of
+// FrameTask.set_target does on the host per robot (pink/tasks/frame_task.py:129-137 takes the pin.SE3 that
+// pin.XYZQUATToSE3 built); the quaternion is normalised here.
+struct PoseTargetsArgs {
+  long long B;
+  const double *pq;  // [B, 7]
+  double *T;         // [B, 12]
+};
+
+__device__ inline void ik_pose_targets_thread(const PoseTargetsArgs &a, long long t) {
+  if (t >= a.B) return;
+  const double *s = a.pq + 7 * t;
+  double x = s[3], y = s[4], z = s[5], w = s[6];
+  const double n = 1.0 / sqrt(x * x + y * y + z * z + w * w);
+  x *= n, y *= n, z *= n, w *= n;
+  double *o = a.T + 12 * t;
+  o[0] = 1.0 - 2.0 * (y * y + z * z);
+  o[1] = 2.0 * (x * y - z * w);
+  o[2] = 2.0 * (x * z + y * w);
+  o[3] = 2.0 * (x * y + z * w);
+  o[4] = 1.0 - 2.0 * (x * x + z * z);
+  o[5] = 2.0 * (y * z - x * w);
+  o[6] = 2.0 * (x * z - y * w);
+  o[7] = 2.0 * (y * z + x * w);
+  o[8] = 1.0 - 2.0 * (x * x + y * y);
+  o[9] = s[0], o[10] = s[1], o[11] = s[2];
+}
+
+__global__ void __launch_bounds__(256) ik_pose_targets_kernel(PoseTargetsArgs a) {
+  ik_pose_targets_thread(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 #endif
 

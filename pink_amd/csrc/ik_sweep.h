@@ -104,10 +104,6 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #else
 #define PINKHIP_WHY(k)
 #endif
-// ... in the whole-step kernel when the guess fixes more than this many coordinates per robot of the wave
-#ifndef PINKHIP_SWEEP_PPM_CRASH_MIN
-#define PINKHIP_SWEEP_PPM_CRASH_MIN 2
-#endif
 // Curvature left along the normal of a coordinate that is fixed / a row that is activated, relative to (a lower bound of) the
 // unreduced one, below which principal pivoting does not pivot: the group goes on with the dual method, which forms a small
 // curvature again as a sum of squares and knows what to do about a dependent normal.  An exchange on 5.6e-8 of it (one
@@ -391,14 +387,12 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     lbv = in ? terms->lb : -INF;
     ubv = in ? terms->ub : INF;
   }
-  // The start is a guessed active set.  In the whole-step kernel only when the guess fixes more than a coordinate or two per
-  // robot of the wave (wave-uniform): a controller that tracks its targets has next to nothing to guess, and there the sweeps
-  // without masks are worth more than the trip the guess saves -- the masked ones cost that kernel 9 % of a converged
-  // step (register pressure: profiles/ab_ppm_r06.txt), two copies of the sweeps cost it 2 %.  The stack + solve kernels
-  // carry the masked sweeps alone: the same experiment there is within the noise, and a second copy of the sweeps is
-  // instruction-cache footprint.
-  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH;
-  bool guess = GUESS;
+  // The start is a guessed active set -- in the stack + solve kernels.  The whole-step kernel starts with every coordinate
+  // free: the Jacobians of a serial chain are far from the diagonal picture the guess is made from, and on closed loops
+  // the guess cost more trips than it saved (7 % of the robots of a converged batch took 20-30 trips to repair a guess
+  // where 1-10 trips from the unconstrained minimum do: profiles/ab_ppm_r06.txt, scripts/gpu_rollout_iters.py); a
+  // controller that tracks its targets has next to nothing to guess anyway.
+  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH && !Src::kOnTheFly;
   if constexpr (GUESS) {
     // ---------------------------------------------------------------- principal pivoting: where it starts
     // Principal pivoting needs no feasibility of any kind from its starting basis, so it does not have to be the
@@ -413,23 +407,13 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
     if (group_first_lane<W>(in && !(hii > 0.0)) < W) status = STATUS_NOT_PD;
     const double xd = -ci * approx_rcp(hii);
     if (in) state = (xd < lbv) ? 1 : ((xd > ubv) ? 2 : 0);
-    if constexpr (Src::kOnTheFly) {
-      // (decided per robot -- a robot's result must not depend on which robot shares its wave: a sharded batch pairs
-      // them differently -- and the masked sweeps of a robot that starts with every coordinate free are the unmasked
-      // ones, operation for operation; the wave only picks the copy of the code)
-      const unsigned long long fixm = wave_ballot(state != 0);
-      const int nfix = __builtin_popcountll(W == 64 ? fixm : (fixm >> (lane & ~(W - 1))) & ((1ull << (W & 63)) - 1ull));
-      const bool gguess = nfix > PINKHIP_SWEEP_PPM_CRASH_MIN;
-      if (!gguess) state = 0;
-      guess = wave_any(gguess);
-    }
     const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
     // this lane's group (W = 64: the wave, a scalar; below: 32 bits of a register)
     using FreeMask = typename std::conditional<W == 64, unsigned long long, unsigned>::type;
     FreeMask gfree = static_cast<FreeMask>(fm);
     if constexpr (W == 32) gfree = (lane >= 32) ? static_cast<unsigned>(fm >> 32) : static_cast<unsigned>(fm);
     else if constexpr (W == 16) gfree = static_cast<unsigned>(fm >> (lane & 48)) & 0xFFFFu;
-    if (guess) static_for<0, NV>([&](auto Kc) {
+    static_for<0, NV>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       {
         // (the lanes of a group that does not sweep coordinate k in are switched off for the sweep -- the broadcast
@@ -459,7 +443,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
       }
     });
   }
-  if ((!GUESS || Src::kOnTheFly) && !guess) {
+  if constexpr (!GUESS) {
     static_for<0, NV>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       if (k < nv) {  // wave-uniform

@@ -51,7 +51,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // part: `x / -g` of a coordinate and its interval, slack / multiplier of a dense row); the arg-min's 8-bit payload holds
   // lane (5 bits), side, role and "nonbasic"
   constexpr bool PPX = PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE && PINKHIP_SWEEPX_PPM && W <= 32;
-  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH;
+  constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH && !Src::kOnTheFly;  // (the whole-step kernel starts all-free: ik_sweep.h)
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;
   constexpr double BIG = 1e300;
@@ -165,15 +165,10 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   }
   if constexpr (GUESS) {
     // where it starts: the guessed active set of ik_sweep.h (coordinate i fixed at the bound -c_i / H_ii violates), only the
-    // free coordinates swept in; in the whole-step kernel per robot, when the guess fixes more than two coordinates
+    // free coordinates swept in
     if (group_first_lane<W>(in && !(hii > 0.0)) < W) status = STATUS_NOT_PD;
     const double xd = -ci * approx_rcp(hii);
     if (in) state = (xd < lbv) ? 1 : ((xd > ubv) ? 2 : 0);
-    if constexpr (Src::kOnTheFly) {
-      const unsigned long long fixm = wave_ballot(state != 0);
-      const int nfix = __builtin_popcountll((fixm >> (lane & ~(W - 1))) & ((1ull << W) - 1ull));
-      if (!(nfix > PINKHIP_SWEEP_PPM_CRASH_MIN)) state = 0;
-    }
     const unsigned long long fm = wave_ballot(li < NV && state == 0 && in);
     const unsigned gfree = static_cast<unsigned>(fm >> (lane & ~(W - 1)));  // this lane's group
     static_for<0, NV>([&](auto Kc) {

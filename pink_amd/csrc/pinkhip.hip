@@ -950,6 +950,18 @@ int pinkhip_check_limits_device(pinkhip_handle *h, const pinkhip_model *m, int64
   return PINKHIP_OK;
 }
 
+int pinkhip_pose_targets_device(pinkhip_handle *h, int64_t B, const double *pq, double *T) {
+  if (!h) return fail(nullptr, PINKHIP_E_INVALID, "null handle");
+  if (B < 0) return fail(h, PINKHIP_E_INVALID, "bad B");
+  if (B == 0) return PINKHIP_OK;
+  if (!pq || !T) return fail(h, PINKHIP_E_INVALID, "null pointer");
+  PH_HIP(h, hipSetDevice(h->device));
+  pinkhip::PoseTargetsArgs a{B, pq, T};
+  hipLaunchKernelGGL(pinkhip::ik_pose_targets_kernel, dim3(static_cast<unsigned>((B + 255) / 256)), dim3(256), 0, h->stream, a);
+  PH_HIP(h, hipGetLastError());
+  return PINKHIP_OK;
+}
+
 int pinkhip_integrate_device(pinkhip_handle *h, const pinkhip_model *m, int64_t B, double *q, const double *dq) {
   if (!h || !m) return fail(h, PINKHIP_E_INVALID, "null handle / model");
   if (B < 0) return fail(h, PINKHIP_E_INVALID, "bad B");

@@ -152,7 +152,7 @@ class DeviceRollout:
     """
 
     _BUFFERS = ("d_q", "d_T", "d_Jb", "d_Tt", "d_J", "d_e", "d_cost", "d_lb", "d_ub", "d_dq", "d_status", "d_iters", "d_qt",
-                "d_fail")
+                "d_fail", "d_Tq")
 
     def __init__(self, api, model: Model, q0: np.ndarray, frame_tasks: Sequence[tuple], dt: float,
                  posture_cost: Optional[float] = None, posture_gain: float = 1.0, damping: float = 1e-12,
@@ -339,6 +339,7 @@ class DeviceRollout:
         self.d_cost = f8(max(self.K, 1))
         self.d_lb, self.d_ub, self.d_dq = f8(B, nv), f8(B, nv), f8(B, nv)
         self.d_status, self.d_iters = a.alloc(4 * B), a.alloc(4 * B)
+        self.d_Tq = None  # staging of [B, 7] translation + quaternion targets, on first use (_pq_stage)
         self.d_fail = a.alloc(4 * B)  # per robot: status | (step << 8) of its first failing step, 0 = none
         a.put(self.d_fail, np.zeros(B, dtype=np.int32))
         self._fail_dirty = False
@@ -452,8 +453,15 @@ class DeviceRollout:
                     tok = getattr(t, "frozen_token", None)  # (FrameTask.freeze_targets: uploaded once per device state)
                     if tok is not None and self._resident.get(f) == tok:
                         continue
-                    t = np.ascontiguousarray(np.broadcast_to(t, (self.B, 12)), dtype=np.float64)
-                    self.api.put(self.d_Tt + 8 * 12 * self.B * f, t)
+                    if np.ndim(t) == 2 and t.shape[1] == 7:  # translation + quaternion: expanded by a device kernel
+                        t = np.ascontiguousarray(t, dtype=np.float64)
+                        if t.shape[0] != self.B:
+                            raise ValueError(f"{t.shape[0]} targets for {self.B} robots")
+                        self.api.put(self._pq_stage(f), t)
+                        self.api.pose_targets(self.B, self._pq_stage(f), self.d_Tt + 8 * 12 * self.B * f)
+                    else:
+                        t = np.ascontiguousarray(np.broadcast_to(t, (self.B, 12)), dtype=np.float64)
+                        self.api.put(self.d_Tt + 8 * 12 * self.B * f, t)
                     self._resident[f] = tok
                 self.targets_per_frame = True
                 return
@@ -462,6 +470,16 @@ class DeviceRollout:
         self.api.put(self.d_Tt, t)
         self.targets_per_frame = False
         self._resident = {}
+
+    def _pq_stage(self, f: int, lo: int = 0) -> int:
+        """Device address of robot ``lo``'s entry in the staging area of frame slot ``f``'s ``[B, 7]`` translation + quaternion
+        targets (``FrameTask.set_target_poses_quat``; allocated on first use, ``pinkhip_pose_targets_device`` writes the
+        poses the kernels read from it)."""
+        if getattr(self, "d_Tq", None) is None:
+            if not hasattr(self.api, "pose_targets"):
+                raise RuntimeError("this solver has no pinkhip_pose_targets_device: translation + quaternion targets need it")
+            self.d_Tq = self.api.alloc(8 * 7 * self.B * max(len(self.frames), 1))
+        return self.d_Tq + 8 * 7 * (self.B * f + lo)
 
     def step(self, integrate: bool = True) -> None:
         """Enqueue one IK step for every robot (asynchronous).  ``integrate=False`` only solves (dq, status and
@@ -538,7 +556,10 @@ class DeviceRollout:
         if not self.targets_per_frame:
             self._resident = {}
         skip = [tok is not None and self._resident.get(f) == tok for f, tok in enumerate(toks)]
-        tg = [None if skip[f] else np.ascontiguousarray(np.broadcast_to(t, (B, 12)), dtype=np.float64) for f, t in enumerate(targets)]
+        # ([B, 7] translation + quaternion arrays go up as they are -- 56 B per robot and frame task instead of 96 -- and a
+        # device kernel writes the poses: FrameTask.set_target_poses_quat)
+        tg = [None if skip[f] else np.ascontiguousarray(t if (np.ndim(t) == 2 and t.shape == (B, 7)) else np.broadcast_to(t, (B, 12)), dtype=np.float64)
+              for f, t in enumerate(targets)]
         if out is not None and (out.shape != (B, nv) or out.dtype != np.float64 or not out.flags.c_contiguous):
             raise ValueError(f"out must be a C-contiguous float64 array of shape {(B, nv)}")
         if self.n_post:  # (the first kernel waits for the copy stream: wait_copies below)
@@ -583,11 +604,19 @@ class DeviceRollout:
             if two:
                 a.select_stream(c & 1)
             put(self.d_q + 8 * nq * lo, q0[lo:hi])
+            quat = []
             for f, t in enumerate(tg):
-                if t is not None:
+                if t is None:
+                    continue
+                if t.shape[1] == 7:
+                    put(self._pq_stage(f, lo), t[lo:hi])
+                    quat.append(f)
+                else:
                     put(self.d_Tt + 8 * 12 * (B * f + lo), t[lo:hi])
             if asyn:
                 a.wait_copies()
+            for f in quat:  # (on the range's compute stream, in front of its kernel)
+                a.pose_targets(hi - lo, self._pq_stage(f, lo), self.d_Tt + 8 * 12 * (B * f + lo))
             if not self._one_kernel_step(False, lo, hi):
                 if c:
                     raise RuntimeError("whole-step kernel refused a later range of the same batch")

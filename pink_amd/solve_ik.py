@@ -677,10 +677,11 @@ def _device_kinematics_plan_tasks_raw(configurations, tasks):
         specs, targets, posture, extras = [], [], None, []
         for t in tasks:
             if type(t) is FrameTask:
-                if t.target_poses is not None:
-                    if t.target_poses.shape != (B, 12):
-                        raise PinkError(f"FrameTask {t.frame!r}: {t.target_poses.shape[0]} target poses for {B} configurations")
-                    targets.append(t.target_poses)
+                if t.target_array() is not None:
+                    # ([B, 12] poses or [B, 7] translation + quaternion: uploaded as they are, the latter expanded on the device)
+                    if t.target_array().shape[0] != B:
+                        raise PinkError(f"FrameTask {t.frame!r}: {t.target_array().shape[0]} target poses for {B} configurations")
+                    targets.append(t.target_array())
                 elif t.transform_target_to_world is not None:
                     targets.append(np.broadcast_to(_pose12(t.transform_target_to_world), (B, 12)))
                 else:

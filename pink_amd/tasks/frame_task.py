@@ -23,6 +23,26 @@ class FrozenTargets(np.ndarray):
     frozen_token: Optional[int] = None
 
 
+def poses_from_pq(pq: np.ndarray) -> np.ndarray:
+    """``[B, 12]`` poses (rotation row-major, translation) of ``[B, 7]`` = translation + quaternion ``(x, y, z, w)``: the
+    host-side statement of ``ik_pose_targets_thread`` (``repo:pink_amd/csrc/ik_kinematics.h``), same operations."""
+    pq = np.asarray(pq, dtype=np.float64)
+    n = 1.0 / np.sqrt(np.einsum("bi,bi->b", pq[:, 3:], pq[:, 3:]))
+    x, y, z, w = (pq[:, 3 + i] * n for i in range(4))
+    out = np.empty((pq.shape[0], 12))
+    out[:, 0] = 1.0 - 2.0 * (y * y + z * z)
+    out[:, 1] = 2.0 * (x * y - z * w)
+    out[:, 2] = 2.0 * (x * z + y * w)
+    out[:, 3] = 2.0 * (x * y + z * w)
+    out[:, 4] = 1.0 - 2.0 * (x * x + z * z)
+    out[:, 5] = 2.0 * (y * z - x * w)
+    out[:, 6] = 2.0 * (x * z - y * w)
+    out[:, 7] = 2.0 * (y * z + x * w)
+    out[:, 8] = 1.0 - 2.0 * (x * x + y * y)
+    out[:, 9:] = pq[:, :3]
+    return out
+
+
 class FrameTask(Task):
     """6-D pose task; cost is ``[position x3, orientation x3]`` (``frame_task.py:44-127``)."""
 
@@ -31,6 +51,7 @@ class FrameTask(Task):
         self.frame = frame
         self.transform_target_to_world: Optional[SE3] = None
         self.target_poses: Optional[np.ndarray] = None  # [B, 12] per-instance targets (set_target_poses)
+        self.target_pq: Optional[np.ndarray] = None  # [B, 7] per-instance targets as translation + quaternion (set_target_poses_quat)
         self.set_position_cost(position_cost)
         self.set_orientation_cost(orientation_cost)
 
@@ -60,7 +81,7 @@ class FrameTask(Task):
         """One target for every configuration the task is evaluated at (``frame_task.py:129-137``); replaces per-instance
         targets set earlier (one target source is live at a time)."""
         self.transform_target_to_world = transform_target_to_world.copy()
-        self.target_poses = None
+        self.target_poses = self.target_pq = None
 
     def set_target_from_configuration(self, configuration) -> None:
         self.set_target(configuration.get_transform_frame_to_world(self.frame))
@@ -82,7 +103,41 @@ class FrameTask(Task):
         out[:, :9] = R.reshape(-1, 9)
         out[:, 9:] = t
         self.target_poses = out
+        self.target_pq = None
         self.transform_target_to_world = None  # (replaces a single target set earlier)
+
+    def set_target_poses_quat(self, translations: np.ndarray, quaternions: np.ndarray, out: Optional[np.ndarray] = None) -> None:
+        """One target per instance as ``translations [B, 3]`` and unit ``quaternions [B, 4]`` in Pinocchio's order
+        ``(x, y, z, w)`` -- what ``pin.SE3ToXYZQUAT`` returns, 7 numbers per pose instead of 12: a moving-target call of
+        :func:`pink_amd.solve_ik_batch` then sends 56 B per frame task and robot across PCIe instead of 96 B, and a device
+        kernel writes the rotation matrices next to the other targets (``pinkhip_pose_targets_device``; the quaternion is
+        normalised there).  Instance ``b`` plays ``set_target(pin.XYZQUATToSE3([*t[b], *quat[b]]))``.  ``out [B, 7]`` (e.g.
+        from :func:`pink_amd.pinned_empty`) receives ``[t, quat]`` and is kept as the task's target array."""
+        t = np.asarray(translations, dtype=np.float64)
+        qt = np.asarray(quaternions, dtype=np.float64)
+        if t.ndim != 2 or t.shape[1] != 3 or qt.shape != (t.shape[0], 4):
+            raise TaskDefinitionError(f"translations [B, 3] and quaternions [B, 4] expected, got {t.shape} and {qt.shape}")
+        if not (np.abs(np.einsum("bi,bi->b", qt, qt) - 1.0) < 1e-6).all():
+            raise TaskDefinitionError("quaternions must have unit norm (x, y, z, w)")
+        if out is None:
+            out = np.empty((t.shape[0], 7))
+        elif out.shape != (t.shape[0], 7) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise TaskDefinitionError(f"out must be a C-contiguous float64 array of shape {(t.shape[0], 7)}")
+        out[:, :3] = t
+        out[:, 3:] = qt
+        self.target_pq = out
+        self.target_poses = None
+        self.transform_target_to_world = None
+
+    def target_array(self) -> Optional[np.ndarray]:
+        """The per-instance target array that is live: ``[B, 12]`` poses, ``[B, 7]`` translation + quaternion, or ``None``."""
+        return self.target_pq if self.target_pq is not None else self.target_poses
+
+    def poses12(self) -> Optional[np.ndarray]:
+        """Per-instance targets as ``[B, 12]`` poses whatever they were given as (the host-evaluated routes read this)."""
+        if self.target_pq is None:
+            return self.target_poses
+        return poses_from_pq(self.target_pq)
 
     def freeze_targets(self) -> None:
         """Declare the per-instance targets set by :meth:`set_target_poses` unchanged until the next ``set_target*`` call:
@@ -94,14 +149,17 @@ class FrameTask(Task):
         The task keeps a READ-ONLY VIEW of the array; the caller's own array object is left as it is (an ``out=`` buffer
         can be handed to the next :meth:`set_target_poses`, which ends the freeze).  The promise is the caller's: a
         write into the buffer while the freeze lasts is NOT seen by the device."""
-        if self.target_poses is None:
+        arr = self.target_array()
+        if arr is None:
             raise TargetNotSet(f"no per-instance targets set for frame '{self.frame}'")
-        arr = self.target_poses
         if getattr(arr, "frozen_token", None) is None:
             view = arr.view(FrozenTargets)
             view.flags.writeable = False  # (the view's flag: the base array stays writeable)
             view.frozen_token = next(_FREEZE_TOKENS)
-            self.target_poses = view
+            if self.target_pq is not None:
+                self.target_pq = view
+            else:
+                self.target_poses = view
 
     def compute_error(self, configuration) -> np.ndarray:
         """Body twist from the frame to its target, ``log6(T_frame^-1 T_target)``

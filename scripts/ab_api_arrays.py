@@ -18,6 +18,7 @@ def main():
     only = os.environ.get("AB_ONLY")  # substring of the labels to run
     for label, kw, split in (("pageable", dict(), "1,1,1,1"),
                              ("page-locked", dict(pinned=True), "1,1,1,1"),
+                             ("page-locked, translation + quaternion targets", dict(pinned=True, quat=True), "1,1,1,1"),
                              ("page-locked, frozen targets, 4 ranges", dict(pinned=True, freeze=True), "1,1,1,1"),
                              ("page-locked, frozen targets, 3 ranges", dict(pinned=True, freeze=True), "1,1,1"),
                              ("page-locked, frozen targets, 2 ranges", dict(pinned=True, freeze=True), "1,1"),

@@ -167,6 +167,11 @@ class EmuSolver:
         self.lib.pinkhip_emu_integrate.argtypes = [vp, ctypes.c_longlong, vp, vp]
         self.lib.pinkhip_emu_integrate(model, B, q, dq)
 
+    def pose_targets(self, B, pq, T):
+        vp = ctypes.c_void_p
+        self.lib.pinkhip_emu_pose_targets.argtypes = [ctypes.c_longlong, vp, vp]
+        self.lib.pinkhip_emu_pose_targets(B, pq, T)
+
     def integrate_checked(self, model, B, q, dq, status, first_failure, step):
         vp = ctypes.c_void_p
         self.lib.pinkhip_emu_integrate_checked.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, ctypes.c_int]

@@ -360,6 +360,11 @@ int pinkhip_emu_integrate(void *mp, long long B, double *q, const double *dq) {
   for (long long t = 0; t < B * m->dev.nj; ++t) pinkhip::ik_integrate_thread(a, t);
   return PINKHIP_OK;
 }
+int pinkhip_emu_pose_targets(long long B, const double *pq, double *T) {
+  pinkhip::PoseTargetsArgs a{B, pq, T};
+  for (long long t = 0; t < B; ++t) pinkhip::ik_pose_targets_thread(a, t);
+  return PINKHIP_OK;
+}
 int pinkhip_emu_integrate_checked(void *mp, long long B, double *q, const double *dq, const int *status,
                                   int *first_failure, int step) {
   EmuModel *m = static_cast<EmuModel *>(mp);

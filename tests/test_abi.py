@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pinkhip_version() == 111
+    assert lib.pinkhip_version() == 112
 
 
 def test_struct_layouts_match_the_header(built):
