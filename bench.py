@@ -513,7 +513,7 @@ def _slice_task(task, n):
     return t
 
 
-def closed_loop_figures(solver, B: int) -> dict:
+def closed_loop_figures(solver, B: int, only=None) -> dict:
     """Device-resident closed loop (pink_amd.rollout.DeviceRollout, the whole control step in one kernel): B robots,
     HIP-event time per step.  Headline shape (nv = 30, 4 FrameTasks + posture) and BASELINE config 4's shape (nv = 50,
     4 FrameTasks + posture + 2 PositionBarriers = 6 barrier rows formed on chip)."""
@@ -525,6 +525,8 @@ def closed_loop_figures(solver, B: int) -> dict:
     for label, model, frames, nbar in (("nv30_4frames_posture", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"], 0),
                                        ("nv30_4frames_posture_2barriers", build_chain(24, free_flyer=True, seed=2), ["tool0", "joint_8", "joint_16", "joint_20"], 2),
                                        ("jvrc_shape_nv50_4frames_posture_2barriers", build_chain(44, free_flyer=True, seed=4), ["tool0", "joint_10", "joint_20", "joint_30"], 2)):
+        if only and only not in label:
+            continue
         rng = np.random.default_rng(1)
         q0 = np.tile(model.neutral(), (B, 1))
         for j in model.joints:

@@ -95,6 +95,15 @@ static __device__ unsigned long long pinkhip_clock[16];  // one copy per transla
 #define PINKHIP_SWEEP_PPM_CRASH 1
 #endif
 // ... and with dense rows: principal pivoting as long as every exchange is regular, the dual method behind it
+// ... and in the whole-step kernels with dense rows: off.  Started all-free (below) principal pivoting takes the dual method's
+// number of trips there (23.10 against 23.14 after a target move at nv = 50 + 6 rows) and the mode per group costs registers:
+// 38 spilled against 15, the converged step 1.73 ms against 1.63 (profiles/ab_ppm_r06.txt)
+#ifndef PINKHIP_ROLLOUT_PPM_DENSE
+#define PINKHIP_ROLLOUT_PPM_DENSE 0
+#endif
+#ifndef PINKHIP_ROLLOUT_PPM_VIRTUAL  // (ik_sweepx.h inside the whole-step kernel: 0.665 against 0.655 ms at nv = 30 + 6 rows)
+#define PINKHIP_ROLLOUT_PPM_VIRTUAL 0
+#endif
 #ifndef PINKHIP_SWEEP_PPM_DENSE
 #define PINKHIP_SWEEP_PPM_DENSE 1
 #endif
@@ -150,7 +159,7 @@ __device__ __forceinline__ int ik_sweep_instance(const KernelArgs &a, long long 
   static_assert((W == 16 || W == 32 || W == 64) && NT <= W && NV % 2 == 0 && MD >= 0, "group of whole rows of 16 lanes");
   constexpr bool DENSE = MD > 0;
   constexpr bool PPM = !DENSE && PINKHIP_SWEEP_PPM;                                  // box-only: the whole iteration
-  constexpr bool PPMD = DENSE && PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE;       // dense rows: in front of the dual method
+  constexpr bool PPMD = DENSE && PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE && (!Src::kOnTheFly || PINKHIP_ROLLOUT_PPM_DENSE);  // dense rows: in front of the dual method
   constexpr bool PPX = PPM || PPMD;
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;

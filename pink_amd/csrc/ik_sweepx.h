@@ -50,7 +50,7 @@ __device__ __forceinline__ int ik_sweepx_instance(const KernelArgs &a, long long
   // principal pivoting from a guessed active set in front of the dual method, as in ik_sweep.h (both roles of a lane take
   // part: `x / -g` of a coordinate and its interval, slack / multiplier of a dense row); the arg-min's 8-bit payload holds
   // lane (5 bits), side, role and "nonbasic"
-  constexpr bool PPX = PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE && PINKHIP_SWEEPX_PPM && W <= 32;
+  constexpr bool PPX = PINKHIP_SWEEP_PPM && PINKHIP_SWEEP_PPM_DENSE && PINKHIP_SWEEPX_PPM && W <= 32 && (!Src::kOnTheFly || PINKHIP_ROLLOUT_PPM_VIRTUAL);
   constexpr bool GUESS = PPX && PINKHIP_SWEEP_PPM_CRASH && !Src::kOnTheFly;  // (the whole-step kernel starts all-free: ik_sweep.h)
   constexpr int G = kWave / W;
   constexpr double INF = INFINITY;
