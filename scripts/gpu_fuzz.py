@@ -28,6 +28,8 @@ for solver in os.environ.get("PINKHIP_FUZZ_KERNELS", "sweep,sweepx,packed").spli
                 n += ps.fuzz(s, [sd], nv_lo=34, nv_hi=61, md_hi=13)
             if sd % 2 == 1:  # weakly regularised objectives
                 n += ps.fuzz(s, [sd], ill=True)
+            if sd % 4 == 1 and solver == "sweep":  # 33 / 34 coordinates behind unbounded leading ones: the instantiation that eliminates two of them
+                n += ps.fuzz(s, [sd], nv_lo=33, nv_hi=35, free_lead=int(2 + sd // 4 % 5))
         except AssertionError as exc:
             bad.append(sd)
             print("  seed", sd, "->", str(exc)[:200], flush=True)

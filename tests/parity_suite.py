@@ -242,10 +242,12 @@ def equality_edge_cases(solver):
     assert (bad.status == 2).all()
 
 
-def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
+def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False, free_lead=0):
     """Random mixes of box bounds (some missing, some with lb == ub), dense inequality rows (some
     duplicated), equalities, LM damping and dimensions; infeasible draws must be reported as such
-    by both sides."""
+    by both sides.  ``free_lead``: the first so many coordinates carry no bound and the draw has no rows (with 33 / 34
+    coordinates: the instantiation that eliminates the leading coordinates, round 6) -- applied after every draw of the
+    seed, so that the seeds of the other shapes keep their problems."""
     n_checked = 0
     n_refuted0 = len(REFUTED)
     for sd in seeds:
@@ -274,6 +276,9 @@ def fuzz(solver, seeds, nv_lo=1, nv_hi=34, md_hi=5, ill=False):
             Gi[:, 1], hi[:, 1] = Gi[:, 0], hi[:, 0] + 0.01
         lm = float(rng.choice([0.0, 0.5]))
         cost = rng.uniform(0.5, 2, size=k)
+        if free_lead:
+            lb[:, :free_lead], ub[:, :free_lead] = -np.inf, np.inf
+            neq, mdi, A, bv, Gi, hi = 0, 0, A[:, :0], bv[:, :0], Gi[:, :0], hi[:, :0]
         # ill: a weak regulariser (posture cost down to 1e-5: cond(H) up to ~1e11) -- the tolerance below follows cond(H)
         dcost = float(10 ** rng.uniform(-5, -1)) if ill else 0.1
         if ill:

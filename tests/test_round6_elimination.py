@@ -78,6 +78,19 @@ def test_undeclared_batches_take_the_wide_group(solver):
     assert np.array_equal(out.status, ref["status"]) and np.abs(out.dq - ref["dq"])[ref["status"] == 0].max() < 1e-10
 
 
+def test_random_problems_behind_unbounded_leading_coordinates(solver):
+    """parity_suite.fuzz at 33 / 34 coordinates with 2 .. 6 unbounded leading ones and no rows: random mixes of bounds (some
+    missing, some pinned), LM damping and batch sizes through the instantiation that eliminates two coordinates --
+    statuses and velocities of the oracle (scripts/gpu_fuzz.py runs thousands of these on the MI355X)."""
+    import parity_suite as ps
+
+    for sd in range(5000, 5012):
+        assert ps.fuzz(solver, [sd], nv_lo=33, nv_hi=35, free_lead=2 + sd % 5) > 0
+    # (the dispatch took the instantiation under test)
+    rng_terms = synthetic.make_terms(_config(34), 3, bounds="tight")
+    assert solver.solve(synthetic.pack(rng_terms)).path.max() == 0
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Round-5 review, item 6(a): the DEVICE route with barrier rows pinned to the reference's rows directly -- not through the
 # host classes.  The whole-step kernel (emulator / MI355X) forms PositionBarrier and BodySphericalBarrier rows on chip; its
