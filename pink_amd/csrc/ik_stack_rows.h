@@ -123,9 +123,10 @@ __device__ __forceinline__ void stack_rows_bcast(const KernelArgs &a, long long 
     static_for<0, RC>([&](auto Kc) {
       constexpr int kk = decltype(Kc)::value;
       if (kk < rc) {  // wave-uniform
-        const BcT rowb = bcast_prepare<W>(cur.r[kk]);
+        // (the row's own uses first: the row copies of the broadcast are then made in its registers)
         const double aa = fma_bcast<W, kk>(0.0, wab, cur.r[kk]);
         ci = fma_bcast<W, kk>(ci, gwb, cur.r[kk]);
+        const BcT rowb = bcast_prepare<W>(cur.r[kk]);
         static_for<0, NV>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
           M[j] = fma_bcast<W, j>(M[j], rowb, aa);

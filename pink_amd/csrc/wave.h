@@ -468,9 +468,14 @@ __device__ __forceinline__ double fma_bcast(double acc, const Bcast<W> &b, doubl
   return acc;
 }
 // the value itself, group-uniform
+// (v_mov_b64 is the one other double-precision instruction that takes the row_newbcast operand: one instruction instead
+// of 0 + value * 1 with its two constants)
 template <int W, int J>
 __device__ __forceinline__ double value_bcast(const Bcast<W> &b) {
-  return fma_bcast<W, J>(0.0, b, 1.0);
+  static_assert(J >= 0 && J < W, "source lane outside the group");
+  double r;
+  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(b.r[J / 16]), "n"(J % 16));
+  return r;
 }
 
 // All-reduce inside each group of W lanes (every lane gets its group's result).
